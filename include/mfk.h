@@ -1,0 +1,182 @@
+/*
+ * mfk.h -- C-ABI of libmfk.so: the MI355X-native flank-discovery kernels ("mustache flank kernels").
+ *
+ * This is the drop-in boundary for the `mustache findflanks` -> `mustache pairflanks` hot path.  The reference
+ * (durrantmm/mustache, pure Python) has no FFI for this path; its boundary is the two Python stage drivers
+ *     _findflanks(...)   mustache/findflanks.py:18-59
+ *     _pairflanks(...)   mustache/pairflanks.py:18-51
+ * and the classes they drive (SoftclipParser findflanks.py:62, SoftclipConsensus findflanks.py:862,
+ * FlankPairer pairflanks.py:54).  Each entry point below names the reference code it replaces.  A ctypes binding is
+ * what a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes, no exceptions: every function returns 0 on success, non-zero on error;
+ *     mfk_last_error(ctx) gives the message.
+ *   - Array pointers inside mfk_reads are DEVICE pointers (e.g. torch.Tensor.data_ptr()), except the two `h_` header
+ *     arrays which are host pointers.  The caller owns every input buffer; result buffers are caller-allocated and
+ *     filled by the *_fetch call after the compute call has reported their sizes (two-call protocol).
+ *   - One ctx per device; calls on one ctx are serialised by the caller.  A ctx owns a HIP stream and a growable
+ *     device workspace.
+ *   - Positions are 0-based reference coordinates, exactly as the reference prints them.
+ */
+#ifndef MFK_H
+#define MFK_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* flags byte of a packed read */
+#define MFK_LKIND(f) ((f) & 3)          /* 0 none, 1 CIGAR S, 2 MD terminal mismatch (sctools.py:25-31)  */
+#define MFK_RKIND(f) (((f) >> 2) & 3)   /* same for the right end (sctools.py:17-23)                      */
+#define MFK_FLAG_COMPLEX 16             /* more than one aligned block: see cx_ / blk_ tables            */
+#define MFK_FLAG_POOL 32                /* query sequence + qualities are in the pool                     */
+
+/* Packed alignments, coordinate-sorted, 24 bytes per read in nine SoA columns (see DESIGN.md "Data layout"). */
+typedef struct mfk_reads {
+    int64_t n_reads;
+    const int32_t *ref_start;      /* pysam reference_start                                              */
+    const int32_t *ref_end;        /* pysam reference_end (exclusive)                                    */
+    const int32_t *link;           /* previous read with the same query name, or -1                      */
+    const uint16_t *contig_id;
+    const uint16_t *qlen;          /* len(query_sequence)                                                */
+    const uint16_t *first_op_len;  /* cigartuples[0][1]  (sctools.py:5-6)                                 */
+    const uint16_t *last_op_len;   /* cigartuples[-1][1] (sctools.py:8-9)                                 */
+    const uint8_t *mapq;
+    const uint8_t *flags;
+    int32_t n_contigs;
+    int32_t max_span;              /* max(ref_end - ref_start) over all reads                            */
+    const int32_t *h_contig_len;         /* HOST, n_contigs   (BAM header LN)                            */
+    const int64_t *h_contig_read_start;  /* HOST, n_contigs+1 (first read of each contig)                */
+    int64_t n_cx;                  /* reads with FLAG_COMPLEX                                            */
+    const uint32_t *cx_read;       /* their read indices, ascending                                      */
+    const uint32_t *cx_off;        /* n_cx+1 offsets into blk_*                                          */
+    int64_t n_blk;
+    const int32_t *blk_start;      /* pysam get_blocks()                                                 */
+    const int32_t *blk_end;
+    const int32_t *blk_ins;        /* query bases in front of the block that are not in a block: insertions (and, for
+                                      the first block, anything but a leading CIGAR S)                    */
+    int64_t n_pool;                /* reads with FLAG_POOL                                               */
+    const uint32_t *pool_read;     /* their read indices, ascending                                      */
+    const uint64_t *pool_off;      /* n_pool+1 base offsets, all even (reads start on byte boundaries)   */
+    const uint8_t *pool_bases;     /* 4-bit BAM base codes "=ACMGRSVTWYHKDBN", base k in byte k>>1, even k in the high
+                                      nibble (the BAM seq encoding)                                      */
+    const uint8_t *pool_quals;     /* one byte per base                                                  */
+} mfk_reads;
+
+/* CLI parameters of both commands (mustache/main.py:68-78, 102-107). */
+typedef struct mfk_params {
+    int32_t min_softclip_length;         /* -minlen   */
+    int32_t min_softclip_count;          /* -mincount */
+    int32_t min_alignment_quality;       /* -minq     */
+    int32_t min_alignment_inner_length;  /* -minial   */
+    int32_t min_distance_to_mate;        /* -mindist  */
+    int32_t large_insertion_cutoff;      /* -lins     */
+    int32_t min_count_consensus;         /* -mcc      */
+    int32_t max_direct_repeat_length;    /* -maxdr    */
+    double min_softclip_ratio;           /* -minratio */
+    double max_indel_ratio;              /* -maxir    */
+    double max_junction_spanning_prop;   /* -maxjsp   */
+} mfk_params;
+
+/* One soft-clip site (the reference's SoftclipSite, findflanks.py:684-859), for stage-level inspection. */
+typedef struct mfk_site {
+    int32_t contig_id;
+    int32_t pos;
+    int32_t softclip_count_5p, softclip_count_3p, runthrough_count;
+    int32_t small_insertion_count_5p, small_insertion_count_3p;
+    int32_t large_insertion_count_5p, large_insertion_count_3p;
+    int32_t deletion_count, upstream_deletion_count, downstream_deletion_count;
+    int32_t keep_5p, keep_3p;
+} mfk_site;
+
+/* One row of the findflanks table (make_dataframe, findflanks.py:631-670). */
+typedef struct mfk_flank {
+    int32_t contig_id;
+    int32_t pos;
+    int32_t orient;                /* 5 or 3 */
+    int32_t softclip_count_5p, softclip_count_3p, runthrough_count;
+    int32_t small_insertion_count_5p, small_insertion_count_3p;
+    int32_t large_insertion_count_5p, large_insertion_count_3p;
+    int32_t deletion_count, upstream_deletion_count, downstream_deletion_count;
+    int32_t total_count;
+    int32_t consensus_softclip_count;
+    int32_t seq_len;
+    int64_t seq_off;               /* consensus_seq = seqs[seq_off .. seq_off+seq_len), ASCII */
+} mfk_flank;
+
+/* One row of the pairflanks table (get_header_list, pairflanks.py:125-130). */
+typedef struct mfk_pair {
+    int32_t contig_id;
+    int32_t pos_5p, pos_3p;
+    int32_t index_5p, index_3p;    /* rows of the flank table (quirk P2) -> seq_5p / seq_3p */
+    int32_t softclip_count_5p, softclip_count_3p;
+    int32_t total_count_5p, total_count_3p;
+    int32_t spanning_count;
+    int32_t has_ir;
+    int32_t ir_length;
+    int32_t ir5_len, ir3_len;      /* -1 = None */
+    int32_t dr_len;                /* len(direct_repeat_reads_consensus) = pos_5p - pos_3p - 1 */
+    int32_t dr_ref_len;            /* len(direct_repeat_reference): same, unless clamped at a contig end */
+    int64_t ir5_off, ir3_off;      /* into strs */
+    int64_t dr_ref_off, dr_reads_off;
+} mfk_pair;
+
+/* stop_after values for mfk_findflanks (the call sequence of _findflanks, findflanks.py:37-49) */
+enum {
+    MFK_STAGE_PARSE = 1,      /* parse_softclips                 findflanks.py:100-121 */
+    MFK_STAGE_MINLENGTH = 2,  /* filter_softclips_minlength      findflanks.py:124-145 */
+    MFK_STAGE_MINCOUNT = 3,   /* filter_softclips_mincount       findflanks.py:148-169 */
+    MFK_STAGE_MINDIST1 = 4,   /* filter_softclips_mindistance    findflanks.py:171-200 */
+    MFK_STAGE_UNCLIPPED = 5,  /* parse_unclipped_read_info       findflanks.py:349-396 */
+    MFK_STAGE_RATIOS = 6,     /* filter_softclips_count_ratios   findflanks.py:203-239 */
+    MFK_STAGE_MINDIST2 = 7,   /* filter_softclips_mindistance (second call)            */
+    MFK_STAGE_CONSENSUS = 8,  /* make_consensus_sequences + 3 consensus filters, findflanks.py:512-532, 241-342 */
+    MFK_STAGE_ALL = 9         /* third filter_softclips_mindistance + make_dataframe   */
+};
+#define MFK_N_STATS 16
+/* stats[0..5]: sites remaining after parse, minlength, mincount, mindistance#1, ratios, mindistance#2;
+ * stats[6..8]: consensus sequences after the minlength, mincount and best-of filters; stats[9]: sites after
+ * mindistance#3; stats[10]: soft-clip events; stats[11]: flank rows. (the reference logs these, findflanks.py:144...) */
+
+typedef struct mfk_ctx mfk_ctx;
+
+/* lifecycle ------------------------------------------------------------------------------------------------ */
+mfk_ctx *mfk_create(int device_id);           /* NULL if no HIP device / out of memory */
+void mfk_destroy(mfk_ctx *ctx);
+const char *mfk_last_error(mfk_ctx *ctx);
+int mfk_version(void);
+
+/* findflanks: replaces SoftclipParser driven as in _findflanks (findflanks.py:24-51).
+ * Runs stages 1..stop_after on the resident arrays.  On return *n_sites is the number of surviving sites, and (when
+ * stop_after == MFK_STAGE_ALL) *n_flanks / *seq_bytes size the flank table. */
+int mfk_findflanks(mfk_ctx *ctx, const mfk_reads *reads, const mfk_params *params, int stop_after,
+                   int64_t *n_sites, int64_t *n_flanks, int64_t *seq_bytes);
+/* copies results of the last mfk_findflanks; any pointer may be NULL */
+int mfk_findflanks_fetch(mfk_ctx *ctx, mfk_site *sites, mfk_flank *flanks, char *seqs, int64_t *stats);
+
+/* pairflanks: replaces FlankPairer.run_pair_flanks (pairflanks.py:96-122).
+ * flanks / flank_seqs: HOST flank table (rows in file order).  h_contig_rank[c] = rank of contig c's name in string
+ * order (the final sort_values(['contig', ...]) of pairflanks.py:248 sorts names).  genome: DEVICE bytes of the FASTA
+ * sequences concatenated in contig order (case preserved, quirk P10), h_genome_off: HOST n_contigs+1 offsets. */
+int mfk_pairflanks(mfk_ctx *ctx, const mfk_reads *reads, const mfk_params *params, const mfk_flank *flanks,
+                   const char *flank_seqs, int64_t n_flanks, const int32_t *h_contig_rank, const uint8_t *genome,
+                   const int64_t *h_genome_off, int64_t *n_pairs, int64_t *str_bytes);
+int mfk_pairflanks_fetch(mfk_ctx *ctx, mfk_pair *pairs, char *strs, int64_t *stats);
+/* pairflanks stats[0]: candidate pairs (pair_all_nearby_flanks), [1]: assigned, [2]: with IR, [3]: spanning_count>0,
+ * [4]: after filter_junction_spanning. */
+
+/* inverted-repeat detection on its own (replaces one einverted run, embosstools.py:8-26 + pairflanks.py:183-213).
+ * seqs: HOST concatenated upper-case sequences, off: n+1 offsets.  out: n x 6 int32:
+ * has_ir, arm1_start, arm1_end, arm2_start, arm2_end (1-based inclusive, einverted convention), n_reported. */
+int mfk_ir_detect(mfk_ctx *ctx, const char *seqs, const int64_t *off, int64_t n, int32_t *out);
+
+/* time spent in device work of the last compute call, milliseconds (HIP events on the ctx stream) */
+double mfk_last_device_ms(mfk_ctx *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MFK_H */

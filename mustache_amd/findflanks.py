@@ -1,0 +1,102 @@
+"""Host side of ``mustache findflanks``: same function name, arguments and TSV as the reference's stage driver
+``_findflanks`` (reference mustache/findflanks.py:18-59); the per-read and per-site work runs in libmfk.so on the GPU.
+
+Flow: BAM decode on the CPU (``bamio``) -> ``pack_reads`` (SoA, 24 B/read) -> device tensors -> ``mfk_findflanks`` ->
+flank rows -> pandas frame with the reference's columns -> ``to_csv(sep='\\t', index=False)``.
+"""
+from __future__ import annotations
+
+import sys
+
+import numpy as np
+import pandas as pd
+
+from . import lib as _lib
+from .pack import PackedReads, pack_reads
+
+FLANK_COLUMNS = ["contig", "pos", "orient", "softclip_count_5p", "softclip_count_3p", "runthrough_count",
+                 "small_insertion_count_5p", "small_insertion_count_3p", "large_insertion_count_5p",
+                 "large_insertion_count_3p", "deletion_count", "upstream_deletion_count", "downstream_deletion_count",
+                 "total_count", "consensus_softclip_count", "consensus_seq"]  # make_dataframe, findflanks.py:633-637
+
+_STAT_MESSAGES = [
+    (1, "After filtering by minimum softclip length of {min_softclip_length:d}, {n:d} sites remain"),
+    (2, "After filtering by minimum softclipped read count of {min_softclip_count:d}, {n:d} sites remain"),
+    (3, "After filtering by minimum nearest mate distance {min_distance_to_mate:d}, {n:d} sites remain"),
+    (4, "After filtering by minimum softclip ratio of {min_softclip_ratio:f} and a maximum indel ratio of "
+        "{max_indel_ratio:f}, {n:d} sites remain"),
+    (5, "After filtering by minimum nearest mate distance {min_distance_to_mate:d}, {n:d} sites remain"),
+    (6, "After filtering consensus sequences by a minimum length of {min_softclip_count:d}, {n:d} flank sequences "
+        "remain"),
+    (7, "After filtering consensus sequences by a minimum softclip count of {min_softclip_count:d}, {n:d} flank "
+        "sequences remain"),
+    (8, "After selecting the best consensus sequence at each site, {n:d} flank sequences remain."),
+    (9, "After filtering by minimum nearest mate distance {min_distance_to_mate:d}, {n:d} sites remain"),
+]
+
+
+def log(msg):
+    print("[mustache_amd] " + msg, file=sys.stderr)
+
+
+def device_reads(binding, packed: PackedReads, device):
+    """Move a PackedReads to ``device`` and describe it to the library."""
+    tensors = packed.to_torch(device)
+    return binding.reads_struct(tensors, packed.n_reads, packed.max_span, _lib.host_header(packed))
+
+
+def flank_frame(result, contig_names):
+    """Result of ``Binding.run_findflanks`` -> DataFrame with the reference's columns and row order."""
+    fl, seqs = result["flanks"], result["seqs"]
+    data = {c: [] for c in FLANK_COLUMNS}
+    for row in fl:
+        data["contig"].append(contig_names[int(row["contig_id"])])
+        data["pos"].append(int(row["pos"]))
+        data["orient"].append("5p" if row["orient"] == 5 else "3p")
+        for c in FLANK_COLUMNS[3:15]:
+            data[c].append(int(row[c]))
+        o, n = int(row["seq_off"]), int(row["seq_len"])
+        data["consensus_seq"].append(seqs[o:o + n].decode("ascii"))
+    df = pd.DataFrame(data, columns=FLANK_COLUMNS)
+    if len(df) == 0:
+        df = pd.DataFrame(columns=FLANK_COLUMNS)
+    return df
+
+
+def findflanks_packed(binding, reads_struct, contig_names, params, sample_id, output_file=None, verbose=True):
+    """The part of ``_findflanks`` after the BAM has been packed and moved to the device."""
+    res = binding.run_findflanks(reads_struct, params)
+    if verbose:
+        pd_ = {k: getattr(params, k) for k, _ in params._fields_}
+        for idx, msg in _STAT_MESSAGES:
+            log(msg.format(n=int(res["stats"][idx]), **pd_))
+    final_df = flank_frame(res, contig_names)
+    final_df.insert(0, "flank_id", list(final_df.index + 1))   # findflanks.py:52
+    final_df.insert(0, "sample", sample_id)                     # findflanks.py:53
+    if output_file:
+        if verbose:
+            log("Saving results to file %s" % output_file)
+        final_df.to_csv(output_file, sep="\t", index=False)     # findflanks.py:57
+    return final_df
+
+
+def _findflanks(bamfile, min_softclip_length, min_softclip_count, min_alignment_quality, min_alignment_inner_length,
+                min_distance_to_mate, min_softclip_ratio, max_indel_ratio, large_insertion_cutoff,
+                min_count_consensus, sample_id, output_file=None, device="cuda:0", verbose=True):
+    """Drop-in for reference findflanks.py:18-59 (same positional arguments)."""
+    from .bamio import BamReader
+    binding = _lib.load(int(str(device).split(":")[1]) if ":" in str(device) else 0)
+    params = _lib.make_params(min_softclip_length=min_softclip_length, min_softclip_count=min_softclip_count,
+                              min_alignment_quality=min_alignment_quality,
+                              min_alignment_inner_length=min_alignment_inner_length,
+                              min_distance_to_mate=min_distance_to_mate, min_softclip_ratio=min_softclip_ratio,
+                              max_indel_ratio=max_indel_ratio, large_insertion_cutoff=large_insertion_cutoff,
+                              min_count_consensus=min_count_consensus)
+    if verbose:
+        log("Parsing softclipped sites from provided BAM file...")
+    with BamReader(bamfile) as bam:
+        packed = pack_reads(bam.contigs, bam, pool="clipped")
+    if verbose:
+        log("Packed %d mapped reads (%.1f MB of records)" % (packed.n_reads, packed.nbytes_hot() / 1e6))
+    rs = device_reads(binding, packed, device)
+    return findflanks_packed(binding, rs, packed.contig_names, params, sample_id, output_file, verbose)

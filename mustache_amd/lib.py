@@ -1,0 +1,214 @@
+"""ctypes binding of the C-ABI declared in ``include/mfk.h``.
+
+``load()`` opens the in-tree HIP library ``mustache_amd/csrc/libmfk.so`` and fails loudly when it is missing or when no
+GPU is present: there is no CPU fallback in the product path.  ``Binding`` itself is a thin, backend-agnostic wrapper
+(symbol prefix + shared object path) so that the test-only CPU oracle, which exports the same signatures under the
+``mfko_`` prefix, can be driven by the same code from ``tests/`` -- the product never loads it.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+N_STATS = 16
+
+STAGE_PARSE, STAGE_MINLENGTH, STAGE_MINCOUNT, STAGE_MINDIST1, STAGE_UNCLIPPED, STAGE_RATIOS, STAGE_MINDIST2, \
+    STAGE_CONSENSUS, STAGE_ALL = range(1, 10)
+
+_p = C.c_void_p
+
+
+class MfkReads(C.Structure):
+    _fields_ = [("n_reads", C.c_int64),
+                ("ref_start", _p), ("ref_end", _p), ("link", _p), ("contig_id", _p), ("qlen", _p),
+                ("first_op_len", _p), ("last_op_len", _p), ("mapq", _p), ("flags", _p),
+                ("n_contigs", C.c_int32), ("max_span", C.c_int32),
+                ("h_contig_len", _p), ("h_contig_read_start", _p),
+                ("n_cx", C.c_int64), ("cx_read", _p), ("cx_off", _p),
+                ("n_blk", C.c_int64), ("blk_start", _p), ("blk_end", _p), ("blk_ins", _p),
+                ("n_pool", C.c_int64), ("pool_read", _p), ("pool_off", _p), ("pool_bases", _p), ("pool_quals", _p)]
+
+
+class MfkParams(C.Structure):
+    _fields_ = [("min_softclip_length", C.c_int32), ("min_softclip_count", C.c_int32),
+                ("min_alignment_quality", C.c_int32), ("min_alignment_inner_length", C.c_int32),
+                ("min_distance_to_mate", C.c_int32), ("large_insertion_cutoff", C.c_int32),
+                ("min_count_consensus", C.c_int32), ("max_direct_repeat_length", C.c_int32),
+                ("min_softclip_ratio", C.c_double), ("max_indel_ratio", C.c_double),
+                ("max_junction_spanning_prop", C.c_double)]
+
+
+SITE_DTYPE = np.dtype([(n, np.int32) for n in (
+    "contig_id", "pos", "softclip_count_5p", "softclip_count_3p", "runthrough_count", "small_insertion_count_5p",
+    "small_insertion_count_3p", "large_insertion_count_5p", "large_insertion_count_3p", "deletion_count",
+    "upstream_deletion_count", "downstream_deletion_count", "keep_5p", "keep_3p")])
+
+FLANK_DTYPE = np.dtype([(n, np.int32) for n in (
+    "contig_id", "pos", "orient", "softclip_count_5p", "softclip_count_3p", "runthrough_count",
+    "small_insertion_count_5p", "small_insertion_count_3p", "large_insertion_count_5p", "large_insertion_count_3p",
+    "deletion_count", "upstream_deletion_count", "downstream_deletion_count", "total_count",
+    "consensus_softclip_count", "seq_len")] + [("seq_off", np.int64)])
+
+PAIR_DTYPE = np.dtype([(n, np.int32) for n in (
+    "contig_id", "pos_5p", "pos_3p", "index_5p", "index_3p", "softclip_count_5p", "softclip_count_3p",
+    "total_count_5p", "total_count_3p", "spanning_count", "has_ir", "ir_length", "ir5_len", "ir3_len", "dr_len",
+    "dr_ref_len")] + [(n, np.int64) for n in ("ir5_off", "ir3_off", "dr_ref_off", "dr_reads_off")])
+
+assert SITE_DTYPE.itemsize == 56 and FLANK_DTYPE.itemsize == 72 and PAIR_DTYPE.itemsize == 96
+
+# CLI defaults are authoritative (reference main.py:68-78, 102-107), not the class defaults
+DEFAULT_PARAMS = dict(min_softclip_length=8, min_softclip_count=2, min_alignment_quality=20,
+                      min_alignment_inner_length=21, min_distance_to_mate=22, large_insertion_cutoff=30,
+                      min_count_consensus=2, max_direct_repeat_length=20, min_softclip_ratio=0.10,
+                      max_indel_ratio=0.03, max_junction_spanning_prop=0.15)
+
+
+def make_params(**kw):
+    d = dict(DEFAULT_PARAMS)
+    for k, v in kw.items():
+        if k not in d:
+            raise TypeError("unknown parameter %r" % k)
+        d[k] = v
+    return MfkParams(**d)
+
+
+class MfkError(RuntimeError):
+    pass
+
+
+def _ptr(x):
+    """Device or host address of a tensor / array (None -> NULL)."""
+    if x is None:
+        return None
+    if hasattr(x, "data_ptr"):
+        return x.data_ptr()
+    return x.ctypes.data
+
+
+class Binding:
+    """One ctx of one shared object exporting the include/mfk.h signatures under ``prefix``."""
+
+    def __init__(self, path, prefix, device_id=0):
+        if not os.path.exists(path):
+            raise MfkError("shared library %s is missing: build it first (python -c 'import __graft_entry__ as g; "
+                           "g.build()')" % path)
+        self.path, self.prefix = path, prefix
+        self.so = C.CDLL(path)
+        f = self._fn
+        f("create", _p, [C.c_int])
+        f("destroy", None, [_p])
+        f("last_error", C.c_char_p, [_p])
+        f("version", C.c_int, [])
+        f("last_device_ms", C.c_double, [_p])
+        f("findflanks", C.c_int, [_p, C.POINTER(MfkReads), C.POINTER(MfkParams), C.c_int, C.POINTER(C.c_int64),
+                                  C.POINTER(C.c_int64), C.POINTER(C.c_int64)])
+        f("findflanks_fetch", C.c_int, [_p, _p, _p, _p, _p])
+        f("pairflanks", C.c_int, [_p, C.POINTER(MfkReads), C.POINTER(MfkParams), _p, _p, C.c_int64, _p, _p, _p,
+                                  C.POINTER(C.c_int64), C.POINTER(C.c_int64)])
+        f("pairflanks_fetch", C.c_int, [_p, _p, _p, _p])
+        f("ir_detect", C.c_int, [_p, _p, _p, C.c_int64, _p])
+        self.ctx = self.create(device_id)
+        if not self.ctx:
+            raise MfkError("%screate(%d) failed: no usable HIP device for %s" % (prefix, device_id, path))
+
+    def _fn(self, name, restype, argtypes):
+        fn = getattr(self.so, self.prefix + name)
+        fn.restype, fn.argtypes = restype, argtypes
+        setattr(self, name, fn)
+
+    def close(self):
+        if getattr(self, "ctx", None):
+            self.destroy(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc != 0:
+            msg = self.last_error(self.ctx)
+            raise MfkError("%s error %d: %s" % (self.prefix, rc, msg.decode() if msg else "?"))
+
+    # ------------------------------------------------------------------------------------------------------
+    def reads_struct(self, arrays, n_reads, max_span, host_hdr):
+        """arrays: dict name -> torch tensor (device) or numpy array (host oracle).  host_hdr: the numpy
+        contig_len / contig_read_start arrays (always host).  Keeps references alive on the returned struct."""
+        r = MfkReads()
+        r.n_reads = n_reads
+        for k in ("ref_start", "ref_end", "link", "contig_id", "qlen", "first_op_len", "last_op_len", "mapq", "flags",
+                  "cx_read", "cx_off", "blk_start", "blk_end", "blk_ins", "pool_read", "pool_off", "pool_bases",
+                  "pool_quals"):
+            setattr(r, k, _ptr(arrays[k]))
+        clen = np.ascontiguousarray(host_hdr["contig_len"], dtype=np.int32)
+        crs = np.ascontiguousarray(host_hdr["contig_read_start"], dtype=np.int64)
+        r.n_contigs = int(clen.shape[0])
+        r.max_span = int(max_span)
+        r.h_contig_len, r.h_contig_read_start = clen.ctypes.data, crs.ctypes.data
+        r.n_cx = int(host_hdr["n_cx"])
+        r.n_blk = int(host_hdr["n_blk"])
+        r.n_pool = int(host_hdr["n_pool"])
+        r._keep = (arrays, clen, crs)
+        return r
+
+    def run_findflanks(self, reads, params, stop_after=STAGE_ALL):
+        ns, nf, sb = C.c_int64(0), C.c_int64(0), C.c_int64(0)
+        self._check(self.findflanks(self.ctx, C.byref(reads), C.byref(params), stop_after, C.byref(ns), C.byref(nf),
+                                    C.byref(sb)))
+        sites = np.zeros(ns.value, dtype=SITE_DTYPE)
+        flanks = np.zeros(nf.value, dtype=FLANK_DTYPE)
+        seqs = np.zeros(max(sb.value, 1), dtype=np.uint8)
+        stats = np.zeros(N_STATS, dtype=np.int64)
+        self._check(self.findflanks_fetch(self.ctx, sites.ctypes.data, flanks.ctypes.data, seqs.ctypes.data,
+                                          stats.ctypes.data))
+        return {"sites": sites, "flanks": flanks, "seqs": seqs[:sb.value].tobytes(), "stats": stats}
+
+    def run_pairflanks(self, reads, params, flanks, flank_seqs, contig_rank, genome, genome_off):
+        """flanks: FLANK_DTYPE array (host); flank_seqs: bytes; genome: device tensor / host array of bytes."""
+        flanks = np.ascontiguousarray(flanks, dtype=FLANK_DTYPE)
+        fs = np.frombuffer(flank_seqs + b"\0", dtype=np.uint8)
+        rank = np.ascontiguousarray(contig_rank, dtype=np.int32)
+        goff = np.ascontiguousarray(genome_off, dtype=np.int64)
+        npairs, sb = C.c_int64(0), C.c_int64(0)
+        self._check(self.pairflanks(self.ctx, C.byref(reads), C.byref(params), flanks.ctypes.data, fs.ctypes.data,
+                                    flanks.shape[0], rank.ctypes.data, _ptr(genome), goff.ctypes.data,
+                                    C.byref(npairs), C.byref(sb)))
+        pairs = np.zeros(npairs.value, dtype=PAIR_DTYPE)
+        strs = np.zeros(max(sb.value, 1), dtype=np.uint8)
+        stats = np.zeros(N_STATS, dtype=np.int64)
+        self._check(self.pairflanks_fetch(self.ctx, pairs.ctypes.data, strs.ctypes.data, stats.ctypes.data))
+        return {"pairs": pairs, "strs": strs[:sb.value].tobytes(), "stats": stats}
+
+    def run_ir_detect(self, seqs):
+        """seqs: list of str -> int32 array [n, 6]: has_ir, arm1 start/end, arm2 start/end (1-based), n_reported."""
+        blob = "".join(seqs).encode() + b"\0"
+        off = np.zeros(len(seqs) + 1, dtype=np.int64)
+        off[1:] = np.cumsum([len(s) for s in seqs])
+        out = np.zeros((len(seqs), 6), dtype=np.int32)
+        buf = np.frombuffer(blob, dtype=np.uint8)
+        self._check(self.ir_detect(self.ctx, buf.ctypes.data, off.ctypes.data, len(seqs), out.ctypes.data))
+        return out
+
+    def device_ms(self):
+        return float(self.last_device_ms(self.ctx))
+
+
+def host_header(packed):
+    a = packed.a
+    return {"contig_len": a["contig_len"], "contig_read_start": a["contig_read_start"],
+            "n_cx": a["cx_read"].shape[0], "n_blk": a["blk_start"].shape[0], "n_pool": a["pool_read"].shape[0]}
+
+
+LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libmfk.so")
+_loaded = {}
+
+
+def load(device_id=0):
+    """The HIP library on ``device_id``.  Raises MfkError when the extension is not built or no GPU is usable."""
+    if device_id not in _loaded:
+        _loaded[device_id] = Binding(LIB_PATH, "mfk_", device_id)
+    return _loaded[device_id]

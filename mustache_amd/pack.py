@@ -1,0 +1,284 @@
+"""Host-side packer: alignment records -> structure-of-arrays the HIP kernels (and the CPU oracle) consume.
+
+This is the only place where CIGAR strings and MD tags are looked at.  It reproduces, per read, the predicates of the
+reference's ``sctools.py`` so the device never needs strings:
+
+* ``lkind`` / ``rkind`` -- "lenient" soft-clip kind of the left / right end (``sctools.py:17-31``):
+  0 = not clipped, 1 = CIGAR ``S`` at that end, 2 = no ``S`` but the MD tag says the terminal aligned base is a
+  mismatch (left: ``MD[0] == '0'``; right: ``MD[-1] == '0' and not MD[-2].isdigit()``).
+* ``first_op_len`` / ``last_op_len`` -- raw length of the first / last CIGAR op *whatever its type* (quirk Q1,
+  ``sctools.py:5-9``): this is what ``meets_minlength`` compares.
+* site coordinates follow ``sctools.py:99-109``: right S -> ``reference_end``; right mismatch -> ``reference_end-1``;
+  left S -> ``reference_start-1``; left mismatch -> ``reference_start``.  (The packer verifies that the first / last
+  reference-consuming op is an aligned op, so first/last aligned position == reference_start / reference_end-1.)
+* clipped sequence (``sctools.py:111-157``): kind 1 -> the ``S`` bases; kind 2 -> the single terminal *query* base.
+
+Layout (one entry per mapped read, BAM order = coordinate order), 24 bytes per read:
+
+    ref_start i32 | ref_end i32 | link i32 | contig_id u16 | qlen u16 | first_op_len u16 | last_op_len u16 |
+    mapq u8 | flags u8
+
+``link`` is the index of the previous read with the same query name (-1 if none): every "count distinct query names"
+in the reference (quirk Q3) becomes "count reads whose name-chain holds no earlier qualifying read", which needs no
+hashing or sorting on the device.
+
+Side tables: ``cx_*`` / ``blk_*`` hold the aligned blocks of reads whose CIGAR is more than ``[H][S]M[S][H]``
+(12 B per block); ``pool_*`` holds full query sequences (4-bit BAM base codes, two per byte, BAM nibble order, every read starting
+on a byte boundary so BAM seq bytes copy straight in) and qualities for the reads
+that need them (clipped reads for findflanks; reads over direct-repeat windows for pairflanks).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from .records import (CDEL, CDIFF, CEQUAL, CHARD_CLIP, CINS, CMATCH, CPAD, CREF_SKIP, CSOFT_CLIP, BASE_TO_CODE)
+
+FLAG_LKIND_SHIFT = 0
+FLAG_RKIND_SHIFT = 2
+FLAG_COMPLEX = 1 << 4
+FLAG_POOL = 1 << 5
+
+_HOT_FIELDS = (("ref_start", np.int32), ("ref_end", np.int32), ("link", np.int32), ("contig_id", np.uint16),
+               ("qlen", np.uint16), ("first_op_len", np.uint16), ("last_op_len", np.uint16), ("mapq", np.uint8),
+               ("flags", np.uint8))
+_SIDE_FIELDS = (("contig_len", np.int32), ("contig_read_start", np.int64), ("cx_read", np.uint32),
+                ("cx_off", np.uint32), ("blk_start", np.int32), ("blk_end", np.int32), ("blk_ins", np.int32),
+                ("pool_read", np.uint32), ("pool_off", np.uint64), ("pool_bases", np.uint8), ("pool_quals", np.uint8))
+ALL_FIELDS = _HOT_FIELDS + _SIDE_FIELDS
+BYTES_PER_READ = sum(np.dtype(t).itemsize for _, t in _HOT_FIELDS)  # 24
+
+
+class PackError(ValueError):
+    pass
+
+
+def clip_kinds(cigartuples, md):
+    """(lkind, rkind) per ``sctools.is_{left,right}_softclipped_lenient`` (reference sctools.py:17-31)."""
+    if cigartuples[0][0] == CSOFT_CLIP:
+        lkind = 1
+    else:
+        if md is None:
+            raise PackError("read without MD tag: the reference's lenient soft-clip test needs it (sctools.py:28)")
+        lkind = 2 if md[0] == "0" else 0
+    if cigartuples[-1][0] == CSOFT_CLIP:
+        rkind = 1
+    else:
+        if md is None:
+            raise PackError("read without MD tag: the reference's lenient soft-clip test needs it (sctools.py:20)")
+        rkind = 2 if (md[-1] == "0" and len(md) >= 2 and not md[-2].isdigit()) else 0
+    return lkind, rkind
+
+
+def _blocks_with_insertions(read):
+    """Aligned blocks as pysam ``get_blocks`` gives them, plus the number of inserted query bases in front of each."""
+    blocks, ins, pos, pending = [], [], read.reference_start, 0
+    for k, (op, l) in enumerate(read.cigartuples):
+        if op in (CMATCH, CEQUAL, CDIFF):
+            blocks.append((pos, pos + l))
+            ins.append(pending)
+            pending = 0
+            pos += l
+        elif op == CINS or (op == CSOFT_CLIP and k > 0 and not blocks):
+            pending += l  # a leading S that is not the first op (after H) still occupies query bases
+        elif op in (CDEL, CREF_SKIP):
+            pos += l
+    return blocks, ins
+
+
+class PackedReads:
+    """The SoA arrays plus header information.  Arrays are numpy on the host; ``to_torch`` moves them to a device."""
+
+    def __init__(self, contig_names, arrays, max_span, read_names=None):
+        self.contig_names = list(contig_names)
+        self.a = arrays
+        self.max_span = int(max_span)
+        self.read_names = read_names  # optional, host only (debugging)
+
+    @property
+    def n_reads(self):
+        return int(self.a["ref_start"].shape[0])
+
+    def __getattr__(self, name):
+        a = self.__dict__.get("a")
+        if a is not None and name in a:
+            return a[name]
+        raise AttributeError(name)
+
+    def nbytes_hot(self):
+        return self.n_reads * BYTES_PER_READ
+
+    def save(self, path):
+        np.savez(path, contig_names=np.array(self.contig_names), max_span=np.int64(self.max_span), **self.a)
+
+    @staticmethod
+    def load(path):
+        z = np.load(path, allow_pickle=False)
+        arrays = {k: z[k] for k, _ in ALL_FIELDS}
+        return PackedReads([str(s) for s in z["contig_names"]], arrays, int(z["max_span"]))
+
+    def slice_reads(self, lo, hi):
+        """Reads [lo, hi) as a self-contained PackedReads (links pointing outside the slice become -1)."""
+        a = self.a
+        out = {}
+        for k, _ in _HOT_FIELDS:
+            out[k] = a[k][lo:hi].copy()
+        link = out["link"].astype(np.int64) - lo
+        link[link < 0] = -1
+        out["link"] = link.astype(np.int32)
+        out["contig_len"] = a["contig_len"].copy()
+        out["contig_read_start"] = np.clip(a["contig_read_start"] - lo, 0, hi - lo).astype(np.int64)
+        c0, c1 = np.searchsorted(a["cx_read"], [lo, hi])
+        out["cx_read"] = (a["cx_read"][c0:c1] - lo).astype(np.uint32)
+        b0, b1 = int(a["cx_off"][c0]), int(a["cx_off"][c1])
+        out["cx_off"] = (a["cx_off"][c0:c1 + 1] - b0).astype(np.uint32)
+        for k in ("blk_start", "blk_end", "blk_ins"):
+            out[k] = a[k][b0:b1].copy()
+        p0, p1 = np.searchsorted(a["pool_read"], [lo, hi])
+        out["pool_read"] = (a["pool_read"][p0:p1] - lo).astype(np.uint32)
+        o0, o1 = int(a["pool_off"][p0]), int(a["pool_off"][p1])
+        ob = o0  # pooled reads start on byte boundaries (even base offsets)
+        out["pool_off"] = (a["pool_off"][p0:p1 + 1] - ob).astype(np.uint64)
+        out["pool_bases"] = a["pool_bases"][ob // 2:(o1 + 1) // 2].copy()
+        out["pool_quals"] = a["pool_quals"][ob:o1].copy()
+        return PackedReads(self.contig_names, out, self.max_span)
+
+    def pool_sequence(self, read_idx):
+        """(sequence str, qualities list) of a pooled read; host-side helper for tests."""
+        from .records import BASE_CODES
+        k = int(np.searchsorted(self.a["pool_read"], read_idx))
+        if k >= len(self.a["pool_read"]) or self.a["pool_read"][k] != read_idx:
+            return None
+        o0 = int(self.a["pool_off"][k])
+        o1 = o0 + int(self.a["qlen"][read_idx])
+        idx = np.arange(o0, o1)
+        nib = (self.a["pool_bases"][idx >> 1] >> ((~idx & 1) * 4)) & 15
+        return "".join(BASE_CODES[c] for c in nib), [int(q) for q in self.a["pool_quals"][o0:o1]]
+
+    def to_torch(self, device):
+        import torch
+        out = {}
+        for k, _ in ALL_FIELDS:
+            arr = np.ascontiguousarray(self.a[k])
+            # torch has no uint16/32/64 arithmetic but can hold the bits; reinterpret as signed of the same width
+            view = {np.dtype(np.uint16): np.int16, np.dtype(np.uint32): np.int32,
+                    np.dtype(np.uint64): np.int64}.get(arr.dtype)
+            if view is not None:
+                arr = arr.view(view)
+            t = torch.from_numpy(arr)
+            if t.numel() == 0:
+                t = torch.zeros(1, dtype=t.dtype)  # keep a valid pointer
+            out[k] = t.to(device)
+        return out
+
+
+def pack_reads(contigs, reads, pool="clipped", keep_names=False):
+    """Pack mapped reads (an iterable of ``AlignedRead``-like objects in BAM order).
+
+    contigs: list of (name, length) from the BAM header.
+    pool:    'clipped' (findflanks), 'all', 'none', or a callable(read, contig_id) -> bool (pairflanks windows).
+    """
+    contig_index = {n: i for i, (n, _) in enumerate(contigs)}
+    if len(contigs) > 65535:
+        raise PackError("more than 65535 contigs")
+    cols = {k: [] for k, _ in _HOT_FIELDS}
+    cx_read, cx_off, blk_start, blk_end, blk_ins = [], [0], [], [], []
+    pool_read, pool_off, pool_codes, pool_quals = [], [0], [], []
+    last_by_name, names = {}, []
+    max_span, prev_key, n = 0, (-1, -1), 0
+    for read in reads:
+        ct = read.cigartuples
+        if ct is None or len(ct) == 0 or (getattr(read, "flag", 0) & 4):
+            continue  # unmapped: mapping quality 0 in the reference, never reaches the CIGAR (quirk Q17)
+        cid = contig_index[read.reference_name]
+        key = (cid, read.reference_start)
+        if key < prev_key:
+            raise PackError("alignments are not coordinate-sorted (the reference needs a sorted, indexed BAM)")
+        prev_key = key
+        md = read.tags.get("MD") if hasattr(read, "tags") else read.get_tag("MD")
+        lkind, rkind = clip_kinds(ct, md)
+        # strip clips to find the alignment core
+        lo, hi = 0, len(ct)
+        while lo < hi and ct[lo][0] in (CHARD_CLIP, CSOFT_CLIP):
+            lo += 1
+        while hi > lo and ct[hi - 1][0] in (CHARD_CLIP, CSOFT_CLIP):
+            hi -= 1
+        core = [(op, l) for op, l in ct[lo:hi] if op != CPAD]
+        if not core:
+            raise PackError("alignment without aligned bases: %r" % (read,))
+        for op, _ in core:
+            if op in (CHARD_CLIP, CSOFT_CLIP):
+                raise PackError("clip operation inside an alignment: %r" % (read,))
+        ref_ops = [op for op, _ in core if op != CINS]
+        if not ref_ops or ref_ops[0] in (CDEL, CREF_SKIP) or ref_ops[-1] in (CDEL, CREF_SKIP):
+            raise PackError("alignment starts or ends with a deletion/skip: unsupported (%r)" % (read,))
+        simple = len(core) == 1 and not (lo > 0 and ct[0][0] == CHARD_CLIP and ct[lo - 1][0] == CSOFT_CLIP)
+        seq = read.query_sequence or ""
+        qlen = len(seq)
+        if qlen > 65535:
+            raise PackError("query longer than 65535 bases")
+        rend = read.reference_end
+        span = rend - read.reference_start
+        if span > max_span:
+            max_span = span
+        flags = (lkind << FLAG_LKIND_SHIFT) | (rkind << FLAG_RKIND_SHIFT)
+        if not simple:
+            flags |= FLAG_COMPLEX
+            blocks, ins = _blocks_with_insertions(read)
+            cx_read.append(n)
+            for (s, e), i in zip(blocks, ins):
+                blk_start.append(s)
+                blk_end.append(e)
+                blk_ins.append(i)
+            cx_off.append(len(blk_start))
+        if callable(pool):
+            want = pool(read, cid)
+        else:
+            want = pool == "all" or (pool == "clipped" and (lkind or rkind))
+        if want and qlen:
+            flags |= FLAG_POOL
+            pool_read.append(n)
+            plen = qlen + (qlen & 1)  # every pooled read starts on a byte boundary of the nibble stream
+            codes = np.zeros(plen, dtype=np.uint8)
+            codes[:qlen] = np.fromiter((BASE_TO_CODE.get(c, 15) for c in seq), dtype=np.uint8, count=qlen)
+            pool_codes.append(codes)
+            q = read.query_qualities
+            quals = np.zeros(plen, dtype=np.uint8)
+            if q is not None:
+                quals[:qlen] = np.asarray(q, dtype=np.uint8)
+            pool_quals.append(quals)
+            pool_off.append(pool_off[-1] + plen)
+        cols["ref_start"].append(read.reference_start)
+        cols["ref_end"].append(rend)
+        cols["link"].append(last_by_name.get(read.query_name, -1))
+        last_by_name[read.query_name] = n
+        cols["contig_id"].append(cid)
+        cols["qlen"].append(qlen)
+        cols["first_op_len"].append(min(ct[0][1], 65535))
+        cols["last_op_len"].append(min(ct[-1][1], 65535))
+        cols["mapq"].append(read.mapping_quality)
+        cols["flags"].append(flags)
+        if keep_names:
+            names.append(read.query_name)
+        n += 1
+    arrays = {k: np.asarray(cols[k], dtype=t) for k, t in _HOT_FIELDS}
+    arrays["contig_len"] = np.asarray([l for _, l in contigs], dtype=np.int32)
+    arrays["contig_read_start"] = np.searchsorted(arrays["contig_id"], np.arange(len(contigs) + 1)).astype(np.int64)
+    arrays["cx_read"] = np.asarray(cx_read, dtype=np.uint32)
+    arrays["cx_off"] = np.asarray(cx_off, dtype=np.uint32)
+    arrays["blk_start"] = np.asarray(blk_start, dtype=np.int32)
+    arrays["blk_end"] = np.asarray(blk_end, dtype=np.int32)
+    arrays["blk_ins"] = np.asarray(blk_ins, dtype=np.int32)
+    arrays["pool_read"] = np.asarray(pool_read, dtype=np.uint32)
+    arrays["pool_off"] = np.asarray(pool_off, dtype=np.uint64)
+    codes = np.concatenate(pool_codes) if pool_codes else np.zeros(0, np.uint8)
+    arrays["pool_bases"] = pack_nibbles(codes)
+    arrays["pool_quals"] = np.concatenate(pool_quals) if pool_quals else np.zeros(0, np.uint8)
+    return PackedReads([n_ for n_, _ in contigs], arrays, max_span, names if keep_names else None)
+
+
+def pack_nibbles(codes):
+    """4-bit base codes -> bytes in BAM order: base k in byte k>>1, even k in the HIGH nibble."""
+    codes = np.asarray(codes, dtype=np.uint8)
+    if codes.size & 1:
+        codes = np.concatenate([codes, np.zeros(1, np.uint8)])
+    return ((codes[0::2] << 4) | codes[1::2]).astype(np.uint8)

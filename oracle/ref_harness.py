@@ -1,0 +1,179 @@
+"""BUILD-CONTAINER ONLY (never runs on the GPU box: /root/reference does not exist there).
+
+Imports the real reference (durrantmm/mustache at /root/reference) with the third-party modules that are absent from
+this image replaced by tiny stand-ins in ``sys.modules``, feeds it duck-typed alignments
+(``mustache_amd.records.ReadSet``) and returns what it computes.  ``tests/golden/make_golden.py`` uses this to
+generate the committed golden vectors; nothing else imports it.
+
+Stand-ins (all for modules the reference imports but whose arithmetic is not under test here):
+  pysam.AlignmentFile   -> returns a registered ReadSet (iteration, fetch, header['SQ'])
+  jellyfish             -> textbook unit-cost Levenshtein distance (what jellyfish.levenshtein_distance computes)
+  pygogo                -> logger that records messages (the "N sites remain" counters are parity probes)
+  snakemake.shell       -> no-op (only used to run einverted / rm)
+  Bio.SeqIO.parse       -> yields records of a registered genome dict
+The one thing the reference cannot do here is run EMBOSS ``einverted`` (pairflanks.py:194): the harness replaces
+``embosstools.run_einverted`` / ``read_emboss_seq_results`` by a caller-supplied repeat finder, so the reference's own
+acceptance logic (pairflanks.py:196-213, 253-266) still runs on the candidates.  IR parity stays UNPINNED.
+"""
+import re
+import sys
+import types
+
+sys.dont_write_bytecode = True  # /root/reference is read-only territory: never write __pycache__ into it
+REF_ROOT = "/root/reference"
+
+_registry = {"bam": {}, "genome": {}}
+_log = []
+
+
+def _levenshtein(a, b):
+    prev = list(range(len(b) + 1))
+    for i, ca in enumerate(a, 1):
+        cur = [i]
+        for j, cb in enumerate(b, 1):
+            cur.append(min(prev[j - 1] + (ca != cb), prev[j] + 1, cur[j - 1] + 1))
+        prev = cur
+    return prev[-1]
+
+
+class _Logger:
+    def info(self, msg, *a):
+        _log.append(msg % a if a else msg)
+
+    warning = error = debug = info
+
+
+def install_stubs():
+    if "mustache" in sys.modules:
+        return
+    m = types.ModuleType("pysam")
+    m.AlignmentFile = lambda path, mode="rb": _registry["bam"][path]
+    sys.modules["pysam"] = m
+    m = types.ModuleType("jellyfish")
+    m.levenshtein_distance = _levenshtein
+    sys.modules["jellyfish"] = m
+    m = types.ModuleType("pygogo")
+
+    class Gogo:
+        def __init__(self, name=None, verbose=False, **kw):
+            self.logger = _Logger()
+    m.Gogo = Gogo
+    sys.modules["pygogo"] = m
+    m = types.ModuleType("snakemake")
+    m.shell = lambda *a, **k: None
+    sys.modules["snakemake"] = m
+    bio = types.ModuleType("Bio")
+    seqio = types.ModuleType("Bio.SeqIO")
+
+    class _Rec:
+        def __init__(self, id_, seq):
+            self.id, self.seq = id_, seq
+
+    def parse(path, fmt):
+        for name, seq in _registry["genome"][path].items():
+            yield _Rec(name, seq)
+    seqio.parse = parse
+    seqio.write = lambda *a, **k: None
+    bio.SeqIO = seqio
+    for sub, attrs in (("Seq", {"Seq": lambda s, *a: s}), ("SeqRecord", {"SeqRecord": lambda *a, **k: None}),
+                       ("Alphabet", {"IUPAC": types.SimpleNamespace(IUPACAmbiguousDNA=None)})):
+        mod = types.ModuleType("Bio." + sub)
+        for k, v in attrs.items():
+            setattr(mod, k, v)
+        sys.modules["Bio." + sub] = mod
+        setattr(bio, sub, mod)
+    sys.modules["Bio"] = bio
+    sys.modules["Bio.SeqIO"] = seqio
+    if REF_ROOT not in sys.path:
+        sys.path.insert(0, REF_ROOT)
+
+
+FINDFLANKS_DEFAULTS = dict(min_softclip_length=8, min_softclip_count=2, min_alignment_quality=20,
+                           min_alignment_inner_length=21, min_distance_to_mate=22, min_softclip_ratio=0.10,
+                           max_indel_ratio=0.03, large_insertion_cutoff=30, min_count_consensus=2)
+PAIRFLANKS_DEFAULTS = dict(max_direct_repeat_length=20, min_alignment_quality=20, min_alignment_inner_length=21,
+                           max_junction_spanning_prop=0.15, large_insertion_cutoff=30)
+
+
+def _stats_from_log():
+    out = []
+    for msg in _log:
+        m = re.search(r"(\d+) (sites remain|flank sequences remain)", msg)
+        if m:
+            out.append(int(m.group(1)))
+    return out
+
+
+def run_findflanks(readset, sample_id="sample", output_file=None, **params):
+    """Run the reference's _findflanks on a ReadSet.  Returns (DataFrame, TSV text, list of logged counters)."""
+    install_stubs()
+    from mustache.findflanks import _findflanks
+    p = dict(FINDFLANKS_DEFAULTS)
+    p.update(params)
+    key = "__readset_%d.bam" % id(readset)
+    _registry["bam"][key] = readset
+    del _log[:]
+    try:
+        df = _findflanks(key, p["min_softclip_length"], p["min_softclip_count"], p["min_alignment_quality"],
+                         p["min_alignment_inner_length"], p["min_distance_to_mate"], p["min_softclip_ratio"],
+                         p["max_indel_ratio"], p["large_insertion_cutoff"], p["min_count_consensus"], sample_id,
+                         output_file)
+    finally:
+        del _registry["bam"][key]
+    return df, df.to_csv(sep="\t", index=False), _stats_from_log()
+
+
+def run_pairflanks(flanks_tsv_path, readset, genome, ir_finder, output_file, **params):
+    """Run the reference's _pairflanks.  ``ir_finder(seq) -> [(a1s, a1e, a2s, a2e), ...]`` (1-based inclusive arms in
+    report order) stands in for the einverted binary.  Returns (DataFrame, TSV text)."""
+    install_stubs()
+    import numpy as np
+    import pandas as pd
+    from mustache import pairflanks as pf, embosstools, fastatools
+    p = dict(PAIRFLANKS_DEFAULTS)
+    p.update(params)
+    bkey, gkey = "__readset_%d.bam" % id(readset), "__genome_%d.fa" % id(genome)
+    _registry["bam"][bkey], _registry["genome"][gkey] = readset, genome
+    state = {}
+
+    def write_sequences_to_fasta(sequences, fasta, names=None):
+        state["seq"] = sequences[0]
+
+    def run_einverted(fasta, **kw):
+        state["irs"] = ir_finder(state["seq"])
+
+    def read_emboss_seq_results(path):
+        s = state["seq"]
+        for a1s, a1e, a2s, a2e in state["irs"]:
+            yield [pd.Series({"ir_pos_5p": a1s, "ir_pos_3p": a1e, "seq": s[a1s - 1:a1e]}),
+                   pd.Series({"ir_pos_5p": a2s, "ir_pos_3p": a2e, "seq": s[a2s - 1:a2e]})]
+
+    orig = (fastatools.write_sequences_to_fasta, embosstools.run_einverted, embosstools.read_emboss_seq_results,
+            pf.FlankPairer.assign_pairs)
+    fastatools.write_sequences_to_fasta = write_sequences_to_fasta
+    embosstools.run_einverted = run_einverted
+    embosstools.read_emboss_seq_results = read_emboss_seq_results
+
+    def assign_pairs(self, pairs):
+        # pandas 0.23 (the reference's pin) reindexes on .loc[:, missing_labels]; newer pandas raises KeyError
+        # (pairflanks.py:247-248).  Pre-seeding the four late columns reproduces the 0.23 behaviour.
+        for col in ("pair_id", "spanning_count", "direct_repeat_reference", "direct_repeat_reads_consensus"):
+            pairs[col] = np.nan
+        return orig[3](self, pairs)
+    pf.FlankPairer.assign_pairs = assign_pairs
+    del _log[:]
+    try:
+        df = pf._pairflanks(flanks_tsv_path, bkey, gkey, p["max_direct_repeat_length"], p["min_alignment_quality"],
+                            p["min_alignment_inner_length"], p["max_junction_spanning_prop"],
+                            p["large_insertion_cutoff"], output_file)
+    finally:
+        (fastatools.write_sequences_to_fasta, embosstools.run_einverted, embosstools.read_emboss_seq_results,
+         pf.FlankPairer.assign_pairs) = orig
+        del _registry["bam"][bkey], _registry["genome"][gkey]
+    return df, open(output_file).read()
+
+
+def reference_modules():
+    install_stubs()
+    from mustache import sctools, misc, flanktrie, pysamtools
+    return sctools, misc, flanktrie, pysamtools
