@@ -34,7 +34,7 @@ extern "C" {
 #define MFK_FLAG_COMPLEX 16             /* more than one aligned block: see cx_ / blk_ tables            */
 #define MFK_FLAG_POOL 32                /* query sequence + qualities are in the pool                     */
 
-/* Packed alignments, coordinate-sorted, 24 bytes per read in nine SoA columns (see DESIGN.md "Data layout"). */
+/* Packed alignments, coordinate-sorted, 22 bytes per read in nine SoA columns (see DESIGN.md "Data layout"). */
 typedef struct mfk_reads {
     int64_t n_reads;
     const int32_t *ref_start;      /* pysam reference_start                                              */

@@ -13,7 +13,8 @@ reference's ``sctools.py`` so the device never needs strings:
   reference-consuming op is an aligned op, so first/last aligned position == reference_start / reference_end-1.)
 * clipped sequence (``sctools.py:111-157``): kind 1 -> the ``S`` bases; kind 2 -> the single terminal *query* base.
 
-Layout (one entry per mapped read, BAM order = coordinate order), 24 bytes per read:
+Layout (one entry per mapped read, BAM order = coordinate order), 22 bytes per read (SURVEY 8d budgets 24: its
+lclip_len / rclip_len columns are derivable from the kinds and op lengths, qlen replaces them):
 
     ref_start i32 | ref_end i32 | link i32 | contig_id u16 | qlen u16 | first_op_len u16 | last_op_len u16 |
     mapq u8 | flags u8
@@ -45,7 +46,7 @@ _SIDE_FIELDS = (("contig_len", np.int32), ("contig_read_start", np.int64), ("cx_
                 ("cx_off", np.uint32), ("blk_start", np.int32), ("blk_end", np.int32), ("blk_ins", np.int32),
                 ("pool_read", np.uint32), ("pool_off", np.uint64), ("pool_bases", np.uint8), ("pool_quals", np.uint8))
 ALL_FIELDS = _HOT_FIELDS + _SIDE_FIELDS
-BYTES_PER_READ = sum(np.dtype(t).itemsize for _, t in _HOT_FIELDS)  # 24
+BYTES_PER_READ = sum(np.dtype(t).itemsize for _, t in _HOT_FIELDS)  # 22
 
 
 class PackError(ValueError):

@@ -152,7 +152,7 @@ def _align_read(ref, sample, segs, a, b, min_anchor=8, tiny_overhang=2):
 
 def simulate_readset(seed=1, contig_lens=(20000,), n_insertions=6, coverage=40, read_len=100, sub_rate=0.004,
                      frag_mean=300, frag_sd=30, n_small_ins=2, n_large_ins=1, n_dels=2, low_mapq_frac=0.03,
-                     tsd_choices=(2, 3, 4, 5, 8, 9), is_library=None):
+                     tsd_choices=(2, 3, 4, 5, 8, 9), is_library=None, wildtype_frac=0.0):
     """Returns (genome dict name->sequence, ReadSet, truth list)."""
     rng = np.random.default_rng(seed)
     lib = is_library or make_is_library(rng)
@@ -183,9 +183,15 @@ def simulate_readset(seed=1, contig_lens=(20000,), n_insertions=6, coverage=40, 
                 events.append((p, "sins", _rand_seq(rng, int(rng.integers(32, 45)))))
             else:
                 events.append((p, "del", int(rng.integers(2, 15))))
-        sample, segs = _build_sample(ref, events)
-        n_frag = int(len(sample) * coverage / (2 * read_len))
+        sample_mut, segs_mut = _build_sample(ref, events)
+        # wild-type fragments come from the unmodified reference: they span insertion sites (pairflanks spanning_count)
+        sample_wt, segs_wt = _build_sample(ref, [])
+        n_frag = int(len(sample_mut) * coverage / (2 * read_len))
         for _ in range(n_frag):
+            if rng.random() < wildtype_frac:
+                sample, segs = sample_wt, segs_wt
+            else:
+                sample, segs = sample_mut, segs_mut
             flen = max(read_len, int(rng.normal(frag_mean, frag_sd)))
             fs = int(rng.integers(0, max(1, len(sample) - flen)))
             qname = "frag%07d" % frag_id

@@ -867,3 +867,11 @@ int mfko_pairflanks_fetch(void *c, mfk_pair *pairs, char *strs, int64_t *stats) 
     if (stats) memcpy(stats, C->pstats, sizeof C->pstats);
     return 0;
 }
+
+/* every repeat ir_detect reports for one sequence, in report order; out: n x 4 (1-based inclusive a1s a1e a2s a2e).
+ * Used by oracle/ref_harness.py to stand in for the einverted binary when the reference itself is run. */
+int mfko_ir_report(const char *s, int L, int32_t *out) {
+    ir_t rep[IR_MAXREP]; int n = ir_detect(s, L, rep);
+    for (int k = 0; k < n; k++) { out[4 * k] = rep[k].a1s + 1; out[4 * k + 1] = rep[k].a1e + 1; out[4 * k + 2] = rep[k].a2s + 1; out[4 * k + 3] = rep[k].a2e + 1; }
+    return n;
+}

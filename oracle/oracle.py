@@ -50,3 +50,10 @@ class Oracle(_lib.Binding):
 
     def levenshtein(self, a: bytes, b: bytes):
         return self.so.mfko_levenshtein(C.c_char_p(a), C.c_int(len(a)), C.c_char_p(b), C.c_int(len(b)))
+
+    def ir_report(self, seq: str):
+        """All inverted repeats the oracle's einverted restatement reports, 1-based inclusive arms, report order."""
+        out = np.zeros(32, dtype=np.int32)
+        self.so.mfko_ir_report.restype = C.c_int
+        n = self.so.mfko_ir_report(C.c_char_p(seq.encode()), C.c_int(len(seq)), C.c_void_p(out.ctypes.data))
+        return [tuple(int(x) for x in out[4 * k:4 * k + 4]) for k in range(n)]

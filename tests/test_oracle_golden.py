@@ -1,0 +1,49 @@
+"""Pins the CPU oracle (oracle/mfk_oracle.c) to the golden vectors the reference itself produced
+(tests/golden/make_golden.py).  CPU only."""
+import numpy as np
+import pytest
+
+from mustache_amd.pack import pack_reads
+from tests import util
+
+
+@pytest.mark.parametrize("name", util.CASES)
+def test_oracle_reproduces_reference_tsvs(oracle, name):
+    case = util.load_json(name)
+    rs = util.case_readset(case)
+    packed = pack_reads(rs.contigs, rs, pool="all")
+    ff, stats, pf = util.run_both_stages(oracle, oracle.reads(packed), packed, case)
+    assert ff == case["findflanks_tsv"]
+    # the nine "N sites remain" counters the reference logs (findflanks.py:144 ... 340)
+    assert stats[1:10] == case["findflanks_log_counts"]
+    assert pf == case["pairflanks_tsv"]
+
+
+def test_take_closest_table(oracle):
+    """misc.takeClosestSmaller / Larger (misc.py:29-76), including the table of its __main__ (misc.py:80-116)."""
+    rows = util.load_json("unit_vectors")["take_closest"]
+    n = 0
+    for lst, x, smaller, larger in rows:
+        if smaller != "IndexError":
+            assert oracle.take_closest(lst, x, larger=False) == smaller, (lst, x)
+            n += 1
+        if larger != "IndexError":
+            assert oracle.take_closest(lst, x, larger=True) == larger, (lst, x)
+    assert n > 100
+
+
+def test_similarity_rule_is_integer_exact():
+    """`1 - d/m >= 0.75` in float64 (findflanks.py:1046-1048) is the same predicate as 4*d <= m: the HIP kernel
+    uses the integer form, the oracle the float form."""
+    for m in range(1, 700):
+        for d in range(0, m + 1):
+            assert ((1 - (d / m)) >= 0.75) == (4 * d <= m), (d, m)
+
+
+def test_levenshtein_matches_textbook(oracle):
+    rng = np.random.default_rng(0)
+    from oracle.ref_harness import _levenshtein
+    for _ in range(200):
+        a = bytes(rng.integers(65, 69, rng.integers(0, 40)).astype(np.uint8))
+        b = bytes(rng.integers(65, 69, rng.integers(0, 40)).astype(np.uint8))
+        assert oracle.levenshtein(a, b) == _levenshtein(a, b)

@@ -1,0 +1,77 @@
+"""The packer's per-read fields against what the reference's sctools.py computed (golden unit vectors)."""
+import numpy as np
+import pytest
+
+from mustache_amd import pack
+from mustache_amd.records import ReadSet, AlignedRead
+from tests import util
+
+
+def test_clip_fields_match_sctools():
+    rows = util.load_json("unit_vectors")["sctools"]
+    reads = [util.read_from_json(r["read"]) for r in rows]
+    rs = ReadSet([("c1", 600)], reads)
+    p = pack.pack_reads(rs.contigs, rs, pool="all")
+    order = {id(r): k for k, r in enumerate(rs.reads)}
+    for row, read in zip(rows, reads):
+        k = order[id(read)]
+        f = int(p.flags[k])
+        lk, rk = f & 3, (f >> 2) & 3
+        assert bool(lk) == row["is_left"] and bool(rk) == row["is_right"], row["read"]
+        assert int(p.first_op_len[k]) == row["left_len"] and int(p.last_op_len[k]) == row["right_len"]
+        seq, quals = p.pool_sequence(k)
+        llen = int(p.first_op_len[k]) if lk == 1 else (1 if lk == 2 else 0)
+        rlen = int(p.last_op_len[k]) if rk == 1 else (1 if rk == 2 else 0)
+        assert seq[:llen] == row["left_seq"] and quals[:llen] == row["left_qual"]
+        assert (seq[len(seq) - rlen:] if rlen else "") == row["right_seq"]
+        assert (quals[len(seq) - rlen:] if rlen else []) == row["right_qual"]
+        if lk:
+            site = int(p.ref_start[k]) - 1 if lk == 1 else int(p.ref_start[k])
+            assert ["c1", site] == row["left_site"]
+        if rk:
+            site = int(p.ref_end[k]) if rk == 1 else int(p.ref_end[k]) - 1
+            assert ["c1", site] == row["right_site"]
+        for minial, key in ((21, "inner21"), (45, "inner45")):
+            ok = not (lk and rk) or (int(p.qlen[k]) - llen - rlen >= minial)
+            assert ok == row[key]
+        # blocks
+        if f & pack.FLAG_COMPLEX:
+            c = int(np.searchsorted(p.cx_read, k))
+            o0, o1 = int(p.cx_off[c]), int(p.cx_off[c + 1])
+            blocks = [[int(a), int(b)] for a, b in zip(p.blk_start[o0:o1], p.blk_end[o0:o1])]
+        else:
+            blocks = [[int(p.ref_start[k]), int(p.ref_end[k])]]
+        assert blocks == [list(b) for b in row["blocks"]]
+
+
+def test_links_and_order():
+    case = util.load_json("quirks")
+    rs = util.case_readset(case)
+    p = pack.pack_reads(rs.contigs, rs, pool="clipped", keep_names=True)
+    last = {}
+    for k, name in enumerate(p.read_names):
+        assert int(p.link[k]) == last.get(name, -1)
+        last[name] = k
+    assert np.all(np.diff(p.contig_id.astype(np.int64)) >= 0)
+    assert pack.BYTES_PER_READ == 22
+
+
+def test_unsorted_input_is_rejected():
+    a = AlignedRead("a", "c1", 50, 60, [(0, 10)], "A" * 10, [30] * 10, md="10")
+    b = AlignedRead("b", "c1", 10, 60, [(0, 10)], "A" * 10, [30] * 10, md="10")
+    with pytest.raises(pack.PackError):
+        pack.pack_reads([("c1", 100)], [a, b])
+
+
+def test_slice_is_self_contained(oracle):
+    from mustache_amd import lib
+    case = util.load_json("sim_a")
+    rs = util.case_readset(case)
+    p = pack.pack_reads(rs.contigs, rs, pool="all")
+    lo = int(p.contig_read_start[1])
+    sub = p.slice_reads(lo, p.n_reads)
+    res_full = oracle.run_findflanks(oracle.reads(p), lib.make_params())
+    res_sub = oracle.run_findflanks(oracle.reads(sub), lib.make_params())
+    full = res_full["flanks"][res_full["flanks"]["contig_id"] == 1]
+    assert np.array_equal(full["pos"], res_sub["flanks"]["pos"])
+    assert np.array_equal(full["consensus_softclip_count"], res_sub["flanks"]["consensus_softclip_count"])

@@ -1,0 +1,55 @@
+"""Shared helpers for the tests: golden fixtures -> alignments, result comparison."""
+import gzip
+import io
+import json
+import os
+
+import numpy as np
+import pandas as pd
+
+from mustache_amd import lib
+from mustache_amd import pairflanks as pfh
+from mustache_amd.findflanks import findflanks_packed
+from mustache_amd.pack import pack_reads
+from mustache_amd.records import AlignedRead, ReadSet, parse_cigar_string
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+CASES = ["quirks", "sim_a", "sim_b", "sim_c", "sim_d"]
+
+
+def load_json(name):
+    with gzip.open(os.path.join(GOLDEN, name + ".json.gz"), "rt") as fh:
+        return json.load(fh)
+
+
+def read_from_json(row):
+    name, contig, start, mapq, cigar, md, seq, qual, flag = row
+    return AlignedRead(name, contig, start, mapq, parse_cigar_string(cigar), seq, [ord(c) - 33 for c in qual], md=md,
+                       flag=flag)
+
+
+def case_readset(case):
+    return ReadSet([tuple(c) for c in case["contigs"]], [read_from_json(r) for r in case["reads"]])
+
+
+def run_both_stages(binding, reads_struct, packed, case, genome_arr=None):
+    """findflanks TSV text, stats, pairflanks TSV text through ``binding`` for a golden case."""
+    fparams = lib.make_params(**case["findflanks_params"])
+    buf = io.StringIO()
+    res = binding.run_findflanks(reads_struct, fparams)
+    df = findflanks_packed(binding, reads_struct, packed.contig_names, fparams, "sample1", None, verbose=False)
+    ff_text = df.to_csv(sep="\t", index=False)
+    flanks = pd.read_csv(io.StringIO(case["findflanks_tsv"]), sep="\t")
+    pparams = lib.make_params(**case["pairflanks_params"])
+    g, goff = pfh.genome_arrays(case["genome"], packed.contig_names)
+    if genome_arr is not None:
+        g = genome_arr(g)
+    pdf = pfh.pairflanks_packed(binding, reads_struct, packed.contig_names, pparams, flanks, g, goff, None, False)
+    del buf
+    return ff_text, [int(x) for x in res["stats"]], pdf.to_csv(sep="\t", index=False)
+
+
+def assert_same_sites(a, b):
+    assert a.shape == b.shape, (a.shape, b.shape)
+    for name in a.dtype.names:
+        assert np.array_equal(a[name], b[name]), (name, a[name][:20], b[name][:20])
