@@ -1,0 +1,186 @@
+// mfk_api.hip -- lifecycle, device arena, input upload and rocPRIM wrappers of libmfk.so
+#include "mfk_host.h"
+
+#include <rocprim/rocprim.hpp>
+
+extern "C" {
+
+mfk_ctx *mfk_create(int device_id) {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device_id < 0 || device_id >= ndev) return nullptr;
+    if (hipSetDevice(device_id) != hipSuccess) return nullptr;
+    mfk_ctx *ctx = new mfk_ctx();
+    ctx->device = device_id;
+    ctx->last_ms = 0.0;
+    ctx->pinned = nullptr;
+    ctx->pinned_cap = 0;
+    ctx->err[0] = 0;
+    memset(ctx->stats, 0, sizeof ctx->stats);
+    memset(ctx->pstats, 0, sizeof ctx->pstats);
+    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return nullptr; }
+    if (hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess) { delete ctx; return nullptr; }
+    return ctx;
+}
+
+void mfk_destroy(mfk_ctx *ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    for (auto &c : ctx->chunks) (void)hipFree(c.p);
+    if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+    (void)hipEventDestroy(ctx->ev0);
+    (void)hipEventDestroy(ctx->ev1);
+    (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+const char *mfk_last_error(mfk_ctx *ctx) { return ctx ? ctx->err : "null ctx"; }
+int mfk_version(void) { return 1; }
+double mfk_last_device_ms(mfk_ctx *ctx) { return ctx ? ctx->last_ms : 0.0; }
+
+}  // extern "C"
+
+// ---- arena ---------------------------------------------------------------------------------------------------
+void arena_reset(mfk_ctx *ctx) {
+    if (ctx->chunks.size() > 1) {
+        // the previous call had to grow: replace the pieces by one chunk of the total size
+        (void)hipStreamSynchronize(ctx->stream);
+        size_t total = 0;
+        for (auto &c : ctx->chunks) { total += c.cap; (void)hipFree(c.p); }
+        ctx->chunks.clear();
+        char *p = nullptr;
+        if (hipMalloc((void **)&p, total) == hipSuccess) ctx->chunks.push_back({p, total, 0});
+    }
+    for (auto &c : ctx->chunks) c.used = 0;
+}
+
+void *arena_alloc(mfk_ctx *ctx, size_t bytes) {
+    bytes = (bytes + 255) & ~(size_t)255;
+    if (!ctx->chunks.empty()) {
+        Chunk &c = ctx->chunks.back();
+        if (c.used + bytes <= c.cap) { void *p = c.p + c.used; c.used += bytes; return p; }
+    }
+    size_t cap = (size_t)64 << 20;
+    if (!ctx->chunks.empty() && ctx->chunks.back().cap * 2 > cap) cap = ctx->chunks.back().cap * 2;
+    if (bytes > cap) cap = bytes;
+    char *p = nullptr;
+    if (hipMalloc((void **)&p, cap) != hipSuccess) {
+        snprintf(ctx->err, sizeof ctx->err, "hipMalloc of %zu bytes failed", cap);
+        return nullptr;
+    }
+    ctx->chunks.push_back({p, cap, bytes});
+    return p;
+}
+
+void *pinned_buf(mfk_ctx *ctx, size_t bytes) {
+    if (bytes > ctx->pinned_cap) {
+        if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+        ctx->pinned = nullptr;
+        size_t cap = bytes < 4096 ? 4096 : bytes * 2;
+        if (hipHostMalloc(&ctx->pinned, cap, hipHostMallocDefault) != hipSuccess) { ctx->pinned_cap = 0; return nullptr; }
+        ctx->pinned_cap = cap;
+    }
+    return ctx->pinned;
+}
+
+// ---- inputs ----------------------------------------------------------------------------------------------------
+// The flat coordinate "gpos": contig c occupies [base[c], base[c] + len[c] + 2) (site positions run from -1 to len),
+// contigs are separated by a gap wider than any neighbourhood the filters look at, so one sorted u32 axis serves all
+// contigs and no neighbour search can cross a contig boundary.
+int upload_reads(mfk_ctx *ctx, const mfk_reads *in, const mfk_params *pr, DevReads *R, DevParams *P) {
+    if (in->n_reads < 0 || in->n_reads >= ((int64_t)1 << 31)) { snprintf(ctx->err, sizeof ctx->err, "n_reads %lld out of range (max 2^31-1 per call)", (long long)in->n_reads); return 1; }
+    if (in->n_contigs <= 0 || in->n_contigs > 65535) { snprintf(ctx->err, sizeof ctx->err, "n_contigs %d out of range", in->n_contigs); return 1; }
+    if (in->n_reads > 0 && (!in->ref_start || !in->ref_end || !in->link || !in->contig_id || !in->qlen || !in->first_op_len || !in->last_op_len || !in->mapq || !in->flags)) {
+        snprintf(ctx->err, sizeof ctx->err, "null column pointer in mfk_reads"); return 1;
+    }
+    if (((uintptr_t)in->flags & 15) != 0) { snprintf(ctx->err, sizeof ctx->err, "flags column must be 16-byte aligned"); return 1; }
+    if (in->h_contig_read_start[0] != 0 || in->h_contig_read_start[in->n_contigs] != in->n_reads) { snprintf(ctx->err, sizeof ctx->err, "contig_read_start does not cover the reads"); return 1; }
+    R->n = in->n_reads;
+    R->ref_start = in->ref_start; R->ref_end = in->ref_end; R->link = in->link;
+    R->contig_id = in->contig_id; R->qlen = in->qlen; R->first_op_len = in->first_op_len; R->last_op_len = in->last_op_len;
+    R->mapq = in->mapq; R->flags = in->flags;
+    R->n_contigs = in->n_contigs; R->max_span = in->max_span < 1 ? 1 : in->max_span;
+    R->n_cx = in->n_cx; R->cx_read = in->cx_read; R->cx_off = in->cx_off;
+    R->blk_start = in->blk_start; R->blk_end = in->blk_end; R->blk_ins = in->blk_ins;
+    R->n_pool = in->n_pool; R->pool_read = in->pool_read; R->pool_off = in->pool_off;
+    R->pool_bases = in->pool_bases; R->pool_quals = in->pool_quals;
+    int nc = in->n_contigs;
+    int64_t pad = (int64_t)pr->min_distance_to_mate + pr->max_direct_repeat_length + 64;
+    if (pad < 64) pad = 64;
+    size_t bytes = (size_t)nc * 4 + (size_t)(nc + 1) * 8 + (size_t)nc * 4;
+    char *h = (char *)pinned_buf(ctx, bytes + 64);
+    if (!h) { snprintf(ctx->err, sizeof ctx->err, "pinned allocation failed"); return 1; }
+    int32_t *h_len = (int32_t *)h; int64_t *h_rs = (int64_t *)(h + (((size_t)nc * 4 + 7) & ~(size_t)7)); uint32_t *h_base = (uint32_t *)(h_rs + nc + 1);
+    int64_t base = 0;
+    for (int c = 0; c < nc; c++) {
+        h_len[c] = in->h_contig_len[c];
+        h_base[c] = (uint32_t)base;
+        base += (int64_t)in->h_contig_len[c] + 2 + pad;
+        if (in->h_contig_read_start[c + 1] < in->h_contig_read_start[c]) { snprintf(ctx->err, sizeof ctx->err, "contig_read_start is not monotone"); return 1; }
+    }
+    if (base >= ((int64_t)1 << 32)) { snprintf(ctx->err, sizeof ctx->err, "total reference length %lld does not fit the 32-bit site axis", (long long)base); return 1; }
+    for (int c = 0; c <= nc; c++) h_rs[c] = in->h_contig_read_start[c];
+    int32_t *d_len = aalloc<int32_t>(ctx, nc); int64_t *d_rs = aalloc<int64_t>(ctx, nc + 1); uint32_t *d_base = aalloc<uint32_t>(ctx, nc);
+    if (!d_len || !d_rs || !d_base) return 1;
+    HIPCHK(hipMemcpyAsync(d_len, h_len, (size_t)nc * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(d_rs, h_rs, (size_t)(nc + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(d_base, h_base, (size_t)nc * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));   // the pinned buffer is reused by later read-backs
+    R->contig_len = d_len; R->contig_rs = d_rs; R->contig_base = d_base;
+    P->minlen = pr->min_softclip_length; P->mincount = pr->min_softclip_count; P->minq = pr->min_alignment_quality;
+    P->minial = pr->min_alignment_inner_length; P->mindist = pr->min_distance_to_mate; P->lins = pr->large_insertion_cutoff;
+    P->mcc = pr->min_count_consensus; P->maxdr = pr->max_direct_repeat_length;
+    P->minratio = pr->min_softclip_ratio; P->maxir = pr->max_indel_ratio; P->maxjsp = pr->max_junction_spanning_prop;
+    return 0;
+}
+
+// ---- rocPRIM wrappers ------------------------------------------------------------------------------------------
+int dev_sort_keys64(mfk_ctx *ctx, uint64_t *in, uint64_t *out, size_t n, int begin_bit, int end_bit) {
+    if (n == 0) return 0;
+    size_t tb = 0;
+    HIPCHK(rocprim::radix_sort_keys(nullptr, tb, in, out, n, (unsigned)begin_bit, (unsigned)end_bit, ctx->stream));
+    void *tmp = arena_alloc(ctx, tb ? tb : 1);
+    if (!tmp) return 1;
+    HIPCHK(rocprim::radix_sort_keys(tmp, tb, in, out, n, (unsigned)begin_bit, (unsigned)end_bit, ctx->stream));
+    return 0;
+}
+
+int dev_sort_pairs64(mfk_ctx *ctx, uint64_t *kin, uint64_t *kout, uint32_t *vin, uint32_t *vout, size_t n, int begin_bit, int end_bit) {
+    if (n == 0) return 0;
+    size_t tb = 0;
+    HIPCHK(rocprim::radix_sort_pairs(nullptr, tb, kin, kout, vin, vout, n, (unsigned)begin_bit, (unsigned)end_bit, ctx->stream));
+    void *tmp = arena_alloc(ctx, tb ? tb : 1);
+    if (!tmp) return 1;
+    HIPCHK(rocprim::radix_sort_pairs(tmp, tb, kin, kout, vin, vout, n, (unsigned)begin_bit, (unsigned)end_bit, ctx->stream));
+    return 0;
+}
+
+__global__ void k_write_total32(const uint32_t *in, uint32_t *out, size_t n) { out[n] = out[n - 1] + in[n - 1]; }
+__global__ void k_write_total64(const uint32_t *in, uint64_t *out, size_t n) { out[n] = out[n - 1] + in[n - 1]; }
+
+int dev_excl_scan32(mfk_ctx *ctx, const uint32_t *in, uint32_t *out, size_t n) {
+    if (n == 0) { HIPCHK(hipMemsetAsync(out, 0, 4, ctx->stream)); return 0; }
+    size_t tb = 0;
+    HIPCHK(rocprim::exclusive_scan(nullptr, tb, in, out, (uint32_t)0, n, rocprim::plus<uint32_t>(), ctx->stream));
+    void *tmp = arena_alloc(ctx, tb ? tb : 1);
+    if (!tmp) return 1;
+    HIPCHK(rocprim::exclusive_scan(tmp, tb, in, out, (uint32_t)0, n, rocprim::plus<uint32_t>(), ctx->stream));
+    hipLaunchKernelGGL(k_write_total32, dim3(1), dim3(1), 0, ctx->stream, in, out, n);
+    KCHK();
+    return 0;
+}
+
+struct U32ToU64 { __device__ uint64_t operator()(uint32_t v) const { return (uint64_t)v; } };
+
+int dev_excl_scan64(mfk_ctx *ctx, const uint32_t *in, uint64_t *out, size_t n) {
+    if (n == 0) { HIPCHK(hipMemsetAsync(out, 0, 8, ctx->stream)); return 0; }
+    size_t tb = 0;
+    auto it = rocprim::make_transform_iterator(in, U32ToU64());
+    HIPCHK(rocprim::exclusive_scan(nullptr, tb, it, out, (uint64_t)0, n, rocprim::plus<uint64_t>(), ctx->stream));
+    void *tmp = arena_alloc(ctx, tb ? tb : 1);
+    if (!tmp) return 1;
+    HIPCHK(rocprim::exclusive_scan(tmp, tb, it, out, (uint64_t)0, n, rocprim::plus<uint64_t>(), ctx->stream));
+    hipLaunchKernelGGL(k_write_total64, dim3(1), dim3(1), 0, ctx->stream, in, out, n);
+    KCHK();
+    return 0;
+}

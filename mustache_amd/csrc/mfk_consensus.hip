@@ -1,0 +1,627 @@
+// mfk_consensus.hip -- consensus flank extension (replaces SoftclipConsensus, findflanks.py:862-1104, and the Trie of
+// flanktrie.py) without building a trie.  With one "word" (clipped sequence + qualities) per query name:
+//
+//   trie node   = distinct non-empty prefix; counter(p) = #words with prefix p; qual(p) = sum of their qualities at
+//                 that depth; word_count(p) = #words equal to p                       (Trie.add, flanktrie.py:31-59)
+//   leaf        = word that is not a proper prefix of another word (first occurrence)  (traverse_seqs 157-170)
+//   leaf order  = DFS with children in insertion order = leaves sorted by the sequence t(a[:1]), t(a[:2]), ... where
+//                 t(p) = index of the first word with prefix p
+//   clusters    = leaf pairs with levenshtein(prefixes of the shorter length) d, 4*d <= m  (== 1 - d/m >= 0.75 in
+//                 float64, tests/test_oracle_golden.py) -> connected components; unmatched leaves are singletons
+//   consensus   = column vote over every word j with reach_C(j) = max over leaves l of C of LCP(j, l): at depth d the
+//                 voters are the words with reach > d; stop when fewer than mcc voters; per-base sum of qualities,
+//                 unique maximum wins, tie -> 'N'                                       (make_consensus_word 306-342)
+//   count       = #words with reach == len(word)                                        (make_subtrie 89-118)
+//
+// All pairwise work (LCP, bit-parallel Myers edit distance) is spread over the whole GPU; words live in an 8-byte
+// aligned byte pool so LCPs are 64-bit XOR + count-trailing-zeros.
+#include "mfk_host.h"
+
+#define MAX_WORD_LEN 512
+#define ERR_READ_NUMBER 1u
+#define ERR_NO_SEQUENCE 2u
+#define ERR_WORD_TOO_LONG 4u
+
+struct CMeta {          // small device struct the host reads back once
+    uint32_t err, max_len, max_R, pad;
+};
+
+struct Words {
+    uint32_t n;                       // number of words (active jobs only)
+    int32_t *first, *second;          // reads
+    uint32_t *nextra;                 // reads beyond the first with that name
+    uint32_t *job;                    // job = 2*k + side
+    uint32_t *len;                    // word length
+    uint32_t *plen;                   // padded to a multiple of 8
+    uint64_t *off;                    // byte offset into ch / q (multiple of 8)
+    uint8_t *ch, *q;                  // characters (4-bit codes, one per byte) and qualities
+    uint32_t *t;                      // per character of a leaf: t(a[:d+1])
+    uint8_t *is_leaf;
+    uint32_t *leaf_word;              // slot w0+k -> local word index of the k-th leaf (word order)
+    uint32_t *leaf_rank;              // DFS rank of the leaf in slot
+    uint32_t *label;                  // cluster label (local leaf index of the representative)
+    uint8_t *has_match;
+    int32_t *cl_count, *cl_len;       // per representative slot
+    uint32_t *cl_key;                 // (is_component << 31) | min DFS rank
+};
+
+struct Jobs {
+    uint32_t n;                       // 2 * n_act slots
+    uint32_t *w0, *R, *nl;            // word range, leaf count
+    uint32_t *adj_words;              // adjacency words of the job: R * ceil(R/32)
+    uint64_t *adj_off;
+    uint32_t *adj;
+    uint32_t *best;                   // best representative slot or 0xFFFFFFFF
+};
+
+__device__ __forceinline__ int d_lcp(const uint8_t *a, int la, const uint8_t *b, int lb) {
+    int m = la < lb ? la : lb;
+    for (int o = 0; o < m; o += 8) {
+        uint64_t x = *reinterpret_cast<const uint64_t *>(a + o) ^ *reinterpret_cast<const uint64_t *>(b + o);
+        if (x) { int k = o + (__builtin_ctzll(x) >> 3); return k < m ? k : m; }
+    }
+    return m;
+}
+
+// ---- words ------------------------------------------------------------------------------------------------------
+__global__ void k_site_act_map(const uint32_t *act_site, uint32_t n_act, int32_t *site_act) {
+    uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n_act) site_act[act_site[k]] = (int32_t)k;
+}
+
+__global__ void k_fill_ev_site(const uint32_t *act_site, uint32_t n_act, const uint32_t *ev_begin, const uint32_t *ev_end, uint32_t *ev_site) {
+    // one block per active site: mark its events (events of inactive sites keep 0xFFFFFFFF)
+    uint32_t k = blockIdx.x;
+    if (k >= n_act) return;
+    uint32_t s = act_site[k];
+    for (uint32_t e = ev_begin[s] + threadIdx.x; e < ev_end[s]; e += blockDim.x) ev_site[e] = s;
+}
+
+__global__ void k_word_flags(const uint8_t *info, const uint32_t *ev_site, const int32_t *site_act, const uint32_t *act_st, uint32_t E, uint32_t *flag) {
+    uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= E) return;
+    uint32_t s = ev_site[e];
+    uint32_t f = 0;
+    if (s != 0xFFFFFFFFu) {
+        uint8_t in = info[e];
+        int32_t k = site_act[s];
+        int side = (in >> 3) & 1;
+        if (k >= 0 && (act_st[k] & 4) && (act_st[k] & (1u << side)) && (in & 2)) f = 1;
+    }
+    flag[e] = f;
+}
+
+__global__ void k_job_meta(ConsensusIO io, const uint32_t *wid, Jobs J, CMeta *meta) {
+    uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= J.n) return;
+    uint32_t k = j >> 1, side = j & 1;
+    uint32_t st = io.act_st[k];
+    uint32_t w0 = 0, R = 0;
+    if ((st & 4) && (st & (1u << side))) {
+        uint32_t s = io.act_site[k];
+        uint32_t b = side == 0 ? io.site_ev_begin[s] : io.site_ev_mid[s];
+        uint32_t e = side == 0 ? io.site_ev_mid[s] : io.site_ev_end[s];
+        w0 = wid[b]; R = wid[e] - wid[b];
+    }
+    J.w0[j] = w0; J.R[j] = R; J.nl[j] = 0; J.best[j] = 0xFFFFFFFFu;
+    J.adj_words[j] = R * ((R + 31) >> 5);
+    if (R) atomicMax(&meta->max_R, R);
+}
+
+// first / second read of every word (combine_softclip_seq_quals_*: one or two reads per name, findflanks.py:932-1027)
+__global__ void k_word_reads(DevReads R, DevParams P, ConsensusIO io, const uint32_t *ev_site, const uint32_t *wflag, const uint32_t *wid, const int32_t *site_act, Words W) {
+    uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= io.n_events) return;
+    uint32_t s = ev_site[e];
+    if (s == 0xFFFFFFFFu) return;
+    uint8_t in = io.ev_info[e];
+    int side = (in >> 3) & 1;
+    int32_t k = site_act[s];
+    if (k < 0 || !(io.act_st[k] & 4) || !(io.act_st[k] & (1u << side))) return;
+    uint64_t key = io.ev_keys[e];
+    int64_t r = (int64_t)(key & 0x7fffffffu);
+    if (in & 2) {
+        uint32_t w = wid[e];
+        W.first[w] = (int32_t)r;
+        W.job[w] = 2u * (uint32_t)k + (uint32_t)side;
+        return;
+    }
+    // not the first read of its name here: find the first one (earliest read of the chain with the same event)
+    uint32_t gpos = (uint32_t)(key >> 32);
+    uint16_t contig = R.contig_id[r];
+    uint32_t base = R.contig_base[contig];
+    int64_t root = -1, prev = r;
+    for (int64_t q = R.link[r]; q >= 0 && q < prev; prev = q, q = R.link[q]) {
+        int32_t site;
+        if (R.contig_id[q] == contig && d_clip_event(R, P, q, side, &site) && base + (uint32_t)(site + 1) == gpos) root = q;
+    }
+    if (root < 0) return;   // cannot happen: info bit 2 is clear exactly when such a read exists
+    // its event: binary search by key in this site-side's range
+    uint32_t lo = side == 0 ? io.site_ev_begin[s] : io.site_ev_mid[s];
+    uint32_t hi = side == 0 ? io.site_ev_mid[s] : io.site_ev_end[s];
+    const uint32_t hi0 = hi;
+    uint64_t want = (key & ~(uint64_t)0x7fffffffu) | (uint64_t)root;
+    while (lo < hi) { uint32_t m = (lo + hi) >> 1; if (io.ev_keys[m] < want) lo = m + 1; else hi = m; }
+    if (lo >= hi0 || io.ev_keys[lo] != want || !wflag[lo]) return;
+    uint32_t w = wid[lo];
+    atomicAdd(&W.nextra[w], 1u);
+    W.second[w] = (int32_t)r;
+}
+
+__global__ void k_word_len(DevReads R, Words W, CMeta *meta) {
+    uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= W.n) return;
+    int side = (int)(W.job[w] & 1);
+    int64_t r1 = W.first[w], r2 = W.second[w];
+    if (W.nextra[w] > 1) atomicOr(&meta->err, ERR_READ_NUMBER);      // findflanks.py:976-978 / 1025-1027
+    uint8_t f1 = R.flags[r1];
+    int len = side == 0 ? d_rlen(R, r1, f1) : d_llen(R, r1, f1);
+    if (r2 >= 0) { uint8_t f2 = R.flags[r2]; int l2 = side == 0 ? d_rlen(R, r2, f2) : d_llen(R, r2, f2); if (l2 > len) len = l2; }
+    if (len > MAX_WORD_LEN) { atomicOr(&meta->err, ERR_WORD_TOO_LONG); len = MAX_WORD_LEN; }
+    W.len[w] = (uint32_t)len;
+    W.plen[w] = (uint32_t)((len + 7) & ~7);
+    atomicMax(&meta->max_len, (uint32_t)len);
+}
+
+// clipped base / quality p of read r in trie orientation: 5p = right clip as is, 3p = left clip reversed (Q14)
+__device__ __forceinline__ void d_clip_char(const DevReads &R, uint64_t pool_off, int qlen, int cliplen, int side, int p, uint8_t *c, uint8_t *q) {
+    uint64_t k = side == 0 ? pool_off + (uint64_t)(qlen - cliplen + p) : pool_off + (uint64_t)(cliplen - 1 - p);
+    *c = d_pool_base(R, k);
+    *q = R.pool_quals[k];
+}
+
+// one wave per word
+__global__ __launch_bounds__(256) void k_word_fill(DevReads R, Words W, CMeta *meta) {
+    uint32_t w = blockIdx.x * 4 + (threadIdx.x >> 6);
+    int lane = threadIdx.x & 63;
+    if (w >= W.n) return;
+    int side = (int)(W.job[w] & 1);
+    int64_t r1 = W.first[w], r2 = W.second[w];
+    uint8_t f1 = R.flags[r1];
+    int l1 = side == 0 ? d_rlen(R, r1, f1) : d_llen(R, r1, f1), l2 = 0;
+    int64_t p1 = d_pool_index(R, r1), p2 = -1;
+    uint64_t o1 = p1 >= 0 ? R.pool_off[p1] : 0, o2 = 0;
+    int q1len = R.qlen[r1], q2len = 0;
+    if (r2 >= 0) {
+        uint8_t f2 = R.flags[r2];
+        l2 = side == 0 ? d_rlen(R, r2, f2) : d_llen(R, r2, f2);
+        p2 = d_pool_index(R, r2);
+        o2 = p2 >= 0 ? R.pool_off[p2] : 0;
+        q2len = R.qlen[r2];
+    }
+    if (p1 < 0 || (r2 >= 0 && p2 < 0) || l1 > q1len || l2 > q2len) { if (lane == 0) atomicOr(&meta->err, ERR_NO_SEQUENCE); return; }
+    if (l1 > MAX_WORD_LEN) l1 = MAX_WORD_LEN;
+    if (l2 > MAX_WORD_LEN) l2 = MAX_WORD_LEN;
+    uint8_t *ch = W.ch + W.off[w], *qq = W.q + W.off[w];
+    int len = (int)W.len[w], plen = (int)W.plen[w];
+    for (int p = lane; p < plen; p += 64) {
+        uint8_t c = 0xFF, q = 0;
+        if (p < len) {
+            uint8_t c1 = 0, qa = 0, c2 = 0, qb = 0;
+            if (p < l1) d_clip_char(R, o1, q1len, l1, side, p, &c1, &qa);
+            if (p < l2) d_clip_char(R, o2, q2len, l2, side, p, &c2, &qb);
+            if (p < l1 && p < l2) { if (qa >= qb) { c = c1; q = qa; } else { c = c2; q = qb; } }   // read1 = first in BAM order (Q4)
+            else if (p < l1) { c = c1; q = qa; }
+            else { c = c2; q = qb; }
+        }
+        ch[p] = c; qq[p] = q;
+    }
+}
+
+// ---- leaves -------------------------------------------------------------------------------------------------------
+// one wave per word i: is some other word an extension of it (or an earlier copy)?
+__global__ __launch_bounds__(256) void k_leaf_flags(Words W, Jobs J) {
+    uint32_t w = blockIdx.x * 4 + (threadIdx.x >> 6);
+    int lane = threadIdx.x & 63;
+    if (w >= W.n) return;
+    uint32_t job = W.job[w], w0 = J.w0[job], R = J.R[job];
+    const uint8_t *a = W.ch + W.off[w];
+    int la = (int)W.len[w];
+    bool covered = false;
+    for (uint32_t j = lane; j < R && !covered; j += 64) {
+        uint32_t v = w0 + j;
+        if (v == w) continue;
+        int lb = (int)W.len[v];
+        if (lb < la) continue;
+        if (d_lcp(a, la, W.ch + W.off[v], lb) >= la && (lb > la || v < w)) covered = true;
+    }
+    unsigned long long any = __ballot(covered);
+    if (lane == 0) W.is_leaf[w] = any ? 0 : 1;
+}
+
+// one block per job: ordered list of its leaves
+__global__ __launch_bounds__(256) void k_leaf_compact(Words W, Jobs J) {
+    __shared__ uint32_t sh[8];
+    uint32_t job = blockIdx.x;
+    if (job >= J.n) return;
+    uint32_t w0 = J.w0[job], R = J.R[job];
+    if (!R) return;
+    uint32_t running = 0;
+    for (uint32_t b = 0; b < R; b += blockDim.x) {
+        uint32_t i = b + threadIdx.x;
+        uint32_t f = (i < R && W.is_leaf[w0 + i]) ? 1u : 0u, tot;
+        uint32_t off = block_excl_scan(f, sh, &tot);
+        if (f) { W.leaf_word[w0 + running + off] = i; W.label[w0 + running + off] = running + off; }
+        running += tot;
+    }
+    if (threadIdx.x == 0) J.nl[job] = running;
+}
+
+// one wave per leaf slot: t(a[:d+1]) = first word sharing d+1 characters with the leaf, for every depth d
+__global__ __launch_bounds__(64) void k_leaf_first(Words W, Jobs J) {
+    __shared__ uint32_t tmin[MAX_WORD_LEN];
+    uint32_t slot = blockIdx.x;
+    int lane = threadIdx.x;
+    if (slot >= W.n) return;
+    uint32_t job = W.job[slot], w0 = J.w0[job], R = J.R[job];
+    uint32_t k = slot - w0;
+    if (k >= J.nl[job]) return;
+    uint32_t wa = w0 + W.leaf_word[slot];
+    const uint8_t *a = W.ch + W.off[wa];
+    int la = (int)W.len[wa];
+    for (int d = lane; d < la; d += 64) tmin[d] = 0xFFFFFFFFu;
+    __syncthreads();
+    for (uint32_t j = lane; j < R; j += 64) {
+        uint32_t v = w0 + j;
+        int l = d_lcp(a, la, W.ch + W.off[v], (int)W.len[v]);
+        if (l > 0) atomicMin(&tmin[l - 1], j);
+    }
+    __syncthreads();
+    if (lane == 0) {   // suffix minimum over depth
+        uint32_t m = 0xFFFFFFFFu;
+        uint32_t *t = W.t + W.off[wa];
+        for (int d = la - 1; d >= 0; d--) { uint32_t v = tmin[d]; if (v < m) m = v; t[d] = m; }
+    }
+}
+
+// ---- leaf pairs: edit distance (Myers / Hyyro bit-vector, global alignment) + DFS order ------------------------------
+template <int NL>
+__device__ __forceinline__ int d_myers(const uint64_t (&plane)[4][NL], const uint8_t *text, int m) {
+    // pattern = leaf a (bit planes of its 4-bit codes), text = b[0:m); returns D(a[0:m), b[0:m))
+    uint64_t Pv[NL], Mv[NL];
+#pragma unroll
+    for (int i = 0; i < NL; i++) { Pv[i] = ~0ull; Mv[i] = 0ull; }
+    int score = m;
+    const int tl = (m - 1) >> 6;
+    const uint64_t tb = 1ull << ((m - 1) & 63);
+    for (int o = 0; o < m; o += 8) {
+        uint64_t chunk = *reinterpret_cast<const uint64_t *>(text + o);
+        int lim = m - o < 8 ? m - o : 8;
+        for (int s = 0; s < lim; s++) {
+            uint32_t c = (uint32_t)(chunk >> (8 * s)) & 0xFF;
+            uint64_t carry_add = 0, carry_ph = 1, carry_mh = 0;   // carry_ph = 1: D[0][j] = j (global alignment)
+#pragma unroll
+            for (int i = 0; i < NL; i++) {
+                uint64_t Eq = ~0ull;
+#pragma unroll
+                for (int p = 0; p < 4; p++) Eq &= ((c >> p) & 1) ? plane[p][i] : ~plane[p][i];
+                if (c > 15) Eq = 0;
+                uint64_t pv = Pv[i], mv = Mv[i];
+                uint64_t Xv = Eq | mv;
+                uint64_t X = Eq & pv;
+                uint64_t sum = X + pv;
+                uint64_t c1 = sum < X ? 1ull : 0ull;
+                uint64_t sum2 = sum + carry_add;
+                uint64_t c2 = sum2 < sum ? 1ull : 0ull;
+                carry_add = c1 | c2;
+                uint64_t Xh = (sum2 ^ pv) | Eq;
+                uint64_t Ph = mv | ~(Xh | pv);
+                uint64_t Mh = pv & Xh;
+                if (i == tl) { if (Ph & tb) score++; else if (Mh & tb) score--; }
+                uint64_t ph_out = Ph >> 63, mh_out = Mh >> 63;
+                Ph = (Ph << 1) | carry_ph;
+                Mh = (Mh << 1) | carry_mh;
+                carry_ph = ph_out; carry_mh = mh_out;
+                Pv[i] = Mh | ~(Xv | Ph);
+                Mv[i] = Ph & Xv;
+            }
+        }
+    }
+    return score;
+}
+
+// one block per leaf slot a; threads take the later leaves b of the same job
+template <int NL>
+__global__ __launch_bounds__(256) void k_leaf_pairs(Words W, Jobs J, uint32_t max_limbs) {
+    __shared__ uint64_t sh_plane[4][NL];
+    uint32_t slot = blockIdx.x;
+    if (slot >= W.n) return;
+    uint32_t job = W.job[slot], w0 = J.w0[job], R = J.R[job], nl = J.nl[job];
+    uint32_t ka = slot - w0;
+    if (ka + 1 >= nl) return;
+    uint32_t wa = w0 + W.leaf_word[slot];
+    const uint8_t *a = W.ch + W.off[wa];
+    const int la = (int)W.len[wa];
+    const int need = (la + 63) >> 6;
+    if (need > NL) return;   // cannot happen: NL is chosen from the longest word of the call
+    (void)max_limbs;
+    if (threadIdx.x < 4 * NL) {
+        int p = threadIdx.x / NL, i = threadIdx.x % NL;
+        uint64_t v = 0;
+        for (int b = 0; b < 64; b++) { int pos = i * 64 + b; if (pos < la && ((a[pos] >> p) & 1)) v |= 1ull << b; }
+        sh_plane[p][i] = v;
+    }
+    __syncthreads();
+    uint64_t plane[4][NL];
+#pragma unroll
+    for (int p = 0; p < 4; p++)
+#pragma unroll
+        for (int i = 0; i < NL; i++) plane[p][i] = sh_plane[p][i];
+    const uint32_t rw = (R + 31) >> 5;
+    uint32_t *adj = J.adj + J.adj_off[job];
+    const uint32_t *ta = W.t + W.off[wa];
+    uint32_t rank_a = 0;
+    for (uint32_t kb = ka + 1 + threadIdx.x; kb < nl; kb += blockDim.x) {
+        uint32_t wb = w0 + W.leaf_word[w0 + kb];
+        const uint8_t *b = W.ch + W.off[wb];
+        const int lb = (int)W.len[wb];
+        const int m = la < lb ? la : lb;
+        int d = d_myers<NL>(plane, b, m);
+        if (4 * d <= m) {   // similarity = 1 - d/m >= 0.75 (findflanks.py:1044-1048, quirk Q11)
+            atomicOr(&adj[(size_t)ka * rw + (kb >> 5)], 1u << (kb & 31));
+            atomicOr(&adj[(size_t)kb * rw + (ka >> 5)], 1u << (ka & 31));
+        }
+        // DFS order: at the first differing depth the branch whose first word came earlier is visited first
+        int k = d_lcp(a, la, b, lb);
+        if (k < m) {
+            uint32_t tav = ta[k], tbv = W.t[W.off[wb] + k];
+            if (tav < tbv) atomicAdd(&W.leaf_rank[w0 + kb], 1u); else rank_a++;
+        }
+    }
+    if (rank_a) atomicAdd(&W.leaf_rank[slot], rank_a);
+}
+
+// one block per job: connected components by label propagation over the adjacency bit matrix
+__global__ __launch_bounds__(256) void k_components(Words W, Jobs J) {
+    __shared__ int changed;
+    uint32_t job = blockIdx.x;
+    if (job >= J.n) return;
+    uint32_t w0 = J.w0[job], R = J.R[job], nl = J.nl[job];
+    if (nl == 0) return;
+    const uint32_t rw = (R + 31) >> 5;
+    const uint32_t *adj = J.adj + J.adj_off[job];
+    uint32_t *label = W.label + w0;
+    for (uint32_t a = threadIdx.x; a < nl; a += blockDim.x) {
+        bool any = false;
+        for (uint32_t x = 0; x < rw; x++) if (adj[(size_t)a * rw + x]) { any = true; break; }
+        W.has_match[w0 + a] = any ? 1 : 0;
+    }
+    for (int iter = 0; iter < (int)nl + 1; iter++) {
+        __syncthreads();
+        if (threadIdx.x == 0) changed = 0;
+        __syncthreads();
+        for (uint32_t a = threadIdx.x; a < nl; a += blockDim.x) {
+            uint32_t l = label[a];
+            for (uint32_t x = 0; x < rw; x++) {
+                uint32_t bits = adj[(size_t)a * rw + x];
+                while (bits) { int b = __builtin_ctz(bits); bits &= bits - 1; uint32_t lb = label[x * 32 + b]; if (lb < l) l = lb; }
+            }
+            uint32_t ll = label[l];   // pointer jumping
+            if (ll < l) l = ll;
+            if (l < label[a]) { label[a] = l; changed = 1; }
+        }
+        __syncthreads();
+        if (!changed) break;
+    }
+}
+
+// ---- clusters -------------------------------------------------------------------------------------------------------
+// one wave per representative leaf slot (EMIT = false) or per job for its best cluster (EMIT = true)
+// dynamic LDS: reach[max_R] (u16) | hq[max_len*16] (u32) | hc[max_len*16] (u32)
+template <bool EMIT>
+__global__ __launch_bounds__(64) void k_cluster(DevParams P, Words W, Jobs J, uint32_t max_R, uint32_t max_len, ConsensusIO io) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    uint32_t *hq = reinterpret_cast<uint32_t *>(smem);
+    uint32_t *hc = hq + (size_t)max_len * 16;
+    uint16_t *reach = reinterpret_cast<uint16_t *>(hc + (size_t)max_len * 16);
+    int lane = threadIdx.x;
+    uint32_t slot, job;
+    if (EMIT) {
+        job = blockIdx.x;
+        if (job >= J.n) return;
+        slot = J.best[job];
+        if (slot == 0xFFFFFFFFu) return;
+    } else {
+        slot = blockIdx.x;
+        if (slot >= W.n) return;
+        job = W.job[slot];
+    }
+    uint32_t w0 = J.w0[job], R = J.R[job], nl = J.nl[job];
+    uint32_t ka = slot - w0;
+    if (ka >= nl || W.label[slot] != ka) return;   // not a representative
+    int maxd = 0;
+    uint32_t minrank = 0xFFFFFFFFu;
+    for (uint32_t j = lane; j < R; j += 64) reach[j] = 0;
+    for (uint32_t d = lane; d < max_len * 16; d += 64) { hq[d] = 0; hc[d] = 0; }
+    __syncthreads();
+    for (uint32_t kl = 0; kl < nl; kl++) {          // wave-uniform loop over the leaves of the job
+        if (W.label[w0 + kl] != ka) continue;
+        uint32_t wl = w0 + W.leaf_word[w0 + kl];
+        const uint8_t *l = W.ch + W.off[wl];
+        int ll = (int)W.len[wl];
+        if (ll > maxd) maxd = ll;
+        uint32_t rk = W.leaf_rank[w0 + kl];
+        if (rk < minrank) minrank = rk;
+        for (uint32_t j = lane; j < R; j += 64) {
+            uint32_t v = w0 + j;
+            int c = d_lcp(l, ll, W.ch + W.off[v], (int)W.len[v]);
+            if (c > (int)reach[j]) reach[j] = (uint16_t)c;
+        }
+    }
+    __syncthreads();
+    uint32_t words = 0;
+    for (uint32_t j = lane; j < R; j += 64) {
+        uint32_t v = w0 + j;
+        int rc = reach[j], lj = (int)W.len[v];
+        if (rc == lj) words++;                       // the word is a prefix of a leaf of the cluster (make_subtrie)
+        const uint8_t *c = W.ch + W.off[v], *q = W.q + W.off[v];
+        for (int d = 0; d < rc; d++) { uint32_t code = c[d] & 15; atomicAdd(&hq[d * 16 + code], (uint32_t)q[d]); atomicAdd(&hc[d * 16 + code], 1u); }
+    }
+    for (int o = 32; o > 0; o >>= 1) words += __shfl_down(words, o, 64);
+    words = __shfl(words, 0, 64);
+    __syncthreads();
+    // make_consensus_word flanktrie.py:306-342: stop at the first depth with fewer than mcc voters
+    int stop = maxd;
+    for (int d = lane; d < maxd; d += 64) {
+        uint32_t tot = 0;
+        for (int c = 0; c < 16; c++) tot += hc[d * 16 + c];
+        if ((int64_t)tot < (int64_t)P.mcc) { if (d < stop) stop = d; }
+    }
+    for (int o = 32; o > 0; o >>= 1) { int other = __shfl_xor(stop, o, 64); if (other < stop) stop = other; }
+    if (!EMIT) {
+        if (lane == 0) {
+            W.cl_count[slot] = (int32_t)words;
+            W.cl_len[slot] = stop;
+            W.cl_key[slot] = ((W.has_match[slot] ? 1u : 0u) << 31) | (minrank & 0x7fffffffu);
+        }
+        return;
+    }
+    const char codes[17] = "=ACMGRSVTWYHKDBN";
+    char *out = io.cons_chars + (size_t)job * io.cons_stride;
+    const int side = (int)(job & 1);
+    for (int d = lane; d < stop; d += 64) {
+        int best = -1, nbest = 0;
+        for (int c = 0; c < 16; c++) {
+            if (!hc[d * 16 + c]) continue;
+            if (best < 0 || hq[d * 16 + c] > hq[d * 16 + best]) { best = c; nbest = 1; }
+            else if (hq[d * 16 + c] == hq[d * 16 + best]) nbest++;
+        }
+        char chv = nbest > 1 ? 'N' : codes[best < 0 ? 15 : best];   // get_best_qual_chars flanktrie.py:344-353
+        out[side == 0 ? d : stop - 1 - d] = chv;                     // 3p consensus is reversed back (findflanks.py:894-895)
+    }
+}
+
+// one thread per job: filters + best consensus (findflanks.py:241-346): max by (count, len), the last in list order
+// wins ties; list order = singletons in leaf (DFS) order, then components by their first leaf (quirk Q12 build rule)
+__global__ void k_job_best(DevParams P, Words W, Jobs J, ConsensusIO io) {
+    uint32_t job = blockIdx.x * blockDim.x + threadIdx.x;
+    if (job >= J.n) return;
+    uint32_t w0 = J.w0[job], nl = J.nl[job];
+    uint32_t npl = 0, npb = 0, best = 0xFFFFFFFFu;
+    int32_t bc = 0, bl = 0; uint32_t bk = 0;
+    for (uint32_t k = 0; k < nl; k++) {
+        uint32_t slot = w0 + k;
+        if (W.label[slot] != k) continue;
+        int32_t cnt = W.cl_count[slot], len = W.cl_len[slot];
+        uint32_t key = W.cl_key[slot];
+        if (len < P.minlen) continue;
+        npl++;
+        if (cnt < P.mincount) continue;
+        npb++;
+        if (best == 0xFFFFFFFFu || cnt > bc || (cnt == bc && (len > bl || (len == bl && key > bk)))) { best = slot; bc = cnt; bl = len; bk = key; }
+    }
+    io.n_pass_len[job] = npl; io.n_pass_both[job] = npb;
+    J.best[job] = best;
+    if (best != 0xFFFFFFFFu) { io.cons_count[job] = bc; io.cons_len[job] = bl; }
+}
+
+// =====================================================================================================================
+static int read_back_c(mfk_ctx *ctx, const void *dev, void *host, size_t bytes) {
+    void *pin = pinned_buf(ctx, bytes);
+    if (!pin) { snprintf(ctx->err, sizeof ctx->err, "pinned allocation failed"); return 1; }
+    HIPCHK(hipMemcpyAsync(pin, dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    memcpy(host, pin, bytes);
+    return 0;
+}
+
+int run_consensus(mfk_ctx *ctx, const DevReads &R, const DevParams &P, ConsensusIO &io) {
+    hipStream_t st = ctx->stream;
+    const uint32_t E = io.n_events, n_act = io.n_act;
+    io.cons_chars = nullptr; io.cons_stride = 0;
+    if (!E || !n_act) return 0;
+    const unsigned eb = nblocks(E, 256);
+    // site -> active index, event -> site
+    // (site table capacity is E)
+    int32_t *site_act = aalloc<int32_t>(ctx, E);
+    uint32_t *ev_site = aalloc<uint32_t>(ctx, E), *wflag = aalloc<uint32_t>(ctx, E), *wid = aalloc<uint32_t>(ctx, (size_t)E + 1);
+    CMeta *meta = aalloc<CMeta>(ctx, 1);
+    if (!site_act || !ev_site || !wflag || !wid || !meta) return 1;
+    HIPCHK(hipMemsetAsync(site_act, 0xFF, (size_t)E * 4, st));
+    HIPCHK(hipMemsetAsync(ev_site, 0xFF, (size_t)E * 4, st));
+    HIPCHK(hipMemsetAsync(meta, 0, sizeof(CMeta), st));
+    hipLaunchKernelGGL(k_site_act_map, dim3(nblocks(n_act, 256)), dim3(256), 0, st, io.act_site, n_act, site_act);
+    KCHK();
+    hipLaunchKernelGGL(k_fill_ev_site, dim3(n_act), dim3(64), 0, st, io.act_site, n_act, io.site_ev_begin, io.site_ev_end, ev_site);
+    KCHK();
+    hipLaunchKernelGGL(k_word_flags, dim3(eb), dim3(256), 0, st, io.ev_info, (const uint32_t *)ev_site, (const int32_t *)site_act, io.act_st, E, wflag);
+    KCHK();
+    if (int rc = dev_excl_scan32(ctx, wflag, wid, E)) return rc;
+    Jobs J; memset(&J, 0, sizeof J);
+    J.n = 2 * n_act;
+    J.w0 = aalloc<uint32_t>(ctx, J.n); J.R = aalloc<uint32_t>(ctx, J.n); J.nl = aalloc<uint32_t>(ctx, J.n);
+    J.adj_words = aalloc<uint32_t>(ctx, J.n); J.adj_off = aalloc<uint64_t>(ctx, (size_t)J.n + 1); J.best = aalloc<uint32_t>(ctx, J.n);
+    if (!J.w0 || !J.R || !J.nl || !J.adj_words || !J.adj_off || !J.best) return 1;
+    hipLaunchKernelGGL(k_job_meta, dim3(nblocks(J.n, 256)), dim3(256), 0, st, io, (const uint32_t *)wid, J, meta);
+    KCHK();
+    if (int rc = dev_excl_scan64(ctx, J.adj_words, J.adj_off, J.n)) return rc;
+    uint32_t Wn = 0; uint64_t adj_total = 0;
+    if (int rc = read_back_c(ctx, wid + E, &Wn, 4)) return rc;
+    if (int rc = read_back_c(ctx, J.adj_off + J.n, &adj_total, 8)) return rc;
+    if (Wn == 0) return 0;
+    Words W; memset(&W, 0, sizeof W);
+    W.n = Wn;
+    W.first = aalloc<int32_t>(ctx, Wn); W.second = aalloc<int32_t>(ctx, Wn); W.nextra = aalloc<uint32_t>(ctx, Wn);
+    W.job = aalloc<uint32_t>(ctx, Wn); W.len = aalloc<uint32_t>(ctx, Wn); W.plen = aalloc<uint32_t>(ctx, Wn);
+    W.off = aalloc<uint64_t>(ctx, (size_t)Wn + 1); W.is_leaf = aalloc<uint8_t>(ctx, Wn); W.leaf_word = aalloc<uint32_t>(ctx, Wn);
+    W.leaf_rank = aalloc<uint32_t>(ctx, Wn); W.label = aalloc<uint32_t>(ctx, Wn); W.has_match = aalloc<uint8_t>(ctx, Wn);
+    W.cl_count = aalloc<int32_t>(ctx, Wn); W.cl_len = aalloc<int32_t>(ctx, Wn); W.cl_key = aalloc<uint32_t>(ctx, Wn);
+    J.adj = aalloc<uint32_t>(ctx, (size_t)adj_total);
+    if (!W.first || !W.second || !W.nextra || !W.job || !W.len || !W.plen || !W.off || !W.is_leaf || !W.leaf_word || !W.leaf_rank || !W.label || !W.has_match || !W.cl_count || !W.cl_len || !W.cl_key || !J.adj) return 1;
+    HIPCHK(hipMemsetAsync(W.second, 0xFF, (size_t)Wn * 4, st));
+    HIPCHK(hipMemsetAsync(W.nextra, 0, (size_t)Wn * 4, st));
+    HIPCHK(hipMemsetAsync(W.leaf_rank, 0, (size_t)Wn * 4, st));
+    HIPCHK(hipMemsetAsync(W.has_match, 0, (size_t)Wn, st));
+    HIPCHK(hipMemsetAsync(W.label, 0xFF, (size_t)Wn * 4, st));
+    HIPCHK(hipMemsetAsync(J.adj, 0, (size_t)(adj_total ? adj_total : 1) * 4, st));
+    const unsigned wb = nblocks(Wn, 256), ww = nblocks(Wn, 4);
+    hipLaunchKernelGGL(k_word_reads, dim3(eb), dim3(256), 0, st, R, P, io, (const uint32_t *)ev_site, (const uint32_t *)wflag, (const uint32_t *)wid, (const int32_t *)site_act, W);
+    KCHK();
+    hipLaunchKernelGGL(k_word_len, dim3(wb), dim3(256), 0, st, R, W, meta);
+    KCHK();
+    if (int rc = dev_excl_scan64(ctx, W.plen, W.off, Wn)) return rc;
+    CMeta hm; uint64_t total_chars = 0;
+    if (int rc = read_back_c(ctx, meta, &hm, sizeof hm)) return rc;
+    if (int rc = read_back_c(ctx, W.off + Wn, &total_chars, 8)) return rc;
+    if (hm.err & ERR_READ_NUMBER) { snprintf(ctx->err, sizeof ctx->err, "READ NUMBER ERROR - ZERO OR MORE THAN TWO READS ASSOCIATED WITH QUERY NAME"); return 3; }
+    if (hm.err & ERR_WORD_TOO_LONG) { snprintf(ctx->err, sizeof ctx->err, "soft clip longer than %d bases: not supported by this build", MAX_WORD_LEN); return 6; }
+    W.ch = aalloc<uint8_t>(ctx, (size_t)total_chars + 8); W.q = aalloc<uint8_t>(ctx, (size_t)total_chars + 8);
+    W.t = aalloc<uint32_t>(ctx, (size_t)total_chars + 8);
+    if (!W.ch || !W.q || !W.t) return 1;
+    hipLaunchKernelGGL(k_word_fill, dim3(ww), dim3(256), 0, st, R, W, meta);
+    KCHK();
+    hipLaunchKernelGGL(k_leaf_flags, dim3(ww), dim3(256), 0, st, W, J);
+    KCHK();
+    hipLaunchKernelGGL(k_leaf_compact, dim3(J.n), dim3(256), 0, st, W, J);
+    KCHK();
+    hipLaunchKernelGGL(k_leaf_first, dim3(Wn), dim3(64), 0, st, W, J);
+    KCHK();
+    const uint32_t limbs = (hm.max_len + 63) / 64;
+    if (limbs <= 1) hipLaunchKernelGGL(k_leaf_pairs<1>, dim3(Wn), dim3(256), 0, st, W, J, limbs);
+    else if (limbs <= 2) hipLaunchKernelGGL(k_leaf_pairs<2>, dim3(Wn), dim3(256), 0, st, W, J, limbs);
+    else if (limbs <= 3) hipLaunchKernelGGL(k_leaf_pairs<3>, dim3(Wn), dim3(256), 0, st, W, J, limbs);
+    else if (limbs <= 4) hipLaunchKernelGGL(k_leaf_pairs<4>, dim3(Wn), dim3(256), 0, st, W, J, limbs);
+    else hipLaunchKernelGGL(k_leaf_pairs<8>, dim3(Wn), dim3(256), 0, st, W, J, limbs);
+    KCHK();
+    hipLaunchKernelGGL(k_components, dim3(J.n), dim3(256), 0, st, W, J);
+    KCHK();
+    const uint32_t max_len = hm.max_len ? hm.max_len : 1, max_R = hm.max_R ? hm.max_R : 1;
+    size_t lds = (size_t)max_len * 16 * 8 + (size_t)max_R * 2 + 16;
+    if (lds > 150 * 1024) { snprintf(ctx->err, sizeof ctx->err, "site with %u clipped names x %u bases exceeds the LDS budget of the consensus kernel", max_R, max_len); return 7; }
+    if (lds > 64 * 1024) {
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_cluster<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_cluster<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    }
+    io.cons_stride = (max_len + 7) & ~7u;
+    io.cons_chars = aalloc<char>(ctx, (size_t)J.n * io.cons_stride);
+    if (!io.cons_chars) return 1;
+    hipLaunchKernelGGL(k_cluster<false>, dim3(Wn), dim3(64), lds, st, P, W, J, max_R, max_len, io);
+    KCHK();
+    hipLaunchKernelGGL(k_job_best, dim3(nblocks(J.n, 256)), dim3(256), 0, st, P, W, J, io);
+    KCHK();
+    hipLaunchKernelGGL(k_cluster<true>, dim3(J.n), dim3(64), lds, st, P, W, J, max_R, max_len, io);
+    KCHK();
+    if (int rc = read_back_c(ctx, meta, &hm, sizeof hm)) return rc;
+    if (hm.err & ERR_NO_SEQUENCE) { snprintf(ctx->err, sizeof ctx->err, "a clipped read at a surviving site has no sequence in the pool (pack with pool='clipped')"); return 2; }
+    return 0;
+}

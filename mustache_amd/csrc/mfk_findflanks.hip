@@ -1,0 +1,554 @@
+// mfk_findflanks.hip -- the findflanks pipeline of libmfk.so (replaces SoftclipParser driven as in the reference's
+// _findflanks, findflanks.py:24-51).  Kernels, in call order:
+//
+//   k_scan_clips<false/true>  parse_softclips (findflanks.py:100-121): streams the flags column (1 B/read, 16 reads per
+//                             lane per load), evaluates the read filters only for lenient-clipped reads and emits one
+//                             64-bit event key (gpos | side | read) per clip.  Two passes (count, then write at the
+//                             scanned offsets): deterministic order, no contended atomics.
+//   rocPRIM radix sort        events -> (site, side, BAM order)
+//   k_event_info              per event: site head, first-of-its-query-name (link-chain walk, quirk Q3), meets_minlength
+//   k_site_accumulate         per-site distinct-name counts and flags (SoftclipSite, findflanks.py:727-745, 797-801)
+//   k_filter_minlength/_mincount/k_mindistance   findflanks.py:124-200 (+ misc.takeClosest*, strict neighbours, Q5)
+//   k_compact_sites           surviving sites -> dense "active" table
+//   k_classify                parse_unclipped_read_info (findflanks.py:349-509): one workgroup per active site joins the
+//                             reads overlapping [pos-1,pos+2) and counts distinct names per category in LDS
+//   k_ratio_filter            filter_softclips_count_ratios (findflanks.py:203-239), fp64 like Python
+//   run_consensus             mfk_consensus.hip
+//   k_consensus_filters       filter_consensus_sequences_minlength/_mincount/filter_multiple (findflanks.py:241-342)
+#include "mfk_host.h"
+
+#define SCAN_THREADS 256
+#define SCAN_MAX_BLOCKS 2048
+
+// ---- K1: clip events -------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t d_emit_events(const DevReads &R, const DevParams &P, int64_t r, uint8_t f, uint64_t *out) {
+    // returns the number of events of read r; writes their keys when out != nullptr
+    if (!(f & 15)) return 0;
+    if (!d_passes(R, P, r, f)) return 0;
+    uint32_t c = 0;
+    uint32_t base = R.contig_base[R.contig_id[r]];
+    if (d_rkind(f)) {   // right clip -> 5p site (findflanks.py:117-118, 594-597)
+        if (out) out[c] = ((uint64_t)(base + (uint32_t)(d_rsite(R, r, f) + 1)) << 32) | (uint64_t)(uint32_t)r;
+        c++;
+    }
+    if (d_lkind(f)) {   // left clip -> 3p site (findflanks.py:120-121, 599-602)
+        if (out) out[c] = ((uint64_t)(base + (uint32_t)(d_lsite(R, r, f) + 1)) << 32) | (1ull << 31) | (uint64_t)(uint32_t)r;
+        c++;
+    }
+    return c;
+}
+
+template <bool WRITE>
+__global__ __launch_bounds__(SCAN_THREADS) void k_scan_clips(DevReads R, DevParams P, uint32_t *block_counts, const uint32_t *block_offsets, uint64_t *ev) {
+    __shared__ uint32_t sh[8];
+    const int64_t ngroups = (R.n + 15) >> 4;
+    const int64_t per_block = (ngroups + gridDim.x - 1) / gridDim.x;
+    const int64_t g0 = (int64_t)blockIdx.x * per_block;
+    int64_t g1 = g0 + per_block;
+    if (g1 > ngroups) g1 = ngroups;
+    uint32_t running = WRITE ? block_offsets[blockIdx.x] : 0;
+    for (int64_t gb = g0; gb < g1; gb += SCAN_THREADS) {
+        const int64_t g = gb + threadIdx.x;
+        uint32_t c = 0;
+        uint32_t w[4] = {0, 0, 0, 0};
+        int nvalid = 0;
+        if (g < g1) {
+            const int64_t r0 = g << 4;
+            if (r0 + 16 <= R.n) {
+                uint4 v = *reinterpret_cast<const uint4 *>(R.flags + r0);
+                w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w; nvalid = 16;
+            } else {
+                nvalid = (int)(R.n - r0);
+                for (int k = 0; k < nvalid; k++) w[k >> 2] |= (uint32_t)R.flags[r0 + k] << ((k & 3) * 8);
+            }
+            if ((w[0] | w[1] | w[2] | w[3]) & 0x0F0F0F0Fu) {
+                for (int k = 0; k < nvalid; k++) {
+                    uint8_t f = (uint8_t)(w[k >> 2] >> ((k & 3) * 8));
+                    if (f & 15) c += d_emit_events(R, P, r0 + k, f, nullptr);
+                }
+            }
+        }
+        if (WRITE) {
+            uint32_t tot;
+            uint32_t off = block_excl_scan(c, sh, &tot);
+            if (c) {
+                uint64_t *dst = ev + running + off;
+                const int64_t r0 = g << 4;
+                for (int k = 0; k < nvalid; k++) {
+                    uint8_t f = (uint8_t)(w[k >> 2] >> ((k & 3) * 8));
+                    if (f & 15) dst += d_emit_events(R, P, r0 + k, f, dst);
+                }
+            }
+            running += tot;
+        } else {
+            running += c;
+        }
+    }
+    if (!WRITE) {
+        uint32_t tot;
+        (void)block_excl_scan(running, sh, &tot);
+        if (threadIdx.x == 0) block_counts[blockIdx.x] = tot;
+    }
+}
+
+// ---- K2: per-event information ---------------------------------------------------------------------------------
+// info bits: 1 site head, 2 first read of its query name at this site-side, 4 meets_minlength, 8 side (0 = 5p, 1 = 3p)
+__global__ void k_event_info(DevReads R, DevParams P, const uint64_t *keys, uint32_t E, uint8_t *info, uint32_t *head) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= E) return;
+    uint64_t key = keys[i];
+    uint32_t gpos = (uint32_t)(key >> 32);
+    int side = (int)((key >> 31) & 1);
+    int64_t r = (int64_t)(key & 0x7fffffffu);
+    bool h = i == 0 || (uint32_t)(keys[i - 1] >> 32) != gpos;
+    uint16_t contig = R.contig_id[r];
+    uint32_t base = R.contig_base[contig];
+    bool first = true;
+    int64_t prev = r;
+    for (int64_t q = R.link[r]; q >= 0 && q < prev; prev = q, q = R.link[q]) {   // strictly decreasing chain
+        int32_t site;
+        if (R.contig_id[q] == contig && d_clip_event(R, P, q, side, &site) && base + (uint32_t)(site + 1) == gpos) { first = false; break; }
+    }
+    // meets_minlength_right / _left: raw length of the last / first CIGAR op (findflanks.py:604-614, quirk Q1)
+    bool meets = side == 0 ? ((int)R.last_op_len[r] >= P.minlen) : ((int)R.first_op_len[r] >= P.minlen);
+    info[i] = (uint8_t)((h ? 1 : 0) | (first ? 2 : 0) | (meets ? 4 : 0) | (side ? 8 : 0));
+    head[i] = h ? 1u : 0u;
+}
+
+// ---- K3: site table ----------------------------------------------------------------------------------------------
+struct SiteTab {
+    uint32_t *gpos; int32_t *contig; uint32_t *cnt2;   // cnt2[2*s + side] distinct query names
+    uint32_t *sflags;                                  // bit0 meets_minlength_5p, bit1 meets_minlength_3p
+    uint32_t *ev_begin, *ev_mid, *ev_end;              // event ranges: [begin, mid) 5p events, [mid, end) 3p events
+    uint32_t *st;                                      // bit0 keep_5p, bit1 keep_3p, bit2 alive
+};
+
+__global__ void k_site_accumulate(DevReads R, const uint64_t *keys, const uint8_t *info, const uint32_t *head_scan, uint32_t E, SiteTab T) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= E) return;
+    uint8_t in = info[i];
+    uint32_t s = head_scan[i] + (in & 1) - 1;   // exclusive scan of heads + own head - 1
+    uint64_t key = keys[i];
+    int side = (in >> 3) & 1;
+    if (in & 1) {
+        T.gpos[s] = (uint32_t)(key >> 32);
+        T.contig[s] = (int32_t)R.contig_id[key & 0x7fffffffu];
+        T.ev_begin[s] = i;
+        if (s > 0) T.ev_end[s - 1] = i;
+    }
+    if (i == E - 1) T.ev_end[s] = E;
+    if (side == 1 && ((in & 1) || !((info[i - 1] >> 3) & 1))) T.ev_mid[s] = i;
+    if (in & 2) atomicAdd(&T.cnt2[2 * s + side], 1u);
+    if (in & 4) atomicOr(&T.sflags[s], 1u << side);
+}
+
+__global__ void k_site_init(SiteTab T, const uint32_t *n_sites_p, uint32_t *stats) {
+    uint32_t n = *n_sites_p;
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        T.st[i] = 7;
+        if (T.ev_mid[i] == 0xFFFFFFFFu) T.ev_mid[i] = T.ev_end[i];
+    }
+    if (i == 0) stats[0] = n;
+}
+
+// filter_softclips_minlength findflanks.py:124-145
+__global__ void k_filter_minlength(SiteTab T, const uint32_t *n_sites_p, uint32_t *stats) {
+    uint32_t n = *n_sites_p;
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    int alive = 0;
+    if (i < n) {
+        uint32_t s = T.st[i];
+        if (s & 4) {
+            uint32_t m = T.sflags[i];
+            if (!(m & 1)) s &= ~1u;
+            if (!(m & 2)) s &= ~2u;
+            if (!(s & 3)) s &= ~4u;
+            T.st[i] = s;
+            alive = (s >> 2) & 1;
+        }
+    }
+    int c = __syncthreads_count(alive);
+    if (threadIdx.x == 0 && c) atomicAdd(&stats[1], (uint32_t)c);
+}
+
+// filter_softclips_mincount findflanks.py:148-169
+__global__ void k_filter_mincount(SiteTab T, const uint32_t *n_sites_p, int mincount, uint32_t *stats) {
+    uint32_t n = *n_sites_p;
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    int alive = 0;
+    if (i < n) {
+        uint32_t s = T.st[i];
+        if (s & 4) {
+            if ((int64_t)T.cnt2[2 * i] < (int64_t)mincount) s &= ~1u;
+            if ((int64_t)T.cnt2[2 * i + 1] < (int64_t)mincount) s &= ~2u;
+            if (!(s & 3)) s &= ~4u;
+            T.st[i] = s;
+            alive = (s >> 2) & 1;
+        }
+    }
+    int c = __syncthreads_count(alive);
+    if (threadIdx.x == 0 && c) atomicAdd(&stats[2], (uint32_t)c);
+}
+
+// filter_softclips_mindistance findflanks.py:171-200.  A site with 5p clips needs a surviving site with 3p clips at a
+// strictly smaller position within mindist (misc.takeClosestSmaller, has_nearby_3p_mate 551-558); a site with 3p clips
+// needs a surviving 5p site strictly to the right (has_nearby_5p_mate 542-549).  Counts decide, not keep flags (Q5).
+// The table is sorted by gpos with distinct positions; dead sites are skipped (they left the dict in an earlier round).
+__global__ void k_mindistance(const uint32_t *gpos, const uint32_t *cnt2, const uint32_t *st_in, uint32_t *st_out, const uint32_t *n_p, uint32_t n_val, int mindist, uint32_t *stat) {
+    uint32_t n = n_p ? *n_p : n_val;
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    int alive = 0;
+    if (i < n) {
+        uint32_t s = st_in[i];
+        if (s & 4) {
+            uint32_t g = gpos[i];
+            uint32_t md = mindist < 0 ? 0u : (uint32_t)mindist;
+            if (cnt2[2 * i] > 0) {
+                bool found = false;
+                if (mindist >= 1)
+                    for (int64_t j = (int64_t)i - 1; j >= 0 && g - gpos[j] <= md; j--)
+                        if ((st_in[j] & 4) && cnt2[2 * j + 1] > 0) { found = true; break; }
+                if (!found) s &= ~1u;
+            }
+            if (cnt2[2 * i + 1] > 0) {
+                bool found = false;
+                if (mindist >= 1)
+                    for (uint32_t j = i + 1; j < n && gpos[j] - g <= md; j++)
+                        if ((st_in[j] & 4) && cnt2[2 * j] > 0) { found = true; break; }
+                if (!found) s &= ~2u;
+            }
+            if (!(s & 3)) s &= ~4u;
+            alive = (s >> 2) & 1;
+        }
+        st_out[i] = s;
+    }
+    int c = __syncthreads_count(alive);
+    if (threadIdx.x == 0 && c) atomicAdd(stat, (uint32_t)c);
+}
+
+__global__ void k_alive_flags(const uint32_t *st, const uint32_t *n_p, uint32_t cap, uint32_t *flag) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= cap) return;
+    flag[i] = (i < *n_p && (st[i] & 4)) ? 1u : 0u;
+}
+
+// active-site table (dense): everything later stages need, in site (gpos) order
+struct ActTab {
+    uint32_t *site, *gpos; int32_t *contig; uint32_t *cnt2, *st;
+    uint32_t *counts;   // counts[8*k + c]: runthrough si5 si3 li5 li3 del updel downdel
+};
+
+__global__ void k_compact_sites(SiteTab T, const uint32_t *n_p, const uint32_t *scan, ActTab A) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= *n_p || !(T.st[i] & 4)) return;
+    uint32_t k = scan[i];
+    A.site[k] = i; A.gpos[k] = T.gpos[i]; A.contig[k] = T.contig[i];
+    A.cnt2[2 * k] = T.cnt2[2 * i]; A.cnt2[2 * k + 1] = T.cnt2[2 * i + 1];
+    A.st[k] = T.st[i];
+}
+
+// ---- K6: parse_unclipped_read_info findflanks.py:349-509 ----------------------------------------------------------
+// One workgroup per active site.  Reads overlapping [pos-1, pos+2) (clamped, get_reads_at_site 399-415) that pass the
+// read filters are classified at pos (six categories) and, deletions only, at pos-1 and pos+1 (380-396).  A read counts
+// for a set only if no earlier read of the same query name (link chain) falls in the same set: that is len(set(names)).
+__device__ __forceinline__ int d_set_of(const DevReads &R, const DevParams &P, int64_t r, uint8_t f, int32_t q, int qi) {
+    if (d_clipped_at(R, r, f, q)) return -1;                      // findflanks.py:429-430
+    int cat = d_classify(R, P, r, f, q, qi != 0);
+    if (qi == 0) return cat - 1;                                  // CAT_NONE -> -1
+    return cat == CAT_DELETION ? 5 + qi : -1;                     // 6 upstream, 7 downstream
+}
+
+__global__ __launch_bounds__(256) void k_classify(DevReads R, DevParams P, ActTab A, uint32_t n_act) {
+    __shared__ uint32_t cnt[8];
+    __shared__ int64_t range[2];
+    const uint32_t k = blockIdx.x;
+    if (k >= n_act) return;
+    const int32_t contig = A.contig[k];
+    const int32_t pos = (int32_t)(A.gpos[k] - R.contig_base[contig]) - 1;
+    const int32_t clen = R.contig_len[contig];
+    int32_t start = pos - 1, end = pos + 2;
+    if (start < 0) start = 0;
+    if (end > clen) end = clen;
+    if (threadIdx.x < 8) cnt[threadIdx.x] = 0;
+    if (threadIdx.x == 0) {
+        if (start < end) d_fetch_range(R, contig, start, end, &range[0], &range[1]);
+        else { range[0] = 0; range[1] = 0; }
+    }
+    __syncthreads();
+    const int64_t lo = range[0], hi = range[1];
+    for (int64_t r = lo + threadIdx.x; r < hi; r += blockDim.x) {
+        if (!d_overlaps(R, r, start)) continue;
+        const uint8_t f = R.flags[r];
+        if (!d_passes(R, P, r, f)) continue;
+        for (int qi = 0; qi < 3; qi++) {
+            int32_t q = qi == 0 ? pos : (qi == 1 ? pos - 1 : pos + 1);
+            if (qi == 1 && pos - 1 < 0) continue;                 // findflanks.py:382
+            if (qi == 2 && pos + 1 >= clen) continue;             // findflanks.py:387
+            int set = d_set_of(R, P, r, f, q, qi);
+            if (set < 0) continue;
+            bool dup = false;
+            int64_t prev = r;
+            for (int64_t p = R.link[r]; p >= 0 && p < prev; prev = p, p = R.link[p]) {
+                if ((int32_t)R.contig_id[p] != contig) continue;
+                if (!(R.ref_start[p] < end && d_overlaps(R, p, start))) continue;
+                const uint8_t fp = R.flags[p];
+                if (!d_passes(R, P, p, fp)) continue;
+                if (d_set_of(R, P, p, fp, q, qi) == set) { dup = true; break; }
+            }
+            if (!dup) atomicAdd(&cnt[set], 1u);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 8) A.counts[8 * k + threadIdx.x] = cnt[threadIdx.x];
+}
+
+// ---- K7: filter_softclips_count_ratios findflanks.py:203-239; ratios 827-845 (float64, quirk Q8) -------------------
+__global__ void k_ratio_filter(ActTab A, uint32_t n_act, double minratio, double maxir, uint32_t *stat) {
+    uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    int alive = 0;
+    if (k < n_act) {
+        uint32_t s = A.st[k];
+        if (s & 4) {
+            const uint32_t *c = A.counts + 8 * k;
+            uint32_t sc5 = A.cnt2[2 * k], sc3 = A.cnt2[2 * k + 1];
+            uint32_t run = c[0], si5 = c[1], si3 = c[2], li5 = c[3], li3 = c[4], del = c[5], up = c[6], down = c[7];
+            double tot = (double)(sc5 + sc3 + run + si5 + si3 + li5 + li3 + del);     // get_total_count 789-795 (Q7)
+            if (s & 1) { if ((double)(sc5 + li5 + li3) / tot < minratio || (double)(si5 + del) / tot > maxir) s &= ~1u; }
+            if (s & 2) { if ((double)(sc3 + li5 + li3) / tot < minratio || (double)(si3 + del) / tot > maxir) s &= ~2u; }
+            if (s & 3) { if ((double)down / tot > maxir || (double)up / tot > maxir) s &= ~3u; }
+            if (!(s & 3)) s &= ~4u;
+            A.st[k] = s;
+            alive = (s >> 2) & 1;
+        }
+    }
+    int c = __syncthreads_count(alive);
+    if (threadIdx.x == 0 && c) atomicAdd(stat, (uint32_t)c);
+}
+
+// ---- consensus filters findflanks.py:241-342 -----------------------------------------------------------------------
+__global__ void k_consensus_filters(ActTab A, uint32_t n_act, const uint32_t *n_pass_len, const uint32_t *n_pass_both, uint32_t *stats) {
+    uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_act) return;
+    uint32_t s = A.st[k];
+    if (!(s & 4)) return;
+    // filter_consensus_sequences_minlength
+    uint32_t n6 = 0, n7 = 0, n8 = 0;
+    for (int side = 0; side < 2; side++) if (s & (1u << side)) { uint32_t c = n_pass_len[2 * k + side]; if (!c) s &= ~(1u << side); else n6 += c; }
+    if (!(s & 3)) { A.st[k] = s & ~4u; return; }
+    atomicAdd(&stats[6], n6);
+    // filter_consensus_sequences_mincount
+    for (int side = 0; side < 2; side++) if (s & (1u << side)) { uint32_t c = n_pass_both[2 * k + side]; if (!c) s &= ~(1u << side); else { n7 += c; n8 += 1; } }
+    if (!(s & 3)) { A.st[k] = s & ~4u; return; }
+    atomicAdd(&stats[7], n7);
+    atomicAdd(&stats[8], n8);   // filter_multiple_consensus_sequences keeps one per remaining side
+    A.st[k] = s;
+}
+
+// =====================================================================================================================
+static int read_back(mfk_ctx *ctx, const void *dev, void *host, size_t bytes) {
+    void *pin = pinned_buf(ctx, bytes);
+    if (!pin) { snprintf(ctx->err, sizeof ctx->err, "pinned allocation failed"); return 1; }
+    HIPCHK(hipMemcpyAsync(pin, dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    memcpy(host, pin, bytes);
+    return 0;
+}
+
+static const char BASE_ASCII[] = "=ACMGRSVTWYHKDBN";
+
+extern "C" int mfk_findflanks(mfk_ctx *ctx, const mfk_reads *reads, const mfk_params *params, int stop_after, int64_t *n_sites_out, int64_t *n_flanks_out, int64_t *seq_bytes_out) {
+    if (!ctx || !reads || !params) return 1;
+    HIPCHK(hipSetDevice(ctx->device));
+    ctx->err[0] = 0;
+    ctx->sites.clear(); ctx->flanks.clear(); ctx->seqs.clear();
+    memset(ctx->stats, 0, sizeof ctx->stats);
+    if (n_sites_out) *n_sites_out = 0;
+    if (n_flanks_out) *n_flanks_out = 0;
+    if (seq_bytes_out) *seq_bytes_out = 0;
+    if (stop_after < MFK_STAGE_PARSE) stop_after = MFK_STAGE_PARSE;
+    arena_reset(ctx);
+    DevReads R; DevParams P;
+    if (int rc = upload_reads(ctx, reads, params, &R, &P)) return rc;
+    hipStream_t st = ctx->stream;
+    HIPCHK(hipEventRecord(ctx->ev0, st));
+    uint32_t *d_stats = aalloc<uint32_t>(ctx, MFK_N_STATS);
+    if (!d_stats) return 1;
+    HIPCHK(hipMemsetAsync(d_stats, 0, MFK_N_STATS * 4, st));
+
+    // ---- stage 1: parse_softclips -------------------------------------------------------------------------------
+    const int64_t ngroups = (R.n + 15) >> 4;
+    unsigned nblk = (unsigned)((ngroups + SCAN_THREADS - 1) / SCAN_THREADS);
+    if (nblk > SCAN_MAX_BLOCKS) nblk = SCAN_MAX_BLOCKS;
+    if (nblk < 1) nblk = 1;
+    uint32_t *blk_cnt = aalloc<uint32_t>(ctx, nblk), *blk_off = aalloc<uint32_t>(ctx, nblk + 1);
+    if (!blk_cnt || !blk_off) return 1;
+    hipLaunchKernelGGL(k_scan_clips<false>, dim3(nblk), dim3(SCAN_THREADS), 0, st, R, P, blk_cnt, (const uint32_t *)nullptr, (uint64_t *)nullptr);
+    KCHK();
+    if (int rc = dev_excl_scan32(ctx, blk_cnt, blk_off, nblk)) return rc;
+    uint32_t E = 0;
+    if (int rc = read_back(ctx, blk_off + nblk, &E, 4)) return rc;
+    ctx->stats[10] = E;
+
+    uint32_t n_act = 0;
+    ActTab A; memset(&A, 0, sizeof A);
+    SiteTab T; memset(&T, 0, sizeof T);
+    uint64_t *ev_sorted = nullptr; uint8_t *ev_info = nullptr;
+    uint32_t *ascan = nullptr; const uint32_t *n_sites_p = nullptr;
+    if (E > 0) {
+        uint64_t *ev = aalloc<uint64_t>(ctx, E);
+        ev_sorted = aalloc<uint64_t>(ctx, E);
+        if (!ev || !ev_sorted) return 1;
+        hipLaunchKernelGGL(k_scan_clips<true>, dim3(nblk), dim3(SCAN_THREADS), 0, st, R, P, (uint32_t *)nullptr, (const uint32_t *)blk_off, ev);
+        KCHK();
+        if (int rc = dev_sort_keys64(ctx, ev, ev_sorted, E, 0, 64)) return rc;
+        ev_info = aalloc<uint8_t>(ctx, E);
+        uint32_t *head = aalloc<uint32_t>(ctx, E), *head_scan = aalloc<uint32_t>(ctx, (size_t)E + 1);
+        T.gpos = aalloc<uint32_t>(ctx, E); T.contig = aalloc<int32_t>(ctx, E); T.cnt2 = aalloc<uint32_t>(ctx, 2 * (size_t)E);
+        T.sflags = aalloc<uint32_t>(ctx, E); T.ev_begin = aalloc<uint32_t>(ctx, E); T.ev_mid = aalloc<uint32_t>(ctx, E);
+        T.ev_end = aalloc<uint32_t>(ctx, E); T.st = aalloc<uint32_t>(ctx, E);
+        uint32_t *st2 = aalloc<uint32_t>(ctx, E);
+        ascan = aalloc<uint32_t>(ctx, (size_t)E + 1);
+        if (!ev_info || !head || !head_scan || !T.gpos || !T.contig || !T.cnt2 || !T.sflags || !T.ev_begin || !T.ev_mid || !T.ev_end || !T.st || !st2 || !ascan) return 1;
+        HIPCHK(hipMemsetAsync(T.cnt2, 0, 2 * (size_t)E * 4, st));
+        HIPCHK(hipMemsetAsync(T.sflags, 0, (size_t)E * 4, st));
+        HIPCHK(hipMemsetAsync(T.ev_mid, 0xFF, (size_t)E * 4, st));
+        const unsigned eb = nblocks(E, 256);
+        hipLaunchKernelGGL(k_event_info, dim3(eb), dim3(256), 0, st, R, P, (const uint64_t *)ev_sorted, E, ev_info, head);
+        KCHK();
+        if (int rc = dev_excl_scan32(ctx, head, head_scan, E)) return rc;
+        n_sites_p = head_scan + E;
+        hipLaunchKernelGGL(k_site_accumulate, dim3(eb), dim3(256), 0, st, R, (const uint64_t *)ev_sorted, (const uint8_t *)ev_info, (const uint32_t *)head_scan, E, T);
+        KCHK();
+        hipLaunchKernelGGL(k_site_init, dim3(eb), dim3(256), 0, st, T, n_sites_p, d_stats);
+        KCHK();
+        if (stop_after >= MFK_STAGE_MINLENGTH) { hipLaunchKernelGGL(k_filter_minlength, dim3(eb), dim3(256), 0, st, T, n_sites_p, d_stats); KCHK(); }
+        if (stop_after >= MFK_STAGE_MINCOUNT) { hipLaunchKernelGGL(k_filter_mincount, dim3(eb), dim3(256), 0, st, T, n_sites_p, P.mincount, d_stats); KCHK(); }
+        if (stop_after >= MFK_STAGE_MINDIST1) {
+            hipLaunchKernelGGL(k_mindistance, dim3(eb), dim3(256), 0, st, (const uint32_t *)T.gpos, (const uint32_t *)T.cnt2, (const uint32_t *)T.st, st2, n_sites_p, 0u, P.mindist, d_stats + 3);
+            KCHK();
+            T.st = st2;
+        }
+        // surviving sites -> dense active table
+        hipLaunchKernelGGL(k_alive_flags, dim3(eb), dim3(256), 0, st, (const uint32_t *)T.st, n_sites_p, E, head);
+        KCHK();
+        if (int rc = dev_excl_scan32(ctx, head, ascan, E)) return rc;
+        if (int rc = read_back(ctx, ascan + E, &n_act, 4)) return rc;
+    }
+    ConsensusIO io; memset(&io, 0, sizeof io);
+    if (n_act > 0) {
+        A.site = aalloc<uint32_t>(ctx, n_act); A.gpos = aalloc<uint32_t>(ctx, n_act); A.contig = aalloc<int32_t>(ctx, n_act);
+        A.cnt2 = aalloc<uint32_t>(ctx, 2 * (size_t)n_act); A.st = aalloc<uint32_t>(ctx, n_act); A.counts = aalloc<uint32_t>(ctx, 8 * (size_t)n_act);
+        uint32_t *st2 = aalloc<uint32_t>(ctx, n_act);
+        if (!A.site || !A.gpos || !A.contig || !A.cnt2 || !A.st || !A.counts || !st2) return 1;
+        HIPCHK(hipMemsetAsync(A.counts, 0, 8 * (size_t)n_act * 4, st));
+        const unsigned eb = nblocks(E, 256), ab = nblocks(n_act, 256);
+        hipLaunchKernelGGL(k_compact_sites, dim3(eb), dim3(256), 0, st, T, n_sites_p, (const uint32_t *)ascan, A);
+        KCHK();
+        if (stop_after >= MFK_STAGE_UNCLIPPED) {
+            hipLaunchKernelGGL(k_classify, dim3(n_act), dim3(256), 0, st, R, P, A, n_act);
+            KCHK();
+        }
+        if (stop_after >= MFK_STAGE_RATIOS) {
+            hipLaunchKernelGGL(k_ratio_filter, dim3(ab), dim3(256), 0, st, A, n_act, P.minratio, P.maxir, d_stats + 4);
+            KCHK();
+        }
+        if (stop_after >= MFK_STAGE_MINDIST2) {
+            hipLaunchKernelGGL(k_mindistance, dim3(ab), dim3(256), 0, st, (const uint32_t *)A.gpos, (const uint32_t *)A.cnt2, (const uint32_t *)A.st, st2, (const uint32_t *)nullptr, n_act, P.mindist, d_stats + 5);
+            KCHK();
+            uint32_t *t = A.st; A.st = st2; st2 = t;
+        }
+        if (stop_after >= MFK_STAGE_CONSENSUS) {
+            io.ev_keys = ev_sorted; io.ev_info = ev_info; io.n_events = E;
+            io.n_act = n_act; io.act_site = A.site; io.act_st = A.st;
+            io.site_ev_begin = T.ev_begin; io.site_ev_mid = T.ev_mid; io.site_ev_end = T.ev_end;
+            io.cons_count = aalloc<int32_t>(ctx, 2 * (size_t)n_act); io.cons_len = aalloc<int32_t>(ctx, 2 * (size_t)n_act);
+            io.n_pass_len = aalloc<uint32_t>(ctx, 2 * (size_t)n_act); io.n_pass_both = aalloc<uint32_t>(ctx, 2 * (size_t)n_act);
+            if (!io.cons_count || !io.cons_len || !io.n_pass_len || !io.n_pass_both) return 1;
+            HIPCHK(hipMemsetAsync(io.cons_count, 0, 2 * (size_t)n_act * 4, st));
+            HIPCHK(hipMemsetAsync(io.cons_len, 0, 2 * (size_t)n_act * 4, st));
+            HIPCHK(hipMemsetAsync(io.n_pass_len, 0, 2 * (size_t)n_act * 4, st));
+            HIPCHK(hipMemsetAsync(io.n_pass_both, 0, 2 * (size_t)n_act * 4, st));
+            if (int rc = run_consensus(ctx, R, P, io)) return rc;
+            hipLaunchKernelGGL(k_consensus_filters, dim3(ab), dim3(256), 0, st, A, n_act, (const uint32_t *)io.n_pass_len, (const uint32_t *)io.n_pass_both, d_stats);
+            KCHK();
+        }
+        if (stop_after >= MFK_STAGE_ALL) {
+            hipLaunchKernelGGL(k_mindistance, dim3(ab), dim3(256), 0, st, (const uint32_t *)A.gpos, (const uint32_t *)A.cnt2, (const uint32_t *)A.st, st2, (const uint32_t *)nullptr, n_act, P.mindist, d_stats + 9);
+            KCHK();
+            uint32_t *t = A.st; A.st = st2; st2 = t;
+        }
+    }
+    HIPCHK(hipEventRecord(ctx->ev1, st));
+    // ---- results to the host -------------------------------------------------------------------------------------
+    uint32_t h_stats[MFK_N_STATS];
+    if (int rc = read_back(ctx, d_stats, h_stats, sizeof h_stats)) return rc;
+    for (int i = 0; i < 10; i++) ctx->stats[i] = h_stats[i];
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1) == hipSuccess) ctx->last_ms = ms;
+    if (n_act > 0) {
+        std::vector<uint32_t> gpos(n_act), cnt2(2 * (size_t)n_act), stv(n_act), counts(8 * (size_t)n_act);
+        std::vector<int32_t> contig(n_act);
+        if (int rc = read_back(ctx, A.gpos, gpos.data(), n_act * 4)) return rc;
+        if (int rc = read_back(ctx, A.contig, contig.data(), n_act * 4)) return rc;
+        if (int rc = read_back(ctx, A.cnt2, cnt2.data(), 2 * (size_t)n_act * 4)) return rc;
+        if (int rc = read_back(ctx, A.st, stv.data(), n_act * 4)) return rc;
+        if (int rc = read_back(ctx, A.counts, counts.data(), 8 * (size_t)n_act * 4)) return rc;
+        std::vector<int32_t> ccount, clen; std::vector<char> cchars;
+        const bool have_cons = stop_after >= MFK_STAGE_CONSENSUS;
+        if (have_cons) {
+            ccount.resize(2 * (size_t)n_act); clen.resize(2 * (size_t)n_act);
+            if (int rc = read_back(ctx, io.cons_count, ccount.data(), 2 * (size_t)n_act * 4)) return rc;
+            if (int rc = read_back(ctx, io.cons_len, clen.data(), 2 * (size_t)n_act * 4)) return rc;
+            cchars.resize((size_t)2 * n_act * io.cons_stride + 1);
+            if (io.cons_stride) if (int rc = read_back(ctx, io.cons_chars, cchars.data(), (size_t)2 * n_act * io.cons_stride)) return rc;
+        }
+        // contig_base on the host (same formula as upload_reads)
+        std::vector<int64_t> base(reads->n_contigs);
+        { int64_t pad = (int64_t)params->min_distance_to_mate + params->max_direct_repeat_length + 64; if (pad < 64) pad = 64; int64_t b = 0; for (int c = 0; c < reads->n_contigs; c++) { base[c] = b; b += (int64_t)reads->h_contig_len[c] + 2 + pad; } }
+        for (uint32_t k = 0; k < n_act; k++) {
+            if (!(stv[k] & 4)) continue;
+            mfk_site s; memset(&s, 0, sizeof s);
+            s.contig_id = contig[k]; s.pos = (int32_t)((int64_t)gpos[k] - base[contig[k]] - 1);
+            s.softclip_count_5p = (int32_t)cnt2[2 * k]; s.softclip_count_3p = (int32_t)cnt2[2 * k + 1];
+            const uint32_t *c = &counts[8 * (size_t)k];
+            s.runthrough_count = c[0]; s.small_insertion_count_5p = c[1]; s.small_insertion_count_3p = c[2];
+            s.large_insertion_count_5p = c[3]; s.large_insertion_count_3p = c[4]; s.deletion_count = c[5];
+            s.upstream_deletion_count = c[6]; s.downstream_deletion_count = c[7];
+            s.keep_5p = stv[k] & 1; s.keep_3p = (stv[k] >> 1) & 1;
+            ctx->sites.push_back(s);
+            if (stop_after < MFK_STAGE_ALL) continue;
+            // make_dataframe findflanks.py:631-670: 5p row then 3p row, one consensus per kept side
+            for (int side = 0; side < 2; side++) {
+                if (!(stv[k] & (1u << side))) continue;
+                mfk_flank f; memset(&f, 0, sizeof f);
+                f.contig_id = s.contig_id; f.pos = s.pos; f.orient = side == 0 ? 5 : 3;
+                f.softclip_count_5p = s.softclip_count_5p; f.softclip_count_3p = s.softclip_count_3p; f.runthrough_count = s.runthrough_count;
+                f.small_insertion_count_5p = s.small_insertion_count_5p; f.small_insertion_count_3p = s.small_insertion_count_3p;
+                f.large_insertion_count_5p = s.large_insertion_count_5p; f.large_insertion_count_3p = s.large_insertion_count_3p;
+                f.deletion_count = s.deletion_count; f.upstream_deletion_count = s.upstream_deletion_count; f.downstream_deletion_count = s.downstream_deletion_count;
+                f.total_count = s.softclip_count_5p + s.softclip_count_3p + s.runthrough_count + s.small_insertion_count_5p + s.small_insertion_count_3p + s.large_insertion_count_5p + s.large_insertion_count_3p + s.deletion_count;
+                size_t job = 2 * (size_t)k + side;
+                f.consensus_softclip_count = ccount[job];
+                f.seq_len = clen[job]; f.seq_off = (int64_t)ctx->seqs.size();
+                ctx->seqs.append(cchars.data() + job * io.cons_stride, (size_t)clen[job]);
+                ctx->flanks.push_back(f);
+            }
+        }
+    }
+    ctx->stats[11] = (int64_t)ctx->flanks.size();
+    if (n_sites_out) *n_sites_out = (int64_t)ctx->sites.size();
+    if (n_flanks_out) *n_flanks_out = (int64_t)ctx->flanks.size();
+    if (seq_bytes_out) *seq_bytes_out = (int64_t)ctx->seqs.size();
+    (void)BASE_ASCII;
+    return 0;
+}
+
+extern "C" int mfk_findflanks_fetch(mfk_ctx *ctx, mfk_site *sites, mfk_flank *flanks, char *seqs, int64_t *stats) {
+    if (!ctx) return 1;
+    if (sites && !ctx->sites.empty()) memcpy(sites, ctx->sites.data(), ctx->sites.size() * sizeof(mfk_site));
+    if (flanks && !ctx->flanks.empty()) memcpy(flanks, ctx->flanks.data(), ctx->flanks.size() * sizeof(mfk_flank));
+    if (seqs && !ctx->seqs.empty()) memcpy(seqs, ctx->seqs.data(), ctx->seqs.size());
+    if (stats) memcpy(stats, ctx->stats, sizeof ctx->stats);
+    return 0;
+}

@@ -1,0 +1,76 @@
+// mfk_host.h -- host-side context of libmfk.so: one HIP stream, a growable device arena that is reset at the start
+// of every compute call, a pinned staging buffer for the few counters the host reads back, and result storage.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "mfk_device.h"
+
+struct Chunk { char *p; size_t cap, used; };
+
+struct mfk_ctx {
+    int device;
+    hipStream_t stream;
+    hipEvent_t ev0, ev1;
+    double last_ms;
+    std::vector<Chunk> chunks;      // device arena
+    void *pinned; size_t pinned_cap;
+    char err[1024];
+    // findflanks results (host)
+    std::vector<mfk_site> sites;
+    std::vector<mfk_flank> flanks;
+    std::string seqs;
+    int64_t stats[MFK_N_STATS];
+    // pairflanks results (host)
+    std::vector<mfk_pair> pairs;
+    std::string strs;
+    int64_t pstats[MFK_N_STATS];
+};
+
+#define HIPCHK(call)                                                                                         \
+    do {                                                                                                     \
+        hipError_t e_ = (call);                                                                              \
+        if (e_ != hipSuccess) {                                                                              \
+            snprintf(ctx->err, sizeof ctx->err, "%s failed at %s:%d: %s", #call, __FILE__, __LINE__,        \
+                     hipGetErrorString(e_));                                                                 \
+            return 100;                                                                                      \
+        }                                                                                                    \
+    } while (0)
+
+#define KCHK() HIPCHK(hipGetLastError())
+
+// arena ----------------------------------------------------------------------------------------------------------
+void arena_reset(mfk_ctx *ctx);                       // frees nothing on the fast path; merges chunks after growth
+void *arena_alloc(mfk_ctx *ctx, size_t bytes);        // 256-byte aligned device memory valid until the next reset
+template <typename T> static inline T *aalloc(mfk_ctx *ctx, size_t n) { return (T *)arena_alloc(ctx, (n ? n : 1) * sizeof(T)); }
+void *pinned_buf(mfk_ctx *ctx, size_t bytes);
+
+int upload_reads(mfk_ctx *ctx, const mfk_reads *reads, const mfk_params *params, DevReads *R, DevParams *P);
+
+static inline unsigned nblocks(int64_t n, int threads) { int64_t b = (n + threads - 1) / threads; return (unsigned)(b < 1 ? 1 : b); }
+
+// device-wide primitives (rocPRIM) on the ctx stream, temp storage from the arena
+int dev_sort_keys64(mfk_ctx *ctx, uint64_t *keys_in, uint64_t *keys_out, size_t n, int begin_bit, int end_bit);
+int dev_sort_pairs64(mfk_ctx *ctx, uint64_t *keys_in, uint64_t *keys_out, uint32_t *vals_in, uint32_t *vals_out, size_t n, int begin_bit, int end_bit);
+int dev_excl_scan32(mfk_ctx *ctx, const uint32_t *in, uint32_t *out, size_t n);   // out has n+1 entries: out[n] = total
+int dev_excl_scan64(mfk_ctx *ctx, const uint32_t *in, uint64_t *out, size_t n);   // 64-bit sums, out[n] = total
+
+// consensus stage (mfk_consensus.hip): fills, per active site k and side s, cons_count / cons_len / n_pass_len /
+// n_pass_both and the consensus characters (ASCII) at cons_chars + job * cons_stride
+struct ConsensusIO {
+    // events, sorted by (gpos, side, read)
+    const uint64_t *ev_keys; const uint8_t *ev_info; uint32_t n_events;
+    // active sites
+    uint32_t n_act; const uint32_t *act_site; const uint32_t *act_st;     // st bits: 1 keep5, 2 keep3, 4 alive
+    const uint32_t *site_ev_begin, *site_ev_mid, *site_ev_end;             // indexed by site
+    // outputs, indexed by job = 2*k + side (side 0 = 5p, 1 = 3p)
+    int32_t *cons_count, *cons_len; uint32_t *n_pass_len, *n_pass_both;
+    char *cons_chars; uint32_t cons_stride;
+};
+int run_consensus(mfk_ctx *ctx, const DevReads &R, const DevParams &P, ConsensusIO &io);

@@ -1,0 +1,582 @@
+// mfk_pairflanks.hip -- the pairflanks pipeline of libmfk.so (replaces FlankPairer.run_pair_flanks,
+// pairflanks.py:96-122).  Kernels, in call order:
+//
+//   k_pair_window<count/fill>  pair_all_nearby_flanks (pairflanks.py:138-169): for each 5p flank the 3p flanks of the same
+//                              contig with pos5-maxdr-1 <= pos3 < pos5, in file order (binary-searched window when the
+//                              table is sorted, full scan otherwise)
+//   k_inverted_repeat          check_pairs_for_ir (172-219): one wave per candidate; local alignment of the combined
+//                              sequence against its reverse complement (einverted's model, match 3 / mismatch -4 / gap 12 /
+//                              threshold 15) with the score matrix in LDS, processed span by span (parity unpinned: the
+//                              reference shells out to EMBOSS einverted; DESIGN.md "IR definition")
+//   radix sort + k_assign      assign_pairs (222-250): stable order by (IR_length desc, diffcount asc, difflength asc),
+//                              then the greedy exclusion resolved in parallel rounds (a pair is kept when it is the
+//                              best undecided pair of both its flanks)
+//   k_spanning                 count_insertion_spanning_reads (370-391): one workgroup per kept pair
+//   k_junction_filter          filter_junction_spanning (421-431), fp64
+//   k_direct_repeats           get_direct_repeats (277-367): reference slice + quality-weighted pileup consensus over the
+//                              50-bp window in LDS
+#include "mfk_host.h"
+
+#define IR_MAXLEN 100      // 40 + 20 + 40 (truncated_flank_length, pairflanks.py:78, 183-186)
+#define IR_MAXREP 8
+
+struct FlankDev {
+    uint32_t n;
+    const int32_t *contig, *pos, *orient, *ccount, *total, *seq_len;
+    const int64_t *seq_off;
+    const char *seqs;
+};
+
+static int read_back_p(mfk_ctx *ctx, const void *dev, void *host, size_t bytes) {
+    void *pin = pinned_buf(ctx, bytes);
+    if (!pin) { snprintf(ctx->err, sizeof ctx->err, "pinned allocation failed"); return 1; }
+    HIPCHK(hipMemcpyAsync(pin, dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    memcpy(host, pin, bytes);
+    return 0;
+}
+
+// ---- pair_all_nearby_flanks ------------------------------------------------------------------------------------------
+template <bool FILL>
+__global__ void k_pair_window(FlankDev F, int maxdr, int sorted, uint32_t *count, const uint32_t *offset, uint32_t *c5, uint32_t *c3) {
+    uint32_t a = blockIdx.x * blockDim.x + threadIdx.x;
+    if (a >= F.n) return;
+    uint32_t c = 0;
+    if (F.orient[a] == 5) {
+        const int32_t contig = F.contig[a], pos5 = F.pos[a];
+        const int64_t min_pos = (int64_t)pos5 - maxdr - 1;
+        uint32_t lo = 0, hi = F.n;
+        if (sorted) {   // rows ordered by (contig, pos): only [first row >= (contig, min_pos), first row >= (contig, pos5)) can match
+            uint32_t l = 0, h = F.n;
+            while (l < h) { uint32_t m = (l + h) >> 1; if (F.contig[m] < contig || (F.contig[m] == contig && (int64_t)F.pos[m] < min_pos)) l = m + 1; else h = m; }
+            lo = l; h = F.n;
+            while (l < h) { uint32_t m = (l + h) >> 1; if (F.contig[m] < contig || (F.contig[m] == contig && F.pos[m] < pos5)) l = m + 1; else h = m; }
+            hi = l;
+        }
+        uint32_t o = FILL ? offset[a] : 0;
+        for (uint32_t b = lo; b < hi; b++) {
+            if (F.orient[b] != 3 || F.contig[b] != contig || (int64_t)F.pos[b] < min_pos || F.pos[b] >= pos5) continue;
+            if (FILL) { c5[o + c] = a; c3[o + c] = b; }
+            c++;
+        }
+    }
+    if (!FILL) count[a] = c;
+}
+
+// ---- inverted repeats ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int d_ir_code(char ch) {
+    switch (ch) { case 'A': case 'a': return 0; case 'C': case 'c': return 1; case 'G': case 'g': return 2; case 'T': case 't': return 3; default: return 4; }
+}
+
+// one wave per sequence.  s: LDS copy of the sequence codes; S: LDS L x L int16 score matrix.
+// out[6]: has_ir, arm1 start/end, arm2 start/end (1-based inclusive), number of repeats reported
+__device__ void d_ir_detect(const uint8_t *code, int L, int16_t *S, uint8_t *mask, int32_t *rep /* 4*IR_MAXREP, LDS */, int32_t *out) {
+    const int MATCH = 3, MISMATCH = -4, GAP = 12, THRESHOLD = 15;
+    const int lane = threadIdx.x & 63;
+    for (int i = lane; i < L; i += 64) mask[i] = 0;
+    __syncthreads();
+    int nrep = 0;
+    while (nrep < IR_MAXREP) {
+        for (int i = lane; i < L; i += 64) S[i * L + i] = 0;
+        __syncthreads();
+        unsigned bestkey = 0;   // score << 16 | (255 - j) << 8 | i : highest score, then smallest j, then largest i
+        for (int d = 1; d < L; d++) {
+            for (int i = lane; i + d < L; i += 64) {
+                int j = i + d, v = 0;
+                if (!mask[i] && !mask[j]) {
+                    int diag = d >= 2 ? S[(i + 1) * L + (j - 1)] : 0;
+                    int m = (code[i] < 4 && code[j] < 4 && code[i] + code[j] == 3) ? MATCH : MISMATCH;
+                    v = diag + m;
+                    int up = S[(i + 1) * L + j] - GAP, left = S[i * L + (j - 1)] - GAP;
+                    if (up > v) v = up;
+                    if (left > v) v = left;
+                    if (v < 0) v = 0;
+                }
+                S[i * L + j] = (int16_t)v;
+                unsigned key = ((unsigned)v << 16) | ((unsigned)(255 - j) << 8) | (unsigned)i;
+                if (v > 0 && key > bestkey) bestkey = key;
+            }
+            __syncthreads();
+        }
+        for (int o = 32; o > 0; o >>= 1) { unsigned other = __shfl_xor(bestkey, o, 64); if (other > bestkey) bestkey = other; }
+        int best = (int)(bestkey >> 16);
+        if (best < THRESHOLD) break;
+        if (lane == 0) {
+            int bi = (int)(bestkey & 255), bj = 255 - (int)((bestkey >> 8) & 255);
+            int i = bi, j = bj, ii = bi, jj = bj;
+            while (i < j && S[i * L + j] > 0) {
+                int diag = (j - i >= 2) ? S[(i + 1) * L + (j - 1)] : 0;
+                int m = (code[i] < 4 && code[j] < 4 && code[i] + code[j] == 3) ? MATCH : MISMATCH;
+                ii = i; jj = j;
+                if (S[i * L + j] == diag + m) { i++; j--; }
+                else if (S[i * L + j] == S[i * L + (j - 1)] - GAP) j--;
+                else i++;
+            }
+            rep[4 * nrep] = bi; rep[4 * nrep + 1] = ii; rep[4 * nrep + 2] = jj; rep[4 * nrep + 3] = bj;
+            for (int k = bi; k <= ii; k++) mask[k] = 1;
+            for (int k = jj; k <= bj; k++) mask[k] = 1;
+        }
+        nrep++;
+        __syncthreads();
+    }
+    if (lane == 0) {
+        // report order: outer end ascending, then arm1 start descending (scan order of the maxima)
+        for (int a = 1; a < nrep; a++) {
+            int32_t t0 = rep[4 * a], t1 = rep[4 * a + 1], t2 = rep[4 * a + 2], t3 = rep[4 * a + 3];
+            int b = a - 1;
+            while (b >= 0 && (rep[4 * b + 3] > t3 || (rep[4 * b + 3] == t3 && rep[4 * b] < t0))) {
+                rep[4 * b + 4] = rep[4 * b]; rep[4 * b + 5] = rep[4 * b + 1]; rep[4 * b + 6] = rep[4 * b + 2]; rep[4 * b + 7] = rep[4 * b + 3];
+                b--;
+            }
+            rep[4 * b + 4] = t0; rep[4 * b + 5] = t1; rep[4 * b + 6] = t2; rep[4 * b + 7] = t3;
+        }
+        // the reference's acceptance loop (pairflanks.py:196-205, pair_has_ir 253-266): the last accepted repeat wins
+        int has = 0, k1s = 0, k1e = 0, k2s = 0, k2e = 0;
+        for (int k = 0; k < nrep; k++) {
+            int ir1_pos_5p = rep[4 * k] + 1, ir2_pos_3p = rep[4 * k + 3] + 1;
+            if (ir1_pos_5p <= 15 && ir2_pos_3p >= L - 15) { has = 1; k1s = rep[4 * k] + 1; k1e = rep[4 * k + 1] + 1; k2s = rep[4 * k + 2] + 1; k2e = rep[4 * k + 3] + 1; }
+        }
+        out[0] = has; out[1] = k1s; out[2] = k1e; out[3] = k2s; out[4] = k2e; out[5] = nrep;
+    }
+    __syncthreads();
+}
+
+// generic entry: sequences given explicitly (mfk_ir_detect)
+__global__ __launch_bounds__(64) void k_ir_seqs(const char *seqs, const int64_t *off, uint32_t n, int32_t *out) {
+    __shared__ int16_t S[IR_MAXLEN * IR_MAXLEN];
+    __shared__ uint8_t code[IR_MAXLEN + 4], mask[IR_MAXLEN + 4];
+    __shared__ int32_t rep[4 * IR_MAXREP + 8];
+    uint32_t k = blockIdx.x;
+    if (k >= n) return;
+    int L = (int)(off[k + 1] - off[k]);
+    if (L > IR_MAXLEN) L = IR_MAXLEN;
+    for (int i = threadIdx.x; i < L; i += 64) code[i] = (uint8_t)d_ir_code(seqs[off[k] + i]);
+    __syncthreads();
+    d_ir_detect(code, L, S, mask, rep, out + 6 * (size_t)k);
+}
+
+// candidate pairs: combined = seq5[:40] + 'N'*20 + seq3[-40:]  (pairflanks.py:183-186, truncate_sequence 268-275)
+__global__ __launch_bounds__(64) void k_inverted_repeat(FlankDev F, const uint32_t *c5, const uint32_t *c3, uint32_t n, int32_t *out) {
+    __shared__ int16_t S[IR_MAXLEN * IR_MAXLEN];
+    __shared__ uint8_t code[IR_MAXLEN + 4], mask[IR_MAXLEN + 4];
+    __shared__ int32_t rep[4 * IR_MAXREP + 8];
+    uint32_t k = blockIdx.x;
+    if (k >= n) return;
+    uint32_t a = c5[k], b = c3[k];
+    int l5 = F.seq_len[a], l3 = F.seq_len[b];
+    int n5 = l5 > 40 ? 40 : l5, n3 = l3 > 40 ? 40 : l3;
+    int L = n5 + 20 + n3;
+    const char *s5 = F.seqs + F.seq_off[a], *s3 = F.seqs + F.seq_off[b] + (l3 - n3);
+    for (int i = threadIdx.x; i < L; i += 64) {
+        char ch = i < n5 ? s5[i] : (i < n5 + 20 ? 'N' : s3[i - n5 - 20]);
+        code[i] = (uint8_t)d_ir_code(ch);
+    }
+    __syncthreads();
+    d_ir_detect(code, L, S, mask, rep, out + 6 * (size_t)k);
+}
+
+// ---- assign_pairs ------------------------------------------------------------------------------------------------------
+__global__ void k_assign_keys(FlankDev F, const uint32_t *c5, const uint32_t *c3, const int32_t *ir, uint32_t n, uint64_t *keys, uint32_t *vals) {
+    uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    uint32_t a = c5[k], b = c3[k];
+    int irlen = ir[6 * k + 1] ? ir[6 * k + 4] - ir[6 * k + 3] + 1 : 0;      // IR_length = len(IR_5p) = arm2 (pairflanks.py:212-213, 225)
+    int64_t dc = (int64_t)F.ccount[a] - (int64_t)F.ccount[b]; if (dc < 0) dc = -dc;   // diffcount (226)
+    int dl = F.seq_len[a] - F.seq_len[b]; if (dl < 0) dl = -dl;             // difflength (227)
+    if (dl > 65535) dl = 65535;
+    keys[k] = ((uint64_t)(127 - irlen) << 48) | ((uint64_t)(dc & 0xFFFFFFFFll) << 16) | (uint64_t)dl;
+    vals[k] = k;
+}
+
+// greedy exclusion (pairflanks.py:233-245) in parallel rounds, one workgroup.  order[p] = candidate at sorted position p.
+__global__ __launch_bounds__(1024) void k_assign(const uint32_t *order, const uint32_t *c5, const uint32_t *c3, uint32_t n, uint32_t nF,
+                                                 uint32_t *best5, uint32_t *best3, uint8_t *used5, uint8_t *used3, uint8_t *state /* by sorted position */) {
+    __shared__ int undecided;
+    for (uint32_t i = threadIdx.x; i < nF; i += blockDim.x) { best5[i] = 0xFFFFFFFFu; best3[i] = 0xFFFFFFFFu; used5[i] = 0; used3[i] = 0; }
+    for (uint32_t p = threadIdx.x; p < n; p += blockDim.x) state[p] = 0;
+    __syncthreads();
+    for (uint32_t round = 0; round <= n; round++) {
+        if (threadIdx.x == 0) undecided = 0;
+        __syncthreads();
+        for (uint32_t p = threadIdx.x; p < n; p += blockDim.x) {
+            if (state[p]) continue;
+            uint32_t c = order[p], a = c5[c], b = c3[c];
+            if (used5[a] || used3[b]) { state[p] = 2; continue; }
+            atomicMin(&best5[a], p); atomicMin(&best3[b], p);
+            undecided = 1;
+        }
+        __syncthreads();
+        if (!undecided) break;
+        for (uint32_t p = threadIdx.x; p < n; p += blockDim.x) {
+            if (state[p]) continue;
+            uint32_t c = order[p], a = c5[c], b = c3[c];
+            if (best5[a] == p && best3[b] == p) { state[p] = 1; used5[a] = 1; used3[b] = 1; }
+        }
+        __syncthreads();
+        for (uint32_t p = threadIdx.x; p < n; p += blockDim.x) {
+            if (state[p]) continue;
+            uint32_t c = order[p];
+            best5[c5[c]] = 0xFFFFFFFFu; best3[c3[c]] = 0xFFFFFFFFu;
+        }
+        __syncthreads();
+    }
+}
+
+__global__ void k_kept_flags(const uint8_t *state, uint32_t n, uint32_t *flag) {
+    uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < n) flag[p] = state[p] == 1 ? 1u : 0u;
+}
+
+// kept pairs in sorted_pairs order -> keys for sort_values(['contig','pos_5p','pos_3p']) (pairflanks.py:248)
+__global__ void k_kept_keys(FlankDev F, const uint32_t *order, const uint32_t *c5, const uint32_t *c3, const uint8_t *state, const uint32_t *scan, uint32_t n,
+                            const int32_t *contig_rank, uint64_t *keys, uint32_t *vals) {
+    uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n || state[p] != 1) return;
+    uint32_t c = order[p], a = c5[c], b = c3[c], o = scan[p];
+    uint32_t diff = (uint32_t)(F.pos[a] - F.pos[b]);
+    if (diff > 0xFFFF) diff = 0xFFFF;
+    keys[o] = ((uint64_t)(uint32_t)contig_rank[F.contig[a]] << 48) | ((uint64_t)(uint32_t)(F.pos[a] + 1) << 16) | (uint64_t)(0xFFFFu - diff);
+    vals[o] = c;
+}
+
+// ---- count_insertion_spanning_reads -------------------------------------------------------------------------------------
+__device__ __forceinline__ bool d_spans(const DevReads &R, const DevParams &P, int64_t r, uint8_t f, int32_t pos3, int32_t pos5) {
+    // pairflanks.py:381-383, insertion_spanning_length = 10 (quirk P7)
+    return R.ref_start[r] < pos3 - 10 && R.ref_end[r] > pos5 + 10 + 1 &&
+           !(d_large_insertion_at(R, P, r, f, pos3) || d_large_insertion_at(R, P, r, f, pos5));
+}
+
+__global__ __launch_bounds__(256) void k_spanning(DevReads R, DevParams P, FlankDev F, const uint32_t *kept, const uint32_t *c5, const uint32_t *c3, uint32_t n, uint32_t *spanning) {
+    __shared__ uint32_t cnt;
+    __shared__ int64_t range[2];
+    uint32_t k = blockIdx.x;
+    if (k >= n) return;
+    uint32_t c = kept[k];
+    const int32_t contig = F.contig[c5[c]], pos5 = F.pos[c5[c]], pos3 = F.pos[c3[c]];
+    const int32_t clen = R.contig_len[contig];
+    int32_t start = pos3 - 1, end = pos5 + 2;
+    if (start < 0) start = 0;
+    if (end > clen) end = clen;
+    if (threadIdx.x == 0) {
+        cnt = 0;
+        if (start < end) d_fetch_range(R, contig, start, end, &range[0], &range[1]); else { range[0] = 0; range[1] = 0; }
+    }
+    __syncthreads();
+    for (int64_t r = range[0] + threadIdx.x; r < range[1]; r += blockDim.x) {
+        if (!d_overlaps(R, r, start)) continue;
+        uint8_t f = R.flags[r];
+        if (!d_passes(R, P, r, f) || !d_spans(R, P, r, f, pos3, pos5)) continue;
+        bool dup = false;
+        int64_t prev = r;
+        for (int64_t p = R.link[r]; p >= 0 && p < prev; prev = p, p = R.link[p]) {
+            if ((int32_t)R.contig_id[p] != contig) continue;
+            if (!(R.ref_start[p] < end && d_overlaps(R, p, start))) continue;
+            uint8_t fp = R.flags[p];
+            if (d_passes(R, P, p, fp) && d_spans(R, P, p, fp, pos3, pos5)) { dup = true; break; }
+        }
+        if (!dup) atomicAdd(&cnt, 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) spanning[k] = cnt;
+}
+
+// filter_junction_spanning pairflanks.py:421-431 (float64, strict <, quirk P9)
+__global__ void k_junction_filter(FlankDev F, const uint32_t *kept, const uint32_t *c5, const uint32_t *c3, const uint32_t *spanning, const int32_t *ir, uint32_t n, double maxjsp, uint32_t *flag, uint32_t *pstats) {
+    uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    uint32_t c = kept[k];
+    double total = (double)((int64_t)F.total[c5[c]] + (int64_t)F.total[c3[c]]) / 2;
+    double prop = (double)spanning[k] / total;
+    flag[k] = prop < maxjsp ? 1u : 0u;
+    if (ir[6 * c]) atomicAdd(&pstats[2], 1u);
+    if (spanning[k] > 0) atomicAdd(&pstats[3], 1u);
+}
+
+__global__ void k_final_list(const uint32_t *kept, const uint32_t *flag, const uint32_t *scan, const uint32_t *spanning, uint32_t n, uint32_t *fin, uint32_t *fin_span) {
+    uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n || !flag[k]) return;
+    fin[scan[k]] = kept[k]; fin_span[scan[k]] = spanning[k];
+}
+
+// ---- get_direct_repeats ---------------------------------------------------------------------------------------------------
+#define DR_WIN 50
+// per final pair: dr_out[k*stride ...] = reference repeat, dr_out[k*stride + half ...] = reads consensus
+__global__ __launch_bounds__(256) void k_direct_repeats(DevReads R, FlankDev F, const uint32_t *fin, const uint32_t *c5, const uint32_t *c3, uint32_t n,
+                                                        const uint8_t *genome, const int64_t *goff, char *dr_out, uint32_t stride, int32_t *dr_meta /* 3 per pair: ref_len, reads_len, err */) {
+    __shared__ uint32_t sum[DR_WIN][17];
+    __shared__ uint32_t firstr[DR_WIN][17];
+    __shared__ uint8_t refch[DR_WIN];
+    __shared__ int64_t range[2];
+    __shared__ int err;
+    const char codes[17] = "=ACMGRSVTWYHKDBN";
+    uint32_t k = blockIdx.x;
+    if (k >= n) return;
+    uint32_t c = fin[k];
+    const int32_t contig = F.contig[c5[c]], end = F.pos[c5[c]], start = F.pos[c3[c]];
+    const int64_t glen = goff[contig + 1] - goff[contig];
+    const uint8_t *g = genome + goff[contig];
+    // round((end + start) / 2): Python 3 rounds x.5 to the even neighbour (pairflanks.py:294); sum >= -1
+    int64_t s2 = (int64_t)end + start, center;
+    if (s2 % 2 == 0) center = s2 / 2; else { int64_t lo = (s2 - 1) / 2; center = (lo % 2 == 0) ? lo : lo + 1; }
+    int64_t es = center - DR_WIN / 2, ee = center + DR_WIN / 2, add_start_n = 0;
+    if (es < 0) { add_start_n = -es; es = 0; }
+    if (ee > glen) ee = glen;
+    int W = (int)(ee - es); if (W < 0) W = 0;
+    for (int i = threadIdx.x; i < DR_WIN * 17; i += blockDim.x) { (&sum[0][0])[i] = 0; (&firstr[0][0])[i] = 0xFFFFFFFFu; }
+    if (threadIdx.x < W) {
+        // initialize_target_region_reads pairflanks.py:347-353 with the mis-indexed left padding of 307 (quirk P10)
+        int64_t idx = threadIdx.x;
+        refch[threadIdx.x] = idx < add_start_n ? (uint8_t)'N' : ((es + idx - add_start_n) < glen ? g[es + idx - add_start_n] : (uint8_t)'N');
+    }
+    if (threadIdx.x == 0) {
+        err = 0;
+        if (W > 0) d_fetch_range(R, contig, (int32_t)es, (int32_t)ee, &range[0], &range[1]); else { range[0] = 0; range[1] = 0; }
+    }
+    __syncthreads();
+    // reads of bam.fetch(contig, expanded_start, expanded_end): no read filter here (pairflanks.py:311)
+    for (int64_t r = range[0] + threadIdx.x; r < range[1]; r += blockDim.x) {
+        if (!d_overlaps(R, r, (int32_t)es)) continue;
+        if (R.qlen[r] == 0) continue;
+        uint8_t f = R.flags[r];
+        int64_t pi = d_pool_index(R, r);
+        if (pi < 0) { err = 1; continue; }
+        uint64_t o0 = R.pool_off[pi];
+        DevBlocks bl = d_blocks(R, r, f);
+        int64_t qpos = d_lkind(f) == 1 ? R.first_op_len[r] : 0;
+        for (int bi = 0; bi < bl.n; bi++) {
+            qpos += bl.bi(bi);
+            int32_t bs = bl.bs(bi), be = bl.be(bi);
+            int32_t lo = bs > (int32_t)es ? bs : (int32_t)es, hi = be < (int32_t)ee ? be : (int32_t)ee;
+            for (int32_t rp = lo; rp < hi; rp++) {
+                uint64_t qi = o0 + (uint64_t)(qpos + (rp - bs));
+                uint32_t code = d_pool_base(R, qi);
+                atomicAdd(&sum[rp - es][code], (uint32_t)R.pool_quals[qi]);
+                atomicMin(&firstr[rp - es][code], (uint32_t)r);
+            }
+            qpos += be - bs;
+        }
+    }
+    __syncthreads();
+    int32_t *meta = dr_meta + 3 * (size_t)k;
+    char *out_ref = dr_out + (size_t)k * stride, *out_reads = out_ref + stride / 2;
+    // get_reference_direct_repeats pairflanks.py:356-367: genome[start+1:end] with Python slice clamping
+    int64_t a = (int64_t)start + 1, b = end;
+    if (a < 0) a = 0;
+    if (b > glen) b = glen;
+    if (b < a) b = a;
+    for (int64_t i = a + threadIdx.x; i < b; i += blockDim.x) out_ref[i - a] = (char)g[i];
+    // .index() raises outside the window (pairflanks.py:323)
+    bool bad = (start + 1 < es || start + 1 >= ee || end < es || end >= ee);
+    if (threadIdx.x == 0) { meta[0] = (int32_t)(b - a); meta[1] = bad ? 0 : end - start - 1; meta[2] = bad ? 2 : err; }
+    if (bad) return;
+    // get_consensus_target_region pairflanks.py:332-344: keys in insertion order (reference base first, then read bases
+    // by first contributing read), strict '>' from 0
+    for (int64_t p = (int64_t)start + 1 + threadIdx.x; p < end; p += blockDim.x) {
+        int col = (int)(p - es);
+        uint8_t rc = refch[col];
+        int refcode = -1;
+        for (int q = 0; q < 16; q++) if ((uint8_t)codes[q] == rc) refcode = q;
+        // reference key first: weight 1 (+ read qualities when a read shows the same character); always > 0
+        uint64_t best_q = 1 + (refcode >= 0 ? sum[col][refcode] : 0);
+        char best_n = (char)rc;
+        uint32_t best_first = 0;
+        bool best_is_ref = true;
+        for (int q = 0; q < 16; q++) {
+            if (q == refcode) continue;
+            uint32_t fr = firstr[col][q];
+            if (fr == 0xFFFFFFFFu) continue;
+            uint64_t v = sum[col][q];
+            // a later key replaces the best only with a strictly larger sum; among equal sums the earlier key stays
+            if (v > best_q || (v == best_q && !best_is_ref && fr < best_first)) { best_q = v; best_n = codes[q]; best_first = fr; best_is_ref = false; }
+        }
+        out_reads[p - (start + 1)] = best_n;
+    }
+}
+
+// =====================================================================================================================
+extern "C" int mfk_ir_detect(mfk_ctx *ctx, const char *seqs, const int64_t *off, int64_t n, int32_t *out) {
+    if (!ctx || n < 0) return 1;
+    HIPCHK(hipSetDevice(ctx->device));
+    ctx->err[0] = 0;
+    if (n == 0) return 0;
+    arena_reset(ctx);
+    hipStream_t st = ctx->stream;
+    int64_t total = off[n];
+    char *d_seqs = aalloc<char>(ctx, (size_t)total + 1); int64_t *d_off = aalloc<int64_t>(ctx, (size_t)n + 1); int32_t *d_out = aalloc<int32_t>(ctx, 6 * (size_t)n);
+    if (!d_seqs || !d_off || !d_out) return 1;
+    HIPCHK(hipMemcpyAsync(d_seqs, seqs, (size_t)total, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(d_off, off, ((size_t)n + 1) * 8, hipMemcpyHostToDevice, st));
+    HIPCHK(hipEventRecord(ctx->ev0, st));
+    hipLaunchKernelGGL(k_ir_seqs, dim3((unsigned)n), dim3(64), 0, st, (const char *)d_seqs, (const int64_t *)d_off, (uint32_t)n, d_out);
+    KCHK();
+    HIPCHK(hipEventRecord(ctx->ev1, st));
+    HIPCHK(hipMemcpyAsync(out, d_out, 6 * (size_t)n * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1) == hipSuccess) ctx->last_ms = ms;
+    return 0;
+}
+
+extern "C" int mfk_pairflanks(mfk_ctx *ctx, const mfk_reads *reads, const mfk_params *params, const mfk_flank *flanks, const char *flank_seqs, int64_t n_flanks,
+                              const int32_t *h_contig_rank, const uint8_t *genome, const int64_t *h_genome_off, int64_t *n_pairs_out, int64_t *str_bytes_out) {
+    if (!ctx || !reads || !params || n_flanks < 0) return 1;
+    HIPCHK(hipSetDevice(ctx->device));
+    ctx->err[0] = 0;
+    ctx->pairs.clear(); ctx->strs.clear();
+    memset(ctx->pstats, 0, sizeof ctx->pstats);
+    if (n_pairs_out) *n_pairs_out = 0;
+    if (str_bytes_out) *str_bytes_out = 0;
+    if (n_flanks == 0) return 0;
+    if (params->max_direct_repeat_length > 65000 || params->max_direct_repeat_length < 0) { snprintf(ctx->err, sizeof ctx->err, "max_direct_repeat_length out of range"); return 1; }
+    arena_reset(ctx);
+    DevReads R; DevParams P;
+    if (int rc = upload_reads(ctx, reads, params, &R, &P)) return rc;
+    hipStream_t st = ctx->stream;
+    const uint32_t nF = (uint32_t)n_flanks;
+    const int nc = reads->n_contigs;
+    // ---- flank table to the device ---------------------------------------------------------------------------------
+    std::vector<int32_t> h(6 * (size_t)nF); std::vector<int64_t> hoff(nF);
+    int sorted = 1; int64_t seq_total = 0;
+    for (uint32_t i = 0; i < nF; i++) {
+        const mfk_flank &f = flanks[i];
+        if (f.contig_id < 0 || f.contig_id >= nc) { snprintf(ctx->err, sizeof ctx->err, "flank %u: contig id %d out of range", i, f.contig_id); return 1; }
+        h[i] = f.contig_id; h[nF + i] = f.pos; h[2 * (size_t)nF + i] = f.orient; h[3 * (size_t)nF + i] = f.consensus_softclip_count;
+        h[4 * (size_t)nF + i] = f.total_count; h[5 * (size_t)nF + i] = f.seq_len; hoff[i] = f.seq_off;
+        if (f.seq_off + f.seq_len > seq_total) seq_total = f.seq_off + f.seq_len;
+        if (i && (flanks[i - 1].contig_id > f.contig_id || (flanks[i - 1].contig_id == f.contig_id && flanks[i - 1].pos > f.pos))) sorted = 0;
+    }
+    int32_t *d_tab = aalloc<int32_t>(ctx, 6 * (size_t)nF); int64_t *d_soff = aalloc<int64_t>(ctx, nF); char *d_seqs = aalloc<char>(ctx, (size_t)seq_total + 1);
+    int32_t *d_rank = aalloc<int32_t>(ctx, nc); int64_t *d_goff = aalloc<int64_t>(ctx, (size_t)nc + 1);
+    uint32_t *d_pstats = aalloc<uint32_t>(ctx, MFK_N_STATS);
+    if (!d_tab || !d_soff || !d_seqs || !d_rank || !d_goff || !d_pstats) return 1;
+    HIPCHK(hipMemcpyAsync(d_tab, h.data(), h.size() * 4, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(d_soff, hoff.data(), hoff.size() * 8, hipMemcpyHostToDevice, st));
+    if (seq_total) HIPCHK(hipMemcpyAsync(d_seqs, flank_seqs, (size_t)seq_total, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(d_rank, h_contig_rank, (size_t)nc * 4, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(d_goff, h_genome_off, ((size_t)nc + 1) * 8, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemsetAsync(d_pstats, 0, MFK_N_STATS * 4, st));
+    HIPCHK(hipStreamSynchronize(st));   // host vectors go out of use
+    HIPCHK(hipEventRecord(ctx->ev0, st));
+    FlankDev F; F.n = nF; F.contig = d_tab; F.pos = d_tab + nF; F.orient = d_tab + 2 * (size_t)nF; F.ccount = d_tab + 3 * (size_t)nF;
+    F.total = d_tab + 4 * (size_t)nF; F.seq_len = d_tab + 5 * (size_t)nF; F.seq_off = d_soff; F.seqs = d_seqs;
+    // ---- candidate pairs ----------------------------------------------------------------------------------------------
+    const unsigned fb = nblocks(nF, 256);
+    uint32_t *cnt = aalloc<uint32_t>(ctx, nF), *coff = aalloc<uint32_t>(ctx, (size_t)nF + 1);
+    if (!cnt || !coff) return 1;
+    hipLaunchKernelGGL(k_pair_window<false>, dim3(fb), dim3(256), 0, st, F, P.maxdr, sorted, cnt, (const uint32_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr);
+    KCHK();
+    if (int rc = dev_excl_scan32(ctx, cnt, coff, nF)) return rc;
+    uint32_t nP = 0;
+    if (int rc = read_back_p(ctx, coff + nF, &nP, 4)) return rc;
+    ctx->pstats[0] = nP;
+    uint32_t nK = 0, nFin = 0;
+    std::vector<uint32_t> h_fin, h_span, h_c5, h_c3; std::vector<int32_t> h_ir, h_meta; std::vector<char> h_dr; uint32_t stride = 0;
+    if (nP > 0) {
+        uint32_t *c5 = aalloc<uint32_t>(ctx, nP), *c3 = aalloc<uint32_t>(ctx, nP);
+        int32_t *ir = aalloc<int32_t>(ctx, 6 * (size_t)nP);
+        uint64_t *keys = aalloc<uint64_t>(ctx, nP), *keys2 = aalloc<uint64_t>(ctx, nP);
+        uint32_t *vals = aalloc<uint32_t>(ctx, nP), *order = aalloc<uint32_t>(ctx, nP);
+        uint32_t *best5 = aalloc<uint32_t>(ctx, nF), *best3 = aalloc<uint32_t>(ctx, nF);
+        uint8_t *used5 = aalloc<uint8_t>(ctx, nF), *used3 = aalloc<uint8_t>(ctx, nF), *state = aalloc<uint8_t>(ctx, nP);
+        uint32_t *kflag = aalloc<uint32_t>(ctx, nP), *kscan = aalloc<uint32_t>(ctx, (size_t)nP + 1);
+        if (!c5 || !c3 || !ir || !keys || !keys2 || !vals || !order || !best5 || !best3 || !used5 || !used3 || !state || !kflag || !kscan) return 1;
+        const unsigned pb = nblocks(nP, 256);
+        hipLaunchKernelGGL(k_pair_window<true>, dim3(fb), dim3(256), 0, st, F, P.maxdr, sorted, (uint32_t *)nullptr, (const uint32_t *)coff, c5, c3);
+        KCHK();
+        hipLaunchKernelGGL(k_inverted_repeat, dim3(nP), dim3(64), 0, st, F, (const uint32_t *)c5, (const uint32_t *)c3, nP, ir);
+        KCHK();
+        hipLaunchKernelGGL(k_assign_keys, dim3(pb), dim3(256), 0, st, F, (const uint32_t *)c5, (const uint32_t *)c3, (const int32_t *)ir, nP, keys, vals);
+        KCHK();
+        if (int rc = dev_sort_pairs64(ctx, keys, keys2, vals, order, nP, 0, 56)) return rc;
+        hipLaunchKernelGGL(k_assign, dim3(1), dim3(1024), 0, st, (const uint32_t *)order, (const uint32_t *)c5, (const uint32_t *)c3, nP, nF, best5, best3, used5, used3, state);
+        KCHK();
+        hipLaunchKernelGGL(k_kept_flags, dim3(pb), dim3(256), 0, st, (const uint8_t *)state, nP, kflag);
+        KCHK();
+        if (int rc = dev_excl_scan32(ctx, kflag, kscan, nP)) return rc;
+        if (int rc = read_back_p(ctx, kscan + nP, &nK, 4)) return rc;
+        ctx->pstats[1] = nK;
+        if (nK > 0) {
+            uint64_t *kk = aalloc<uint64_t>(ctx, nK), *kk2 = aalloc<uint64_t>(ctx, nK);
+            uint32_t *kv = aalloc<uint32_t>(ctx, nK), *kept = aalloc<uint32_t>(ctx, nK), *spanning = aalloc<uint32_t>(ctx, nK);
+            uint32_t *jflag = aalloc<uint32_t>(ctx, nK), *jscan = aalloc<uint32_t>(ctx, (size_t)nK + 1);
+            if (!kk || !kk2 || !kv || !kept || !spanning || !jflag || !jscan) return 1;
+            const unsigned kb = nblocks(nK, 256);
+            hipLaunchKernelGGL(k_kept_keys, dim3(pb), dim3(256), 0, st, F, (const uint32_t *)order, (const uint32_t *)c5, (const uint32_t *)c3, (const uint8_t *)state, (const uint32_t *)kscan, nP, (const int32_t *)d_rank, kk, kv);
+            KCHK();
+            if (int rc = dev_sort_pairs64(ctx, kk, kk2, kv, kept, nK, 0, 64)) return rc;
+            hipLaunchKernelGGL(k_spanning, dim3(nK), dim3(256), 0, st, R, P, F, (const uint32_t *)kept, (const uint32_t *)c5, (const uint32_t *)c3, nK, spanning);
+            KCHK();
+            hipLaunchKernelGGL(k_junction_filter, dim3(kb), dim3(256), 0, st, F, (const uint32_t *)kept, (const uint32_t *)c5, (const uint32_t *)c3, (const uint32_t *)spanning, (const int32_t *)ir, nK, P.maxjsp, jflag, d_pstats);
+            KCHK();
+            if (int rc = dev_excl_scan32(ctx, jflag, jscan, nK)) return rc;
+            if (int rc = read_back_p(ctx, jscan + nK, &nFin, 4)) return rc;
+            if (nFin > 0) {
+                uint32_t *fin = aalloc<uint32_t>(ctx, nFin), *fin_span = aalloc<uint32_t>(ctx, nFin);
+                stride = 2 * (((uint32_t)P.maxdr + 1 + 15) & ~15u);
+                char *dr = aalloc<char>(ctx, (size_t)nFin * stride); int32_t *meta = aalloc<int32_t>(ctx, 3 * (size_t)nFin);
+                if (!fin || !fin_span || !dr || !meta) return 1;
+                HIPCHK(hipMemsetAsync(dr, 0, (size_t)nFin * stride, st));
+                hipLaunchKernelGGL(k_final_list, dim3(kb), dim3(256), 0, st, (const uint32_t *)kept, (const uint32_t *)jflag, (const uint32_t *)jscan, (const uint32_t *)spanning, nK, fin, fin_span);
+                KCHK();
+                hipLaunchKernelGGL(k_direct_repeats, dim3(nFin), dim3(256), 0, st, R, F, (const uint32_t *)fin, (const uint32_t *)c5, (const uint32_t *)c3, nFin, genome, (const int64_t *)d_goff, dr, stride, meta);
+                KCHK();
+                HIPCHK(hipEventRecord(ctx->ev1, st));
+                h_fin.resize(nFin); h_span.resize(nFin); h_meta.resize(3 * (size_t)nFin); h_dr.resize((size_t)nFin * stride);
+                if (int rc = read_back_p(ctx, fin, h_fin.data(), nFin * 4)) return rc;
+                if (int rc = read_back_p(ctx, fin_span, h_span.data(), nFin * 4)) return rc;
+                if (int rc = read_back_p(ctx, meta, h_meta.data(), 3 * (size_t)nFin * 4)) return rc;
+                if (int rc = read_back_p(ctx, dr, h_dr.data(), (size_t)nFin * stride)) return rc;
+            }
+        }
+        if (nFin > 0) {
+            h_c5.resize(nP); h_c3.resize(nP); h_ir.resize(6 * (size_t)nP);
+            if (int rc = read_back_p(ctx, c5, h_c5.data(), nP * 4)) return rc;
+            if (int rc = read_back_p(ctx, c3, h_c3.data(), nP * 4)) return rc;
+            if (int rc = read_back_p(ctx, ir, h_ir.data(), 6 * (size_t)nP * 4)) return rc;
+        }
+    }
+    if (nFin == 0) HIPCHK(hipEventRecord(ctx->ev1, st));
+    uint32_t h_ps[MFK_N_STATS];
+    if (int rc = read_back_p(ctx, d_pstats, h_ps, sizeof h_ps)) return rc;
+    ctx->pstats[2] = h_ps[2]; ctx->pstats[3] = h_ps[3]; ctx->pstats[4] = nFin;
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1) == hipSuccess) ctx->last_ms = ms;
+    // ---- rows ------------------------------------------------------------------------------------------------------------
+    for (uint32_t k = 0; k < nFin; k++) {
+        uint32_t c = h_fin[k], a = h_c5[c], b = h_c3[c];
+        const mfk_flank &f5 = flanks[a], &f3 = flanks[b];
+        const int32_t *m = &h_meta[3 * (size_t)k];
+        if (m[2] == 2) { snprintf(ctx->err, sizeof ctx->err, "ValueError: direct-repeat bounds %d..%d fall outside the target window (pairflanks.py:323)", f3.pos + 1, f5.pos); return 5; }
+        if (m[2] == 1) { snprintf(ctx->err, sizeof ctx->err, "a read over a direct-repeat window has no sequence in the pool"); return 4; }
+        mfk_pair o; memset(&o, 0, sizeof o);
+        o.contig_id = f5.contig_id; o.pos_5p = f5.pos; o.pos_3p = f3.pos; o.index_5p = (int32_t)a; o.index_3p = (int32_t)b;
+        o.softclip_count_5p = f5.consensus_softclip_count; o.softclip_count_3p = f3.consensus_softclip_count;
+        o.total_count_5p = f5.total_count; o.total_count_3p = f3.total_count; o.spanning_count = (int32_t)h_span[k];
+        const int32_t *r = &h_ir[6 * (size_t)c];
+        o.has_ir = r[0]; o.ir5_len = o.ir3_len = -1; o.ir_length = 0;
+        if (r[1]) {
+            int n5 = f5.seq_len > 40 ? 40 : f5.seq_len, n3 = f3.seq_len > 40 ? 40 : f3.seq_len;
+            std::string comb(flank_seqs + f5.seq_off, (size_t)n5);
+            comb.append(20, 'N');
+            comb.append(flank_seqs + f3.seq_off + (f3.seq_len - n3), (size_t)n3);
+            o.ir3_len = r[2] - r[1] + 1; o.ir3_off = (int64_t)ctx->strs.size(); ctx->strs.append(comb, (size_t)r[1] - 1, (size_t)o.ir3_len);   // IR_3p = ir1.seq
+            o.ir5_len = r[4] - r[3] + 1; o.ir5_off = (int64_t)ctx->strs.size(); ctx->strs.append(comb, (size_t)r[3] - 1, (size_t)o.ir5_len);   // IR_5p = ir2.seq
+            o.ir_length = o.ir5_len;
+        }
+        o.dr_ref_len = m[0]; o.dr_len = m[1];
+        o.dr_ref_off = (int64_t)ctx->strs.size(); ctx->strs.append(h_dr.data() + (size_t)k * stride, (size_t)m[0]);
+        o.dr_reads_off = (int64_t)ctx->strs.size(); ctx->strs.append(h_dr.data() + (size_t)k * stride + stride / 2, (size_t)m[1]);
+        ctx->pairs.push_back(o);
+    }
+    if (n_pairs_out) *n_pairs_out = (int64_t)ctx->pairs.size();
+    if (str_bytes_out) *str_bytes_out = (int64_t)ctx->strs.size();
+    return 0;
+}
+
+extern "C" int mfk_pairflanks_fetch(mfk_ctx *ctx, mfk_pair *pairs, char *strs, int64_t *stats) {
+    if (!ctx) return 1;
+    if (pairs && !ctx->pairs.empty()) memcpy(pairs, ctx->pairs.data(), ctx->pairs.size() * sizeof(mfk_pair));
+    if (strs && !ctx->strs.empty()) memcpy(strs, ctx->strs.data(), ctx->strs.size());
+    if (stats) memcpy(stats, ctx->pstats, sizeof ctx->pstats);
+    return 0;
+}

@@ -1,0 +1,105 @@
+"""GPU parity tests: the HIP library (through its C-ABI) against the CPU oracle and the golden vectors of the reference.
+Bit-exact: every count, position, flag and sequence must be identical."""
+import numpy as np
+import pytest
+
+from mustache_amd import lib
+from mustache_amd.pack import pack_reads
+from mustache_amd.simulate import simulate_readset
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+
+def _device_reads(hip, packed):
+    from mustache_amd.findflanks import device_reads
+    return device_reads(hip, packed, "cuda:0")
+
+
+@pytest.mark.parametrize("name", util.CASES)
+def test_golden_tsvs_bit_exact(hip, name):
+    """findflanks + pairflanks TSVs equal to what the reference printed (IR columns: build's definition)."""
+    import torch
+    case = util.load_json(name)
+    rs = util.case_readset(case)
+    packed = pack_reads(rs.contigs, rs, pool="all")
+    rsd = _device_reads(hip, packed)
+    ff, stats, pf = util.run_both_stages(hip, rsd, packed, case, genome_arr=lambda g: torch.from_numpy(g).to("cuda:0"))
+    assert ff == case["findflanks_tsv"]
+    assert stats[1:10] == case["findflanks_log_counts"]
+    assert pf == case["pairflanks_tsv"]
+
+
+@pytest.mark.parametrize("name", ["quirks", "sim_a", "sim_c"])
+@pytest.mark.parametrize("stage", range(1, 10))
+def test_site_table_after_every_stage(hip, oracle, name, stage):
+    """Site table (positions, ten counts, keep flags) after each call of _findflanks' sequence, vs the oracle."""
+    case = util.load_json(name)
+    rs = util.case_readset(case)
+    packed = pack_reads(rs.contigs, rs, pool="clipped")
+    params = lib.make_params(**case["findflanks_params"])
+    got = hip.run_findflanks(_device_reads(hip, packed), params, stop_after=stage)
+    want = oracle.run_findflanks(oracle.reads(packed), params, stop_after=stage)
+    util.assert_same_sites(got["sites"], want["sites"])
+    assert list(got["stats"][:12]) == list(want["stats"][:12])
+
+
+@pytest.mark.parametrize("seed", range(20, 32))
+def test_random_simulations_match_oracle(hip, oracle, seed):
+    import torch
+    rng = np.random.default_rng(seed)
+    kw = dict(seed=seed, contig_lens=(int(rng.integers(3000, 9000)),) * int(rng.integers(1, 4)),
+              n_insertions=int(rng.integers(1, 4)), coverage=int(rng.integers(10, 120)),
+              read_len=int(rng.choice([75, 100, 150])), sub_rate=float(rng.choice([0.002, 0.01, 0.03])),
+              wildtype_frac=float(rng.choice([0, 0.1, 0.4])))
+    fp = dict(min_softclip_length=int(rng.choice([4, 8])), min_softclip_count=int(rng.choice([2, 4])),
+              min_softclip_ratio=float(rng.choice([0.1, 0.15])), min_count_consensus=int(rng.choice([1, 2, 3])),
+              max_indel_ratio=float(rng.choice([0.03, 0.2])))
+    genome, rs, _ = simulate_readset(**kw)
+    packed = pack_reads(rs.contigs, rs, pool="all")
+    case = {"findflanks_params": fp, "pairflanks_params": {}, "genome": genome}
+    o_res = oracle.run_findflanks(oracle.reads(packed), lib.make_params(**fp))
+    # pairflanks consumes the findflanks TSV: feed both backends the oracle's table
+    from mustache_amd.findflanks import flank_frame
+    df = flank_frame(o_res, packed.contig_names)
+    df.insert(0, "flank_id", list(df.index + 1))
+    df.insert(0, "sample", "sample1")
+    case["findflanks_tsv"] = df.to_csv(sep="\t", index=False)
+    want = util.run_both_stages(oracle, oracle.reads(packed), packed, case)
+    got = util.run_both_stages(hip, _device_reads(hip, packed), packed, case,
+                               genome_arr=lambda g: torch.from_numpy(g).to("cuda:0"))
+    assert got[0] == want[0]
+    assert got[1][:12] == want[1][:12]
+    assert got[2] == want[2]
+
+
+def test_ir_detect_matches_oracle(hip, oracle):
+    rng = np.random.default_rng(7)
+    seqs = []
+    for k in range(300):
+        n5, n3 = int(rng.integers(8, 41)), int(rng.integers(8, 41))
+        a = "".join("ACGT"[i] for i in rng.integers(0, 4, n5))
+        if k % 3:
+            comp = {"A": "T", "C": "G", "G": "C", "T": "A"}
+            arm = "".join(comp[c] for c in reversed(a[:int(rng.integers(6, n5 + 1))]))
+            b = "".join("ACGT"[i] for i in rng.integers(0, 4, max(0, n3 - len(arm)))) + arm
+            b = list(b)
+            for _ in range(int(rng.integers(0, 3))):
+                b[int(rng.integers(0, len(b)))] = "ACGTN"[int(rng.integers(0, 5))]
+            b = "".join(b)[-40:]
+        else:
+            b = "".join("ACGT"[i] for i in rng.integers(0, 4, n3))
+        seqs.append(a + "N" * 20 + b)
+    got = hip.run_ir_detect(seqs)
+    want = oracle.run_ir_detect(seqs)
+    assert np.array_equal(got, want)
+    assert want[:, 0].sum() > 50
+
+
+def test_empty_and_tiny_inputs(hip, oracle):
+    from mustache_amd.records import AlignedRead, ReadSet
+    reads = [AlignedRead("a", "c1", 10, 60, [(0, 50)], "A" * 50, [30] * 50, md="50")]
+    rs = ReadSet([("c1", 1000)], reads)
+    packed = pack_reads(rs.contigs, rs, pool="all")
+    res = hip.run_findflanks(_device_reads(hip, packed), lib.make_params())
+    assert len(res["flanks"]) == 0 and len(res["sites"]) == 0
