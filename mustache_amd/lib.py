@@ -210,5 +210,11 @@ _loaded = {}
 def load(device_id=0):
     """The HIP library on ``device_id``.  Raises MfkError when the extension is not built or no GPU is usable."""
     if device_id not in _loaded:
+        # torch owns the device buffers and must bring up ITS HIP runtime first: libmfk.so then binds to the same
+        # libamdhip64 instead of loading a second runtime (which leaves torch with "No HIP GPUs are available")
+        import torch
+        if not torch.cuda.is_available():
+            raise MfkError("no HIP device visible to torch: the flank kernels need an MI355X (there is no CPU path)")
+        torch.cuda.init()
         _loaded[device_id] = Binding(LIB_PATH, "mfk_", device_id)
     return _loaded[device_id]
