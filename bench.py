@@ -1,0 +1,189 @@
+#!/usr/bin/env python3
+"""bench.py -- aligned reads/sec of the flank-discovery hot path (findflanks + pairflanks) on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config NAME]
+
+A step is one pass of the hot path over one resident batch: ``mfk_findflanks`` (read scan -> sites -> filters -> site x read
+join -> consensus) followed by ``mfk_pairflanks`` (window join, inverted repeats, assignment, spanning reads, direct
+repeats) on the packed alignments that already sit in HBM.  The workload is synthetic simulated-insertion alignments
+(mustache_amd/synth.py); the default is BASELINE.json configs[1], "S. aureus single isolate at 1000x" (2.8 Mb, 2x150 bp,
+18.7 M reads, 20 insertions).  With N > 1 every rank holds its own isolate of that size (sample sharding, weak scaling)
+and the per-rank flank tables are merged by one all-gather (RCCL) inside the step.
+
+Prints ONE JSON line (rank 0): whole-job reads/s, the roofline of the dominant kernel (HIP-event timing inside the library,
+on the library's stream) and, at N = 1, the CPU port (oracle/mfk_oracle.c) timed on a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s is what a float4 copy reaches
+
+
+def algorithmic_bytes(kernel, meta):
+    """Bytes one launch of `kernel` has to move for this workload (DESIGN.md "Kernels"); None = not a streaming kernel."""
+    n, clipped, ev = meta["n_reads"], meta["clipped_reads"], meta["events"]
+    if kernel.startswith("k_scan_clips"):
+        # flags of every read (1 B) + the rest of the 22-byte record of lenient-clipped reads; the write pass adds 8 B/event
+        return n * 1 + clipped * 21 + (ev * 8 if "true" in kernel else 0)
+    if kernel == "k_classify":
+        return meta["join_visits"] * 13  # ref_start, ref_end (8 B) + mapq, flags, link (5 B)... per (site, read) visit
+    if kernel.startswith("rocprim::radix_sort_keys"):
+        return ev * 8 * 2 * 8  # 8 digit passes, read + write
+    return None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default="C2_saureus_1000x")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-insertions", type=int, default=20)
+    ap.add_argument("--dump-profile", default=None, help="write the per-kernel table to this file")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    torch.cuda.set_device(local_rank)
+    device = "cuda:%d" % local_rank
+
+    from mustache_amd import lib, pairflanks as pfh
+    from mustache_amd.dist import allgather_flanks
+    from mustache_amd.findflanks import device_reads
+    from mustache_amd.synth import CONFIGS, synth_packed
+
+    t0 = time.time()
+    packed, genome, truth = synth_packed(**CONFIGS[args.config], seed=100 + rank)
+    gen_s = time.time() - t0
+    hip = lib.load(local_rank)
+    params = lib.make_params()
+    reads = device_reads(hip, packed, device)
+    g, goff = pfh.genome_arrays(genome, packed.contig_names)
+    g_dev = torch.from_numpy(g).to(device)
+    ranks = pfh.contig_ranks(packed.contig_names)
+
+    def step():
+        ff = hip.run_findflanks(reads, params)
+        pf = hip.run_pairflanks(reads, params, ff["flanks"], ff["seqs"], ranks, g_dev, goff)
+        if world > 1:
+            allgather_flanks(ff["flanks"], ff["seqs"], device)
+        return ff, pf
+
+    for _ in range(args.warmup):
+        ff, pf = step()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    hip.profile(True)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        ff, pf = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    prof = hip.profile_totals()
+    hip.profile(False)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        nr = torch.tensor([packed.n_reads], dtype=torch.int64, device=device)
+        dist.all_reduce(nr)
+        total_reads = int(nr.item())
+    else:
+        total_reads = packed.n_reads
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        value = total_reads * args.steps / elapsed
+        flags = packed.flags
+        meta = {"n_reads": packed.n_reads, "clipped_reads": int(((flags & 15) != 0).sum()),
+                "events": int(ff["stats"][10]),
+                "join_visits": int(ff["stats"][3]) * 3 * int(CONFIGS[args.config]["coverage"])}
+        table = sorted(((nm, ms / max(calls, 1), calls, ms) for nm, (ms, calls) in prof.items()), key=lambda r: -r[3])
+        dev_ms = sum(r[3] for r in table) / args.steps
+        roofline = None
+        if table:
+            # dominant kernel = largest share of device time among the kernels of the path
+            nm, avg_ms, calls, tot = table[0]
+            ab = algorithmic_bytes(nm, meta)
+            stream = next((r for r in table if r[0].startswith("k_scan_clips")), None)
+            roofline = {"kernel": nm, "bound": "hbm", "avg_ms": round(avg_ms, 5), "share_of_device_time": round(tot / max(sum(r[3] for r in table), 1e-12), 3)}
+            if ab is not None:
+                ach = ab / (avg_ms * 1e-3) / 1e9
+                roofline.update({"achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5),
+                                 "algorithmic_bytes": ab, "traffic": None})
+            else:
+                roofline.update({"achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
+                                 "note": "integer-ALU/latency-bound pairwise kernel, not a streaming kernel: see DESIGN.md"})
+            if stream is not None:
+                sab = algorithmic_bytes(stream[0], meta)
+                roofline["read_scan"] = {"kernel": stream[0], "avg_ms": round(stream[1], 5), "algorithmic_bytes": sab,
+                                         "achieved": round(sab / (stream[1] * 1e-3) / 1e9, 2), "unit": "GB/s",
+                                         "frac": round(sab / (stream[1] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}
+        if args.dump_profile:
+            with open(args.dump_profile, "w") as fh:
+                fh.write("# per-kernel HIP-event timing over %d timed steps (config %s)\n" % (args.steps, args.config))
+                fh.write("%-40s %10s %8s %12s\n" % ("kernel", "avg_ms", "calls", "total_ms"))
+                for nm, avg_ms, calls, tot in table:
+                    fh.write("%-40s %10.5f %8d %12.4f\n" % (nm, avg_ms, calls, tot))
+                fh.write("device ms per step (sum of kernels) %.4f, wall ms per step %.4f\n" % (dev_ms, ms_per_step))
+        cpu = None
+        if world == 1 and not args.no_cpu_baseline:
+            cpu = cpu_baseline(packed, genome, truth, params, args.cpu_sample_insertions)
+        out = {"metric": "aligned reads/sec (findflanks+pairflanks, whole node)", "value": round(value, 1), "unit": "reads/s",
+               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8/int32 (+f64 ratio tests)",
+               "data": "synthetic",
+               "config": {"workload": args.config, "reads_per_gpu": packed.n_reads, "genome_bp": int(sum(CONFIGS[args.config]["contig_lens"])),
+                          "coverage": CONFIGS[args.config]["coverage"], "read_length": 150, "insertions": len(truth),
+                          "flank_rows": int(len(ff["flanks"])), "pairs": int(len(pf["pairs"])), "sharding": "sample per GPU",
+                          "device_ms_per_step": round(dev_ms, 4), "generate_s": round(gen_s, 1)},
+               "roofline": roofline, "cpu_baseline": cpu}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(packed, genome, truth, params, n_insertions):
+    """The CPU port (oracle) on a bounded sample: the reads of the first `n_insertions` insertion sites' stretch of the
+    genome.  1 core, like the reference (single-threaded Python)."""
+    import numpy as np
+    from mustache_amd import pairflanks as pfh
+    from oracle.oracle import Oracle
+    ora = Oracle()
+    pos = sorted(t[1] for t in truth if t[0] == packed.contig_names[0])
+    cut = pos[min(n_insertions, len(pos)) - 1] + 2000 if pos else int(packed.contig_len[0])
+    hi = int(np.searchsorted(packed.ref_start[:int(packed.contig_read_start[1])], cut))
+    sub = packed.slice_reads(0, hi)
+    R = ora.reads(sub)
+    g, goff = pfh.genome_arrays(genome, packed.contig_names)
+    t0 = time.perf_counter()
+    ff = ora.run_findflanks(R, params)
+    ora.run_pairflanks(R, params, ff["flanks"], ff["seqs"], pfh.contig_ranks(packed.contig_names), g, goff)
+    dt = time.perf_counter() - t0
+    return {"value": round(sub.n_reads / dt, 1), "unit": "reads/s", "cores": 1, "kind": "port",
+            "sample": "first %d reads (%d insertion sites, %.1f%% of the workload), findflanks+pairflanks in %.2f s"
+                      % (sub.n_reads, min(n_insertions, len(pos)), 100.0 * sub.n_reads / packed.n_reads, dt)}
+
+
+if __name__ == "__main__":
+    main()

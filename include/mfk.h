@@ -176,6 +176,12 @@ int mfk_ir_detect(mfk_ctx *ctx, const char *seqs, const int64_t *off, int64_t n,
 /* time spent in device work of the last compute call, milliseconds (HIP events on the ctx stream) */
 double mfk_last_device_ms(mfk_ctx *ctx);
 
+/* per-kernel timing for bench.py: when enabled, every kernel launch of the compute calls is bracketed by HIP events on
+ * the ctx stream and the durations are accumulated per kernel name.  enable(…, on) also clears the totals.
+ * fetch: names = '\n'-separated kernel names in the order of ms[] / calls[]. */
+int mfk_profile_enable(mfk_ctx *ctx, int on);
+int mfk_profile_fetch(mfk_ctx *ctx, char *names, int64_t names_cap, double *ms, int64_t *calls, int64_t cap, int64_t *n);
+
 #ifdef __cplusplus
 }
 #endif

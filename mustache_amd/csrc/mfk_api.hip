@@ -15,6 +15,8 @@ mfk_ctx *mfk_create(int device_id) {
     ctx->pinned = nullptr;
     ctx->pinned_cap = 0;
     ctx->err[0] = 0;
+    ctx->prof_on = false;
+    ctx->prof_used = 0;
     memset(ctx->stats, 0, sizeof ctx->stats);
     memset(ctx->pstats, 0, sizeof ctx->pstats);
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return nullptr; }
@@ -28,6 +30,7 @@ void mfk_destroy(mfk_ctx *ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     for (auto &c : ctx->chunks) (void)hipFree(c.p);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+    for (auto e : ctx->prof_events) (void)hipEventDestroy(e);
     (void)hipEventDestroy(ctx->ev0);
     (void)hipEventDestroy(ctx->ev1);
     (void)hipStreamDestroy(ctx->stream);
@@ -38,10 +41,66 @@ const char *mfk_last_error(mfk_ctx *ctx) { return ctx ? ctx->err : "null ctx"; }
 int mfk_version(void) { return 1; }
 double mfk_last_device_ms(mfk_ctx *ctx) { return ctx ? ctx->last_ms : 0.0; }
 
+int mfk_profile_enable(mfk_ctx *ctx, int on) {
+    if (!ctx) return 1;
+    ctx->prof_on = on != 0;
+    ctx->prof_kernel.clear(); ctx->prof_ms.clear(); ctx->prof_calls.clear();
+    return 0;
+}
+
+int mfk_profile_fetch(mfk_ctx *ctx, char *names, int64_t names_cap, double *ms, int64_t *calls, int64_t cap, int64_t *n) {
+    if (!ctx || !n) return 1;
+    int64_t k = 0, o = 0;
+    for (size_t i = 0; i < ctx->prof_kernel.size() && k < cap; i++, k++) {
+        const std::string &nm = ctx->prof_kernel[i];
+        if (names && o + (int64_t)nm.size() + 1 < names_cap) { memcpy(names + o, nm.c_str(), nm.size()); o += (int64_t)nm.size(); names[o++] = '\n'; }
+        if (ms) ms[k] = ctx->prof_ms[i];
+        if (calls) calls[k] = ctx->prof_calls[i];
+    }
+    if (names && names_cap > 0) names[o < names_cap ? o : names_cap - 1] = 0;
+    *n = k;
+    return 0;
+}
+
 }  // extern "C"
+
+void prof_begin(mfk_ctx *ctx, const char *name) {
+    if (!ctx->prof_on) return;
+    if (ctx->prof_used + 2 > ctx->prof_events.size()) {
+        hipEvent_t a, b;
+        if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { ctx->prof_on = false; return; }
+        ctx->prof_events.push_back(a); ctx->prof_events.push_back(b);
+    }
+    ctx->prof_names.push_back(name);
+    (void)hipEventRecord(ctx->prof_events[ctx->prof_used], ctx->stream);
+}
+
+void prof_end(mfk_ctx *ctx) {
+    if (!ctx->prof_on || ctx->prof_names.size() * 2 != ctx->prof_used + 2) return;
+    (void)hipEventRecord(ctx->prof_events[ctx->prof_used + 1], ctx->stream);
+    ctx->prof_used += 2;
+}
+
+void prof_collect(mfk_ctx *ctx) {
+    if (ctx->prof_on) {
+        (void)hipStreamSynchronize(ctx->stream);
+        for (size_t i = 0; i * 2 + 1 < ctx->prof_used && i < ctx->prof_names.size(); i++) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, ctx->prof_events[2 * i], ctx->prof_events[2 * i + 1]) != hipSuccess) continue;
+            size_t k = 0;
+            for (; k < ctx->prof_kernel.size(); k++) if (ctx->prof_kernel[k] == ctx->prof_names[i]) break;
+            if (k == ctx->prof_kernel.size()) { ctx->prof_kernel.push_back(ctx->prof_names[i]); ctx->prof_ms.push_back(0.0); ctx->prof_calls.push_back(0); }
+            ctx->prof_ms[k] += ms; ctx->prof_calls[k] += 1;
+        }
+    }
+    ctx->prof_names.clear();
+    ctx->prof_used = 0;
+}
 
 // ---- arena ---------------------------------------------------------------------------------------------------
 void arena_reset(mfk_ctx *ctx) {
+    ctx->prof_names.clear();   // a call that failed half-way leaves its launches behind
+    ctx->prof_used = 0;
     if (ctx->chunks.size() > 1) {
         // the previous call had to grow: replace the pieces by one chunk of the total size
         (void)hipStreamSynchronize(ctx->stream);
@@ -141,7 +200,9 @@ int dev_sort_keys64(mfk_ctx *ctx, uint64_t *in, uint64_t *out, size_t n, int beg
     HIPCHK(rocprim::radix_sort_keys(nullptr, tb, in, out, n, (unsigned)begin_bit, (unsigned)end_bit, ctx->stream));
     void *tmp = arena_alloc(ctx, tb ? tb : 1);
     if (!tmp) return 1;
+    prof_begin(ctx, "rocprim::radix_sort_keys");
     HIPCHK(rocprim::radix_sort_keys(tmp, tb, in, out, n, (unsigned)begin_bit, (unsigned)end_bit, ctx->stream));
+    prof_end(ctx);
     return 0;
 }
 
@@ -151,7 +212,9 @@ int dev_sort_pairs64(mfk_ctx *ctx, uint64_t *kin, uint64_t *kout, uint32_t *vin,
     HIPCHK(rocprim::radix_sort_pairs(nullptr, tb, kin, kout, vin, vout, n, (unsigned)begin_bit, (unsigned)end_bit, ctx->stream));
     void *tmp = arena_alloc(ctx, tb ? tb : 1);
     if (!tmp) return 1;
+    prof_begin(ctx, "rocprim::radix_sort_pairs");
     HIPCHK(rocprim::radix_sort_pairs(tmp, tb, kin, kout, vin, vout, n, (unsigned)begin_bit, (unsigned)end_bit, ctx->stream));
+    prof_end(ctx);
     return 0;
 }
 
@@ -164,7 +227,9 @@ int dev_excl_scan32(mfk_ctx *ctx, const uint32_t *in, uint32_t *out, size_t n) {
     HIPCHK(rocprim::exclusive_scan(nullptr, tb, in, out, (uint32_t)0, n, rocprim::plus<uint32_t>(), ctx->stream));
     void *tmp = arena_alloc(ctx, tb ? tb : 1);
     if (!tmp) return 1;
+    prof_begin(ctx, "rocprim::exclusive_scan");
     HIPCHK(rocprim::exclusive_scan(tmp, tb, in, out, (uint32_t)0, n, rocprim::plus<uint32_t>(), ctx->stream));
+    prof_end(ctx);
     hipLaunchKernelGGL(k_write_total32, dim3(1), dim3(1), 0, ctx->stream, in, out, n);
     KCHK();
     return 0;
@@ -179,7 +244,9 @@ int dev_excl_scan64(mfk_ctx *ctx, const uint32_t *in, uint64_t *out, size_t n) {
     HIPCHK(rocprim::exclusive_scan(nullptr, tb, it, out, (uint64_t)0, n, rocprim::plus<uint64_t>(), ctx->stream));
     void *tmp = arena_alloc(ctx, tb ? tb : 1);
     if (!tmp) return 1;
+    prof_begin(ctx, "rocprim::exclusive_scan");
     HIPCHK(rocprim::exclusive_scan(tmp, tb, it, out, (uint64_t)0, n, rocprim::plus<uint64_t>(), ctx->stream));
+    prof_end(ctx);
     hipLaunchKernelGGL(k_write_total64, dim3(1), dim3(1), 0, ctx->stream, in, out, n);
     KCHK();
     return 0;

@@ -406,80 +406,100 @@ __global__ __launch_bounds__(256) void k_components(Words W, Jobs J) {
 }
 
 // ---- clusters -------------------------------------------------------------------------------------------------------
-// one wave per representative leaf slot (EMIT = false) or per job for its best cluster (EMIT = true)
-// dynamic LDS: reach[max_R] (u16) | hq[max_len*16] (u32) | hc[max_len*16] (u32)
-template <bool EMIT>
-__global__ __launch_bounds__(64) void k_cluster(DevParams P, Words W, Jobs J, uint32_t max_R, uint32_t max_len, ConsensusIO io) {
+// reach rows: one row of R counters per representative leaf, at reach[(adj_off[job] * 32) + ka * (rw * 32) + j]
+__device__ __forceinline__ uint32_t *d_reach_row(const Jobs &J, uint32_t *reach, uint32_t job, uint32_t ka) {
+    const uint32_t rw = (J.R[job] + 31) >> 5;
+    return reach + J.adj_off[job] * 32 + (size_t)ka * rw * 32;
+}
+
+// one block per leaf slot: representatives clear their row
+__global__ __launch_bounds__(256) void k_reach_init(Words W, Jobs J, uint32_t *reach) {
+    uint32_t slot = blockIdx.x;
+    if (slot >= W.n) return;
+    uint32_t job = W.job[slot], w0 = J.w0[job], R = J.R[job], ka = slot - w0;
+    if (ka >= J.nl[job] || W.label[slot] != ka) return;
+    uint32_t *row = d_reach_row(J, reach, job, ka);
+    for (uint32_t j = threadIdx.x; j < R; j += blockDim.x) row[j] = 0;
+}
+
+// one wave per leaf: reach_C(j) = max over the leaves l of cluster C of LCP(word j, l)
+__global__ __launch_bounds__(256) void k_reach(Words W, Jobs J, uint32_t *reach) {
+    uint32_t slot = blockIdx.x * 4 + (threadIdx.x >> 6);
+    int lane = threadIdx.x & 63;
+    if (slot >= W.n) return;
+    uint32_t job = W.job[slot], w0 = J.w0[job], R = J.R[job], kl = slot - w0;
+    if (kl >= J.nl[job]) return;
+    uint32_t *row = d_reach_row(J, reach, job, W.label[slot]);
+    uint32_t wl = w0 + W.leaf_word[slot];
+    const uint8_t *l = W.ch + W.off[wl];
+    const int ll = (int)W.len[wl];
+    for (uint32_t j = lane; j < R; j += 64) {
+        uint32_t v = w0 + j;
+        int c = d_lcp(l, ll, W.ch + W.off[v], (int)W.len[v]);
+        if (c > 0) atomicMax(&row[j], (uint32_t)c);
+    }
+}
+
+// one block per representative leaf slot: column vote (make_consensus_word flanktrie.py:306-342), merged count
+// (make_subtrie 89-118) and the cluster's place in the reference's list order.
+// dynamic LDS: hq[max_len*16] (u32) | hc[max_len*16] (u32)
+__global__ __launch_bounds__(256) void k_cluster_vote(DevParams P, Words W, Jobs J, const uint32_t *reach, uint32_t max_len, char *cl_chars, uint32_t cl_stride) {
     extern __shared__ __align__(16) unsigned char smem[];
     uint32_t *hq = reinterpret_cast<uint32_t *>(smem);
     uint32_t *hc = hq + (size_t)max_len * 16;
-    uint16_t *reach = reinterpret_cast<uint16_t *>(hc + (size_t)max_len * 16);
-    int lane = threadIdx.x;
-    uint32_t slot, job;
-    if (EMIT) {
-        job = blockIdx.x;
-        if (job >= J.n) return;
-        slot = J.best[job];
-        if (slot == 0xFFFFFFFFu) return;
-    } else {
-        slot = blockIdx.x;
-        if (slot >= W.n) return;
-        job = W.job[slot];
-    }
-    uint32_t w0 = J.w0[job], R = J.R[job], nl = J.nl[job];
-    uint32_t ka = slot - w0;
+    __shared__ int s_maxd, s_stop;
+    __shared__ uint32_t s_minrank, s_words;
+    const uint32_t slot = blockIdx.x;
+    if (slot >= W.n) return;
+    const uint32_t job = W.job[slot], w0 = J.w0[job], R = J.R[job], nl = J.nl[job], ka = slot - w0;
     if (ka >= nl || W.label[slot] != ka) return;   // not a representative
-    int maxd = 0;
-    uint32_t minrank = 0xFFFFFFFFu;
-    for (uint32_t j = lane; j < R; j += 64) reach[j] = 0;
-    for (uint32_t d = lane; d < max_len * 16; d += 64) { hq[d] = 0; hc[d] = 0; }
+    for (uint32_t d = threadIdx.x; d < max_len * 16; d += blockDim.x) { hq[d] = 0; hc[d] = 0; }
+    if (threadIdx.x == 0) { s_maxd = 0; s_minrank = 0xFFFFFFFFu; s_words = 0; }
     __syncthreads();
-    for (uint32_t kl = 0; kl < nl; kl++) {          // wave-uniform loop over the leaves of the job
+    // members: longest leaf and first leaf in DFS order
+    for (uint32_t kl = threadIdx.x; kl < nl; kl += blockDim.x) {
         if (W.label[w0 + kl] != ka) continue;
-        uint32_t wl = w0 + W.leaf_word[w0 + kl];
-        const uint8_t *l = W.ch + W.off[wl];
-        int ll = (int)W.len[wl];
-        if (ll > maxd) maxd = ll;
-        uint32_t rk = W.leaf_rank[w0 + kl];
-        if (rk < minrank) minrank = rk;
-        for (uint32_t j = lane; j < R; j += 64) {
-            uint32_t v = w0 + j;
-            int c = d_lcp(l, ll, W.ch + W.off[v], (int)W.len[v]);
-            if (c > (int)reach[j]) reach[j] = (uint16_t)c;
+        atomicMax(&s_maxd, (int)W.len[w0 + W.leaf_word[w0 + kl]]);
+        atomicMin(&s_minrank, W.leaf_rank[w0 + kl]);
+    }
+    const uint32_t *row = reach + J.adj_off[job] * 32 + (size_t)ka * ((R + 31) >> 5) * 32;
+    uint32_t words = 0;
+    for (uint32_t j = threadIdx.x; j < R; j += blockDim.x) {
+        const uint32_t v = w0 + j;
+        const int rc = (int)row[j], lj = (int)W.len[v];
+        if (rc == lj) words++;                       // the word is a prefix of a leaf of the cluster
+        if (rc == 0) continue;
+        const uint8_t *c = W.ch + W.off[v], *q = W.q + W.off[v];
+        int d = (int)((threadIdx.x * 7u) % (uint32_t)rc);   // staggered start: spreads the LDS atomics over the columns
+        for (int i = 0; i < rc; i++) {
+            uint32_t code = c[d] & 15;
+            atomicAdd(&hq[d * 16 + code], (uint32_t)q[d]);
+            atomicAdd(&hc[d * 16 + code], 1u);
+            if (++d == rc) d = 0;
         }
     }
+    if (words) atomicAdd(&s_words, words);
     __syncthreads();
-    uint32_t words = 0;
-    for (uint32_t j = lane; j < R; j += 64) {
-        uint32_t v = w0 + j;
-        int rc = reach[j], lj = (int)W.len[v];
-        if (rc == lj) words++;                       // the word is a prefix of a leaf of the cluster (make_subtrie)
-        const uint8_t *c = W.ch + W.off[v], *q = W.q + W.off[v];
-        for (int d = 0; d < rc; d++) { uint32_t code = c[d] & 15; atomicAdd(&hq[d * 16 + code], (uint32_t)q[d]); atomicAdd(&hc[d * 16 + code], 1u); }
-    }
-    for (int o = 32; o > 0; o >>= 1) words += __shfl_down(words, o, 64);
-    words = __shfl(words, 0, 64);
+    const int maxd = s_maxd;
+    if (threadIdx.x == 0) s_stop = maxd;
     __syncthreads();
-    // make_consensus_word flanktrie.py:306-342: stop at the first depth with fewer than mcc voters
-    int stop = maxd;
-    for (int d = lane; d < maxd; d += 64) {
+    // stop at the first depth with fewer than mcc voters
+    for (int d = threadIdx.x; d < maxd; d += blockDim.x) {
         uint32_t tot = 0;
         for (int c = 0; c < 16; c++) tot += hc[d * 16 + c];
-        if ((int64_t)tot < (int64_t)P.mcc) { if (d < stop) stop = d; }
+        if ((int64_t)tot < (int64_t)P.mcc) atomicMin(&s_stop, d);
     }
-    for (int o = 32; o > 0; o >>= 1) { int other = __shfl_xor(stop, o, 64); if (other < stop) stop = other; }
-    if (!EMIT) {
-        if (lane == 0) {
-            W.cl_count[slot] = (int32_t)words;
-            W.cl_len[slot] = stop;
-            W.cl_key[slot] = ((W.has_match[slot] ? 1u : 0u) << 31) | (minrank & 0x7fffffffu);
-        }
-        return;
+    __syncthreads();
+    const int stop = s_stop;
+    if (threadIdx.x == 0) {
+        W.cl_count[slot] = (int32_t)s_words;
+        W.cl_len[slot] = stop;
+        W.cl_key[slot] = ((W.has_match[slot] ? 1u : 0u) << 31) | (s_minrank & 0x7fffffffu);
     }
     const char codes[17] = "=ACMGRSVTWYHKDBN";
-    char *out = io.cons_chars + (size_t)job * io.cons_stride;
+    char *out = cl_chars + (size_t)slot * cl_stride;
     const int side = (int)(job & 1);
-    for (int d = lane; d < stop; d += 64) {
+    for (int d = threadIdx.x; d < stop; d += blockDim.x) {
         int best = -1, nbest = 0;
         for (int c = 0; c < 16; c++) {
             if (!hc[d * 16 + c]) continue;
@@ -489,6 +509,17 @@ __global__ __launch_bounds__(64) void k_cluster(DevParams P, Words W, Jobs J, ui
         char chv = nbest > 1 ? 'N' : codes[best < 0 ? 15 : best];   // get_best_qual_chars flanktrie.py:344-353
         out[side == 0 ? d : stop - 1 - d] = chv;                     // 3p consensus is reversed back (findflanks.py:894-895)
     }
+}
+
+__global__ __launch_bounds__(64) void k_emit_best(Jobs J, ConsensusIO io, const char *cl_chars, uint32_t cl_stride) {
+    uint32_t job = blockIdx.x;
+    if (job >= J.n) return;
+    uint32_t slot = J.best[job];
+    if (slot == 0xFFFFFFFFu) return;
+    int len = io.cons_len[job];
+    const char *src = cl_chars + (size_t)slot * cl_stride;
+    char *dst = io.cons_chars + (size_t)job * io.cons_stride;
+    for (int d = threadIdx.x; d < len; d += blockDim.x) dst[d] = src[d];
 }
 
 // one thread per job: filters + best consensus (findflanks.py:241-346): max by (count, len), the last in list order
@@ -540,11 +571,11 @@ int run_consensus(mfk_ctx *ctx, const DevReads &R, const DevParams &P, Consensus
     HIPCHK(hipMemsetAsync(site_act, 0xFF, (size_t)E * 4, st));
     HIPCHK(hipMemsetAsync(ev_site, 0xFF, (size_t)E * 4, st));
     HIPCHK(hipMemsetAsync(meta, 0, sizeof(CMeta), st));
-    hipLaunchKernelGGL(k_site_act_map, dim3(nblocks(n_act, 256)), dim3(256), 0, st, io.act_site, n_act, site_act);
+    PROF_LAUNCH(k_site_act_map, dim3(nblocks(n_act, 256)), dim3(256), 0, st, io.act_site, n_act, site_act);
     KCHK();
-    hipLaunchKernelGGL(k_fill_ev_site, dim3(n_act), dim3(64), 0, st, io.act_site, n_act, io.site_ev_begin, io.site_ev_end, ev_site);
+    PROF_LAUNCH(k_fill_ev_site, dim3(n_act), dim3(64), 0, st, io.act_site, n_act, io.site_ev_begin, io.site_ev_end, ev_site);
     KCHK();
-    hipLaunchKernelGGL(k_word_flags, dim3(eb), dim3(256), 0, st, io.ev_info, (const uint32_t *)ev_site, (const int32_t *)site_act, io.act_st, E, wflag);
+    PROF_LAUNCH(k_word_flags, dim3(eb), dim3(256), 0, st, io.ev_info, (const uint32_t *)ev_site, (const int32_t *)site_act, io.act_st, E, wflag);
     KCHK();
     if (int rc = dev_excl_scan32(ctx, wflag, wid, E)) return rc;
     Jobs J; memset(&J, 0, sizeof J);
@@ -552,7 +583,7 @@ int run_consensus(mfk_ctx *ctx, const DevReads &R, const DevParams &P, Consensus
     J.w0 = aalloc<uint32_t>(ctx, J.n); J.R = aalloc<uint32_t>(ctx, J.n); J.nl = aalloc<uint32_t>(ctx, J.n);
     J.adj_words = aalloc<uint32_t>(ctx, J.n); J.adj_off = aalloc<uint64_t>(ctx, (size_t)J.n + 1); J.best = aalloc<uint32_t>(ctx, J.n);
     if (!J.w0 || !J.R || !J.nl || !J.adj_words || !J.adj_off || !J.best) return 1;
-    hipLaunchKernelGGL(k_job_meta, dim3(nblocks(J.n, 256)), dim3(256), 0, st, io, (const uint32_t *)wid, J, meta);
+    PROF_LAUNCH(k_job_meta, dim3(nblocks(J.n, 256)), dim3(256), 0, st, io, (const uint32_t *)wid, J, meta);
     KCHK();
     if (int rc = dev_excl_scan64(ctx, J.adj_words, J.adj_off, J.n)) return rc;
     uint32_t Wn = 0; uint64_t adj_total = 0;
@@ -575,9 +606,9 @@ int run_consensus(mfk_ctx *ctx, const DevReads &R, const DevParams &P, Consensus
     HIPCHK(hipMemsetAsync(W.label, 0xFF, (size_t)Wn * 4, st));
     HIPCHK(hipMemsetAsync(J.adj, 0, (size_t)(adj_total ? adj_total : 1) * 4, st));
     const unsigned wb = nblocks(Wn, 256), ww = nblocks(Wn, 4);
-    hipLaunchKernelGGL(k_word_reads, dim3(eb), dim3(256), 0, st, R, P, io, (const uint32_t *)ev_site, (const uint32_t *)wflag, (const uint32_t *)wid, (const int32_t *)site_act, W);
+    PROF_LAUNCH(k_word_reads, dim3(eb), dim3(256), 0, st, R, P, io, (const uint32_t *)ev_site, (const uint32_t *)wflag, (const uint32_t *)wid, (const int32_t *)site_act, W);
     KCHK();
-    hipLaunchKernelGGL(k_word_len, dim3(wb), dim3(256), 0, st, R, W, meta);
+    PROF_LAUNCH(k_word_len, dim3(wb), dim3(256), 0, st, R, W, meta);
     KCHK();
     if (int rc = dev_excl_scan64(ctx, W.plen, W.off, Wn)) return rc;
     CMeta hm; uint64_t total_chars = 0;
@@ -588,38 +619,40 @@ int run_consensus(mfk_ctx *ctx, const DevReads &R, const DevParams &P, Consensus
     W.ch = aalloc<uint8_t>(ctx, (size_t)total_chars + 8); W.q = aalloc<uint8_t>(ctx, (size_t)total_chars + 8);
     W.t = aalloc<uint32_t>(ctx, (size_t)total_chars + 8);
     if (!W.ch || !W.q || !W.t) return 1;
-    hipLaunchKernelGGL(k_word_fill, dim3(ww), dim3(256), 0, st, R, W, meta);
+    PROF_LAUNCH(k_word_fill, dim3(ww), dim3(256), 0, st, R, W, meta);
     KCHK();
-    hipLaunchKernelGGL(k_leaf_flags, dim3(ww), dim3(256), 0, st, W, J);
+    PROF_LAUNCH(k_leaf_flags, dim3(ww), dim3(256), 0, st, W, J);
     KCHK();
-    hipLaunchKernelGGL(k_leaf_compact, dim3(J.n), dim3(256), 0, st, W, J);
+    PROF_LAUNCH(k_leaf_compact, dim3(J.n), dim3(256), 0, st, W, J);
     KCHK();
-    hipLaunchKernelGGL(k_leaf_first, dim3(Wn), dim3(64), 0, st, W, J);
+    PROF_LAUNCH(k_leaf_first, dim3(Wn), dim3(64), 0, st, W, J);
     KCHK();
     const uint32_t limbs = (hm.max_len + 63) / 64;
-    if (limbs <= 1) hipLaunchKernelGGL(k_leaf_pairs<1>, dim3(Wn), dim3(256), 0, st, W, J, limbs);
-    else if (limbs <= 2) hipLaunchKernelGGL(k_leaf_pairs<2>, dim3(Wn), dim3(256), 0, st, W, J, limbs);
-    else if (limbs <= 3) hipLaunchKernelGGL(k_leaf_pairs<3>, dim3(Wn), dim3(256), 0, st, W, J, limbs);
-    else if (limbs <= 4) hipLaunchKernelGGL(k_leaf_pairs<4>, dim3(Wn), dim3(256), 0, st, W, J, limbs);
-    else hipLaunchKernelGGL(k_leaf_pairs<8>, dim3(Wn), dim3(256), 0, st, W, J, limbs);
+    if (limbs <= 1) PROF_LAUNCH(k_leaf_pairs<1>, dim3(Wn), dim3(256), 0, st, W, J, limbs);
+    else if (limbs <= 2) PROF_LAUNCH(k_leaf_pairs<2>, dim3(Wn), dim3(256), 0, st, W, J, limbs);
+    else if (limbs <= 3) PROF_LAUNCH(k_leaf_pairs<3>, dim3(Wn), dim3(256), 0, st, W, J, limbs);
+    else if (limbs <= 4) PROF_LAUNCH(k_leaf_pairs<4>, dim3(Wn), dim3(256), 0, st, W, J, limbs);
+    else PROF_LAUNCH(k_leaf_pairs<8>, dim3(Wn), dim3(256), 0, st, W, J, limbs);
     KCHK();
-    hipLaunchKernelGGL(k_components, dim3(J.n), dim3(256), 0, st, W, J);
+    PROF_LAUNCH(k_components, dim3(J.n), dim3(256), 0, st, W, J);
     KCHK();
-    const uint32_t max_len = hm.max_len ? hm.max_len : 1, max_R = hm.max_R ? hm.max_R : 1;
-    size_t lds = (size_t)max_len * 16 * 8 + (size_t)max_R * 2 + 16;
-    if (lds > 150 * 1024) { snprintf(ctx->err, sizeof ctx->err, "site with %u clipped names x %u bases exceeds the LDS budget of the consensus kernel", max_R, max_len); return 7; }
-    if (lds > 64 * 1024) {
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_cluster<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_cluster<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    }
+    const uint32_t max_len = hm.max_len ? hm.max_len : 1;
+    size_t lds = (size_t)max_len * 16 * 8;
+    if (lds > 64 * 1024) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_cluster_vote), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     io.cons_stride = (max_len + 7) & ~7u;
     io.cons_chars = aalloc<char>(ctx, (size_t)J.n * io.cons_stride);
-    if (!io.cons_chars) return 1;
-    hipLaunchKernelGGL(k_cluster<false>, dim3(Wn), dim3(64), lds, st, P, W, J, max_R, max_len, io);
+    char *cl_chars = aalloc<char>(ctx, (size_t)Wn * io.cons_stride);
+    uint32_t *reach = aalloc<uint32_t>(ctx, (size_t)adj_total * 32);
+    if (!io.cons_chars || !cl_chars || !reach) return 1;
+    PROF_LAUNCH(k_reach_init, dim3(Wn), dim3(256), 0, st, W, J, reach);
     KCHK();
-    hipLaunchKernelGGL(k_job_best, dim3(nblocks(J.n, 256)), dim3(256), 0, st, P, W, J, io);
+    PROF_LAUNCH(k_reach, dim3(ww), dim3(256), 0, st, W, J, reach);
     KCHK();
-    hipLaunchKernelGGL(k_cluster<true>, dim3(J.n), dim3(64), lds, st, P, W, J, max_R, max_len, io);
+    PROF_LAUNCH(k_cluster_vote, dim3(Wn), dim3(256), lds, st, P, W, J, (const uint32_t *)reach, max_len, cl_chars, io.cons_stride);
+    KCHK();
+    PROF_LAUNCH(k_job_best, dim3(nblocks(J.n, 256)), dim3(256), 0, st, P, W, J, io);
+    KCHK();
+    PROF_LAUNCH(k_emit_best, dim3(J.n), dim3(64), 0, st, J, io, (const char *)cl_chars, io.cons_stride);
     KCHK();
     if (int rc = read_back_c(ctx, meta, &hm, sizeof hm)) return rc;
     if (hm.err & ERR_NO_SEQUENCE) { snprintf(ctx->err, sizeof ctx->err, "a clipped read at a surviving site has no sequence in the pool (pack with pool='clipped')"); return 2; }

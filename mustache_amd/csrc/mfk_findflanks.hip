@@ -383,7 +383,7 @@ extern "C" int mfk_findflanks(mfk_ctx *ctx, const mfk_reads *reads, const mfk_pa
     if (nblk < 1) nblk = 1;
     uint32_t *blk_cnt = aalloc<uint32_t>(ctx, nblk), *blk_off = aalloc<uint32_t>(ctx, nblk + 1);
     if (!blk_cnt || !blk_off) return 1;
-    hipLaunchKernelGGL(k_scan_clips<false>, dim3(nblk), dim3(SCAN_THREADS), 0, st, R, P, blk_cnt, (const uint32_t *)nullptr, (uint64_t *)nullptr);
+    PROF_LAUNCH(k_scan_clips<false>, dim3(nblk), dim3(SCAN_THREADS), 0, st, R, P, blk_cnt, (const uint32_t *)nullptr, (uint64_t *)nullptr);
     KCHK();
     if (int rc = dev_excl_scan32(ctx, blk_cnt, blk_off, nblk)) return rc;
     uint32_t E = 0;
@@ -399,7 +399,7 @@ extern "C" int mfk_findflanks(mfk_ctx *ctx, const mfk_reads *reads, const mfk_pa
         uint64_t *ev = aalloc<uint64_t>(ctx, E);
         ev_sorted = aalloc<uint64_t>(ctx, E);
         if (!ev || !ev_sorted) return 1;
-        hipLaunchKernelGGL(k_scan_clips<true>, dim3(nblk), dim3(SCAN_THREADS), 0, st, R, P, (uint32_t *)nullptr, (const uint32_t *)blk_off, ev);
+        PROF_LAUNCH(k_scan_clips<true>, dim3(nblk), dim3(SCAN_THREADS), 0, st, R, P, (uint32_t *)nullptr, (const uint32_t *)blk_off, ev);
         KCHK();
         if (int rc = dev_sort_keys64(ctx, ev, ev_sorted, E, 0, 64)) return rc;
         ev_info = aalloc<uint8_t>(ctx, E);
@@ -414,23 +414,23 @@ extern "C" int mfk_findflanks(mfk_ctx *ctx, const mfk_reads *reads, const mfk_pa
         HIPCHK(hipMemsetAsync(T.sflags, 0, (size_t)E * 4, st));
         HIPCHK(hipMemsetAsync(T.ev_mid, 0xFF, (size_t)E * 4, st));
         const unsigned eb = nblocks(E, 256);
-        hipLaunchKernelGGL(k_event_info, dim3(eb), dim3(256), 0, st, R, P, (const uint64_t *)ev_sorted, E, ev_info, head);
+        PROF_LAUNCH(k_event_info, dim3(eb), dim3(256), 0, st, R, P, (const uint64_t *)ev_sorted, E, ev_info, head);
         KCHK();
         if (int rc = dev_excl_scan32(ctx, head, head_scan, E)) return rc;
         n_sites_p = head_scan + E;
-        hipLaunchKernelGGL(k_site_accumulate, dim3(eb), dim3(256), 0, st, R, (const uint64_t *)ev_sorted, (const uint8_t *)ev_info, (const uint32_t *)head_scan, E, T);
+        PROF_LAUNCH(k_site_accumulate, dim3(eb), dim3(256), 0, st, R, (const uint64_t *)ev_sorted, (const uint8_t *)ev_info, (const uint32_t *)head_scan, E, T);
         KCHK();
-        hipLaunchKernelGGL(k_site_init, dim3(eb), dim3(256), 0, st, T, n_sites_p, d_stats);
+        PROF_LAUNCH(k_site_init, dim3(eb), dim3(256), 0, st, T, n_sites_p, d_stats);
         KCHK();
-        if (stop_after >= MFK_STAGE_MINLENGTH) { hipLaunchKernelGGL(k_filter_minlength, dim3(eb), dim3(256), 0, st, T, n_sites_p, d_stats); KCHK(); }
-        if (stop_after >= MFK_STAGE_MINCOUNT) { hipLaunchKernelGGL(k_filter_mincount, dim3(eb), dim3(256), 0, st, T, n_sites_p, P.mincount, d_stats); KCHK(); }
+        if (stop_after >= MFK_STAGE_MINLENGTH) { PROF_LAUNCH(k_filter_minlength, dim3(eb), dim3(256), 0, st, T, n_sites_p, d_stats); KCHK(); }
+        if (stop_after >= MFK_STAGE_MINCOUNT) { PROF_LAUNCH(k_filter_mincount, dim3(eb), dim3(256), 0, st, T, n_sites_p, P.mincount, d_stats); KCHK(); }
         if (stop_after >= MFK_STAGE_MINDIST1) {
-            hipLaunchKernelGGL(k_mindistance, dim3(eb), dim3(256), 0, st, (const uint32_t *)T.gpos, (const uint32_t *)T.cnt2, (const uint32_t *)T.st, st2, n_sites_p, 0u, P.mindist, d_stats + 3);
+            PROF_LAUNCH(k_mindistance, dim3(eb), dim3(256), 0, st, (const uint32_t *)T.gpos, (const uint32_t *)T.cnt2, (const uint32_t *)T.st, st2, n_sites_p, 0u, P.mindist, d_stats + 3);
             KCHK();
             T.st = st2;
         }
         // surviving sites -> dense active table
-        hipLaunchKernelGGL(k_alive_flags, dim3(eb), dim3(256), 0, st, (const uint32_t *)T.st, n_sites_p, E, head);
+        PROF_LAUNCH(k_alive_flags, dim3(eb), dim3(256), 0, st, (const uint32_t *)T.st, n_sites_p, E, head);
         KCHK();
         if (int rc = dev_excl_scan32(ctx, head, ascan, E)) return rc;
         if (int rc = read_back(ctx, ascan + E, &n_act, 4)) return rc;
@@ -443,18 +443,18 @@ extern "C" int mfk_findflanks(mfk_ctx *ctx, const mfk_reads *reads, const mfk_pa
         if (!A.site || !A.gpos || !A.contig || !A.cnt2 || !A.st || !A.counts || !st2) return 1;
         HIPCHK(hipMemsetAsync(A.counts, 0, 8 * (size_t)n_act * 4, st));
         const unsigned eb = nblocks(E, 256), ab = nblocks(n_act, 256);
-        hipLaunchKernelGGL(k_compact_sites, dim3(eb), dim3(256), 0, st, T, n_sites_p, (const uint32_t *)ascan, A);
+        PROF_LAUNCH(k_compact_sites, dim3(eb), dim3(256), 0, st, T, n_sites_p, (const uint32_t *)ascan, A);
         KCHK();
         if (stop_after >= MFK_STAGE_UNCLIPPED) {
-            hipLaunchKernelGGL(k_classify, dim3(n_act), dim3(256), 0, st, R, P, A, n_act);
+            PROF_LAUNCH(k_classify, dim3(n_act), dim3(256), 0, st, R, P, A, n_act);
             KCHK();
         }
         if (stop_after >= MFK_STAGE_RATIOS) {
-            hipLaunchKernelGGL(k_ratio_filter, dim3(ab), dim3(256), 0, st, A, n_act, P.minratio, P.maxir, d_stats + 4);
+            PROF_LAUNCH(k_ratio_filter, dim3(ab), dim3(256), 0, st, A, n_act, P.minratio, P.maxir, d_stats + 4);
             KCHK();
         }
         if (stop_after >= MFK_STAGE_MINDIST2) {
-            hipLaunchKernelGGL(k_mindistance, dim3(ab), dim3(256), 0, st, (const uint32_t *)A.gpos, (const uint32_t *)A.cnt2, (const uint32_t *)A.st, st2, (const uint32_t *)nullptr, n_act, P.mindist, d_stats + 5);
+            PROF_LAUNCH(k_mindistance, dim3(ab), dim3(256), 0, st, (const uint32_t *)A.gpos, (const uint32_t *)A.cnt2, (const uint32_t *)A.st, st2, (const uint32_t *)nullptr, n_act, P.mindist, d_stats + 5);
             KCHK();
             uint32_t *t = A.st; A.st = st2; st2 = t;
         }
@@ -470,11 +470,11 @@ extern "C" int mfk_findflanks(mfk_ctx *ctx, const mfk_reads *reads, const mfk_pa
             HIPCHK(hipMemsetAsync(io.n_pass_len, 0, 2 * (size_t)n_act * 4, st));
             HIPCHK(hipMemsetAsync(io.n_pass_both, 0, 2 * (size_t)n_act * 4, st));
             if (int rc = run_consensus(ctx, R, P, io)) return rc;
-            hipLaunchKernelGGL(k_consensus_filters, dim3(ab), dim3(256), 0, st, A, n_act, (const uint32_t *)io.n_pass_len, (const uint32_t *)io.n_pass_both, d_stats);
+            PROF_LAUNCH(k_consensus_filters, dim3(ab), dim3(256), 0, st, A, n_act, (const uint32_t *)io.n_pass_len, (const uint32_t *)io.n_pass_both, d_stats);
             KCHK();
         }
         if (stop_after >= MFK_STAGE_ALL) {
-            hipLaunchKernelGGL(k_mindistance, dim3(ab), dim3(256), 0, st, (const uint32_t *)A.gpos, (const uint32_t *)A.cnt2, (const uint32_t *)A.st, st2, (const uint32_t *)nullptr, n_act, P.mindist, d_stats + 9);
+            PROF_LAUNCH(k_mindistance, dim3(ab), dim3(256), 0, st, (const uint32_t *)A.gpos, (const uint32_t *)A.cnt2, (const uint32_t *)A.st, st2, (const uint32_t *)nullptr, n_act, P.mindist, d_stats + 9);
             KCHK();
             uint32_t *t = A.st; A.st = st2; st2 = t;
         }
@@ -484,6 +484,7 @@ extern "C" int mfk_findflanks(mfk_ctx *ctx, const mfk_reads *reads, const mfk_pa
     uint32_t h_stats[MFK_N_STATS];
     if (int rc = read_back(ctx, d_stats, h_stats, sizeof h_stats)) return rc;
     for (int i = 0; i < 10; i++) ctx->stats[i] = h_stats[i];
+    prof_collect(ctx);
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1) == hipSuccess) ctx->last_ms = ms;
     if (n_act > 0) {

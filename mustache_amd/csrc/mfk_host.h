@@ -22,6 +22,14 @@ struct mfk_ctx {
     std::vector<Chunk> chunks;      // device arena
     void *pinned; size_t pinned_cap;
     char err[1024];
+    // optional per-kernel timing (mfk_profile_enable): HIP events around every launch on the ctx stream
+    bool prof_on;
+    std::vector<hipEvent_t> prof_events;       // pool, two per launch
+    std::vector<const char *> prof_names;      // launches of the current call
+    size_t prof_used;
+    std::vector<std::string> prof_kernel;      // accumulated totals since the last reset
+    std::vector<double> prof_ms;
+    std::vector<int64_t> prof_calls;
     // findflanks results (host)
     std::vector<mfk_site> sites;
     std::vector<mfk_flank> flanks;
@@ -44,6 +52,16 @@ struct mfk_ctx {
     } while (0)
 
 #define KCHK() HIPCHK(hipGetLastError())
+
+void prof_begin(mfk_ctx *ctx, const char *name);
+void prof_end(mfk_ctx *ctx);
+void prof_collect(mfk_ctx *ctx);               // call after the stream has been synchronised
+#define PROF_LAUNCH(kern, grid, block, lds, stream, ...)                      \
+    do {                                                                      \
+        prof_begin(ctx, #kern);                                               \
+        hipLaunchKernelGGL(kern, grid, block, lds, stream, __VA_ARGS__);      \
+        prof_end(ctx);                                                        \
+    } while (0)
 
 // arena ----------------------------------------------------------------------------------------------------------
 void arena_reset(mfk_ctx *ctx);                       // frees nothing on the fast path; merges chunks after growth

@@ -407,7 +407,7 @@ extern "C" int mfk_ir_detect(mfk_ctx *ctx, const char *seqs, const int64_t *off,
     HIPCHK(hipMemcpyAsync(d_seqs, seqs, (size_t)total, hipMemcpyHostToDevice, st));
     HIPCHK(hipMemcpyAsync(d_off, off, ((size_t)n + 1) * 8, hipMemcpyHostToDevice, st));
     HIPCHK(hipEventRecord(ctx->ev0, st));
-    hipLaunchKernelGGL(k_ir_seqs, dim3((unsigned)n), dim3(64), 0, st, (const char *)d_seqs, (const int64_t *)d_off, (uint32_t)n, d_out);
+    PROF_LAUNCH(k_ir_seqs, dim3((unsigned)n), dim3(64), 0, st, (const char *)d_seqs, (const int64_t *)d_off, (uint32_t)n, d_out);
     KCHK();
     HIPCHK(hipEventRecord(ctx->ev1, st));
     HIPCHK(hipMemcpyAsync(out, d_out, 6 * (size_t)n * 4, hipMemcpyDeviceToHost, st));
@@ -463,7 +463,7 @@ extern "C" int mfk_pairflanks(mfk_ctx *ctx, const mfk_reads *reads, const mfk_pa
     const unsigned fb = nblocks(nF, 256);
     uint32_t *cnt = aalloc<uint32_t>(ctx, nF), *coff = aalloc<uint32_t>(ctx, (size_t)nF + 1);
     if (!cnt || !coff) return 1;
-    hipLaunchKernelGGL(k_pair_window<false>, dim3(fb), dim3(256), 0, st, F, P.maxdr, sorted, cnt, (const uint32_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr);
+    PROF_LAUNCH(k_pair_window<false>, dim3(fb), dim3(256), 0, st, F, P.maxdr, sorted, cnt, (const uint32_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr);
     KCHK();
     if (int rc = dev_excl_scan32(ctx, cnt, coff, nF)) return rc;
     uint32_t nP = 0;
@@ -481,16 +481,16 @@ extern "C" int mfk_pairflanks(mfk_ctx *ctx, const mfk_reads *reads, const mfk_pa
         uint32_t *kflag = aalloc<uint32_t>(ctx, nP), *kscan = aalloc<uint32_t>(ctx, (size_t)nP + 1);
         if (!c5 || !c3 || !ir || !keys || !keys2 || !vals || !order || !best5 || !best3 || !used5 || !used3 || !state || !kflag || !kscan) return 1;
         const unsigned pb = nblocks(nP, 256);
-        hipLaunchKernelGGL(k_pair_window<true>, dim3(fb), dim3(256), 0, st, F, P.maxdr, sorted, (uint32_t *)nullptr, (const uint32_t *)coff, c5, c3);
+        PROF_LAUNCH(k_pair_window<true>, dim3(fb), dim3(256), 0, st, F, P.maxdr, sorted, (uint32_t *)nullptr, (const uint32_t *)coff, c5, c3);
         KCHK();
-        hipLaunchKernelGGL(k_inverted_repeat, dim3(nP), dim3(64), 0, st, F, (const uint32_t *)c5, (const uint32_t *)c3, nP, ir);
+        PROF_LAUNCH(k_inverted_repeat, dim3(nP), dim3(64), 0, st, F, (const uint32_t *)c5, (const uint32_t *)c3, nP, ir);
         KCHK();
-        hipLaunchKernelGGL(k_assign_keys, dim3(pb), dim3(256), 0, st, F, (const uint32_t *)c5, (const uint32_t *)c3, (const int32_t *)ir, nP, keys, vals);
+        PROF_LAUNCH(k_assign_keys, dim3(pb), dim3(256), 0, st, F, (const uint32_t *)c5, (const uint32_t *)c3, (const int32_t *)ir, nP, keys, vals);
         KCHK();
         if (int rc = dev_sort_pairs64(ctx, keys, keys2, vals, order, nP, 0, 56)) return rc;
-        hipLaunchKernelGGL(k_assign, dim3(1), dim3(1024), 0, st, (const uint32_t *)order, (const uint32_t *)c5, (const uint32_t *)c3, nP, nF, best5, best3, used5, used3, state);
+        PROF_LAUNCH(k_assign, dim3(1), dim3(1024), 0, st, (const uint32_t *)order, (const uint32_t *)c5, (const uint32_t *)c3, nP, nF, best5, best3, used5, used3, state);
         KCHK();
-        hipLaunchKernelGGL(k_kept_flags, dim3(pb), dim3(256), 0, st, (const uint8_t *)state, nP, kflag);
+        PROF_LAUNCH(k_kept_flags, dim3(pb), dim3(256), 0, st, (const uint8_t *)state, nP, kflag);
         KCHK();
         if (int rc = dev_excl_scan32(ctx, kflag, kscan, nP)) return rc;
         if (int rc = read_back_p(ctx, kscan + nP, &nK, 4)) return rc;
@@ -501,12 +501,12 @@ extern "C" int mfk_pairflanks(mfk_ctx *ctx, const mfk_reads *reads, const mfk_pa
             uint32_t *jflag = aalloc<uint32_t>(ctx, nK), *jscan = aalloc<uint32_t>(ctx, (size_t)nK + 1);
             if (!kk || !kk2 || !kv || !kept || !spanning || !jflag || !jscan) return 1;
             const unsigned kb = nblocks(nK, 256);
-            hipLaunchKernelGGL(k_kept_keys, dim3(pb), dim3(256), 0, st, F, (const uint32_t *)order, (const uint32_t *)c5, (const uint32_t *)c3, (const uint8_t *)state, (const uint32_t *)kscan, nP, (const int32_t *)d_rank, kk, kv);
+            PROF_LAUNCH(k_kept_keys, dim3(pb), dim3(256), 0, st, F, (const uint32_t *)order, (const uint32_t *)c5, (const uint32_t *)c3, (const uint8_t *)state, (const uint32_t *)kscan, nP, (const int32_t *)d_rank, kk, kv);
             KCHK();
             if (int rc = dev_sort_pairs64(ctx, kk, kk2, kv, kept, nK, 0, 64)) return rc;
-            hipLaunchKernelGGL(k_spanning, dim3(nK), dim3(256), 0, st, R, P, F, (const uint32_t *)kept, (const uint32_t *)c5, (const uint32_t *)c3, nK, spanning);
+            PROF_LAUNCH(k_spanning, dim3(nK), dim3(256), 0, st, R, P, F, (const uint32_t *)kept, (const uint32_t *)c5, (const uint32_t *)c3, nK, spanning);
             KCHK();
-            hipLaunchKernelGGL(k_junction_filter, dim3(kb), dim3(256), 0, st, F, (const uint32_t *)kept, (const uint32_t *)c5, (const uint32_t *)c3, (const uint32_t *)spanning, (const int32_t *)ir, nK, P.maxjsp, jflag, d_pstats);
+            PROF_LAUNCH(k_junction_filter, dim3(kb), dim3(256), 0, st, F, (const uint32_t *)kept, (const uint32_t *)c5, (const uint32_t *)c3, (const uint32_t *)spanning, (const int32_t *)ir, nK, P.maxjsp, jflag, d_pstats);
             KCHK();
             if (int rc = dev_excl_scan32(ctx, jflag, jscan, nK)) return rc;
             if (int rc = read_back_p(ctx, jscan + nK, &nFin, 4)) return rc;
@@ -516,9 +516,9 @@ extern "C" int mfk_pairflanks(mfk_ctx *ctx, const mfk_reads *reads, const mfk_pa
                 char *dr = aalloc<char>(ctx, (size_t)nFin * stride); int32_t *meta = aalloc<int32_t>(ctx, 3 * (size_t)nFin);
                 if (!fin || !fin_span || !dr || !meta) return 1;
                 HIPCHK(hipMemsetAsync(dr, 0, (size_t)nFin * stride, st));
-                hipLaunchKernelGGL(k_final_list, dim3(kb), dim3(256), 0, st, (const uint32_t *)kept, (const uint32_t *)jflag, (const uint32_t *)jscan, (const uint32_t *)spanning, nK, fin, fin_span);
+                PROF_LAUNCH(k_final_list, dim3(kb), dim3(256), 0, st, (const uint32_t *)kept, (const uint32_t *)jflag, (const uint32_t *)jscan, (const uint32_t *)spanning, nK, fin, fin_span);
                 KCHK();
-                hipLaunchKernelGGL(k_direct_repeats, dim3(nFin), dim3(256), 0, st, R, F, (const uint32_t *)fin, (const uint32_t *)c5, (const uint32_t *)c3, nFin, genome, (const int64_t *)d_goff, dr, stride, meta);
+                PROF_LAUNCH(k_direct_repeats, dim3(nFin), dim3(256), 0, st, R, F, (const uint32_t *)fin, (const uint32_t *)c5, (const uint32_t *)c3, nFin, genome, (const int64_t *)d_goff, dr, stride, meta);
                 KCHK();
                 HIPCHK(hipEventRecord(ctx->ev1, st));
                 h_fin.resize(nFin); h_span.resize(nFin); h_meta.resize(3 * (size_t)nFin); h_dr.resize((size_t)nFin * stride);
@@ -539,6 +539,7 @@ extern "C" int mfk_pairflanks(mfk_ctx *ctx, const mfk_reads *reads, const mfk_pa
     uint32_t h_ps[MFK_N_STATS];
     if (int rc = read_back_p(ctx, d_pstats, h_ps, sizeof h_ps)) return rc;
     ctx->pstats[2] = h_ps[2]; ctx->pstats[3] = h_ps[3]; ctx->pstats[4] = nFin;
+    prof_collect(ctx);
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1) == hipSuccess) ctx->last_ms = ms;
     // ---- rows ------------------------------------------------------------------------------------------------------------

@@ -109,6 +109,9 @@ class Binding:
                                   C.POINTER(C.c_int64), C.POINTER(C.c_int64)])
         f("pairflanks_fetch", C.c_int, [_p, _p, _p, _p])
         f("ir_detect", C.c_int, [_p, _p, _p, C.c_int64, _p])
+        if hasattr(self.so, prefix + "profile_enable"):
+            f("profile_enable", C.c_int, [_p, C.c_int])
+            f("profile_fetch", C.c_int, [_p, _p, C.c_int64, _p, _p, C.c_int64, C.POINTER(C.c_int64)])
         self.ctx = self.create(device_id)
         if not self.ctx:
             raise MfkError("%screate(%d) failed: no usable HIP device for %s" % (prefix, device_id, path))
@@ -192,6 +195,22 @@ class Binding:
         buf = np.frombuffer(blob, dtype=np.uint8)
         self._check(self.ir_detect(self.ctx, buf.ctypes.data, off.ctypes.data, len(seqs), out.ctypes.data))
         return out
+
+    def profile(self, on=True):
+        """Start (and clear) or stop per-kernel HIP-event timing of the compute calls."""
+        self._check(self.profile_enable(self.ctx, 1 if on else 0))
+
+    def profile_totals(self):
+        """dict kernel name -> (total ms, launches) since profile(True)."""
+        cap = 256
+        names = C.create_string_buffer(1 << 16)
+        ms = np.zeros(cap, dtype=np.float64)
+        calls = np.zeros(cap, dtype=np.int64)
+        n = C.c_int64(0)
+        self._check(self.profile_fetch(self.ctx, C.cast(names, _p), len(names), ms.ctypes.data, calls.ctypes.data, cap,
+                                       C.byref(n)))
+        lst = names.value.decode().split("\n")[:n.value]
+        return {nm: (float(ms[i]), int(calls[i])) for i, nm in enumerate(lst)}
 
     def device_ms(self):
         return float(self.last_device_ms(self.ctx))
