@@ -1,0 +1,83 @@
+"""Command line: ``mustache findflanks`` / ``mustache pairflanks`` with the reference's flags, short flags and defaults
+(reference mustache/main.py:66-117; the CLI defaults are authoritative, not the class defaults or the help texts).
+
+    python -m mustache_amd.main findflanks BAM -o out.findflanks.tsv
+    python -m mustache_amd.main pairflanks FLANKS BAM GENOME -o out.pairflanks.tsv
+
+The Snakemake workflow of the reference calls exactly these two commands (workflow/Snakefile:82-87, 105-109); every flag
+it passes is accepted here.  Only these two sub-commands exist: the rest of the toolbox is outside the hot path.
+"""
+from __future__ import annotations
+
+import sys
+from os.path import abspath
+
+import click
+
+
+def log_params(**kw):
+    print("[mustache_amd] parameters: " + ", ".join("%s=%s" % (k, v) for k, v in kw.items()), file=sys.stderr)
+
+
+@click.group()
+def cli():
+    """MI355X-native flank discovery (drop-in for `mustache findflanks` / `mustache pairflanks`)."""
+
+
+@cli.command(short_help="Find insertion sites and reconstruct flanks of inserted sequence")
+@click.argument("bamfile", type=click.Path(exists=True))
+@click.option("--min_softclip_length", "-minlen", default=8)
+@click.option("--min_softclip_count", "-mincount", default=2)
+@click.option("--min_alignment_quality", "-minq", default=20)
+@click.option("--min_alignment_inner_length", "-minial", default=21)
+@click.option("--min_distance_to_mate", "-mindist", default=22)
+@click.option("--min_softclip_ratio", "-minratio", default=0.10)
+@click.option("--max_indel_ratio", "-maxir", default=0.03)
+@click.option("--large_insertion_cutoff", "-lins", default=30)
+@click.option("--min_count_consensus", "-mcc", default=2)
+@click.option("--sample_id", "-id", default=None)
+@click.option("--output_file", "-o", default="mustache.findflanks.tsv")
+@click.option("--device", default="cuda:0", help="GPU to run on (not in the reference).")
+def findflanks(bamfile, min_softclip_length, min_softclip_count, min_alignment_quality, min_alignment_inner_length,
+               min_distance_to_mate, min_softclip_ratio, max_indel_ratio, large_insertion_cutoff,
+               min_count_consensus, sample_id, output_file, device):
+    from .findflanks import _findflanks
+    if sample_id is None:
+        sample_id = abspath(output_file)           # reference main.py:84-85
+    log_params(command="findflanks", bamfile=bamfile, min_softclip_length=min_softclip_length,
+               min_softclip_count=min_softclip_count, min_alignment_quality=min_alignment_quality,
+               min_alignment_inner_length=min_alignment_inner_length, min_distance_to_mate=min_distance_to_mate,
+               min_softclip_ratio=min_softclip_ratio, max_indel_ratio=max_indel_ratio,
+               large_insertion_cutoff=large_insertion_cutoff, min_count_consensus=min_count_consensus,
+               sample_id=sample_id, output_file=output_file)
+    _findflanks(bamfile, min_softclip_length, min_softclip_count, min_alignment_quality, min_alignment_inner_length,
+                min_distance_to_mate, min_softclip_ratio, max_indel_ratio, large_insertion_cutoff,
+                min_count_consensus, sample_id, output_file, device=device)
+
+
+@cli.command(short_help="Pair identified flanks with each other to represent 5' and 3' ends of inserted sequence.")
+@click.argument("flanksfile", type=click.Path(exists=True))
+@click.argument("bamfile", type=click.Path(exists=True))
+@click.argument("genome", type=click.Path(exists=True))
+@click.option("--max_direct_repeat_length", "-maxdr", default=20)
+@click.option("--min_alignment_quality", "-minq", default=20)
+@click.option("--min_alignment_inner_length", "-minial", default=21)
+@click.option("--max_junction_spanning_prop", "-maxjsp", default=0.15)
+@click.option("--large_insertion_cutoff", "-lins", default=30)
+@click.option("--output_file", "-o", default="mustache.pairflanks.tsv")
+@click.option("--device", default="cuda:0", help="GPU to run on (not in the reference).")
+def pairflanks(flanksfile, bamfile, genome, max_direct_repeat_length, min_alignment_quality,
+               min_alignment_inner_length, max_junction_spanning_prop, large_insertion_cutoff, output_file, device):
+    from .pairflanks import _pairflanks
+    log_params(command="pairflanks", flanksfile=flanksfile, bamfile=bamfile, genome=genome,
+               max_direct_repeat_length=max_direct_repeat_length, min_alignment_quality=min_alignment_quality,
+               min_alignment_inner_length=min_alignment_inner_length,
+               max_junction_spanning_prop=max_junction_spanning_prop, large_insertion_cutoff=large_insertion_cutoff,
+               output_file=output_file)
+    _pairflanks(flanksfile, bamfile, genome, max_direct_repeat_length, min_alignment_quality,
+                min_alignment_inner_length, max_junction_spanning_prop, large_insertion_cutoff, output_file,
+                device=device)
+
+
+if __name__ == "__main__":
+    cli()

@@ -1,0 +1,58 @@
+"""The command line keeps the reference's flags (main.py:66-117).  The end-to-end BAM -> TSV run needs the GPU."""
+import os
+
+import pytest
+from click.testing import CliRunner
+
+from mustache_amd import bamio
+from mustache_amd.main import cli, findflanks, pairflanks
+from tests import util
+
+FINDFLANKS_FLAGS = {  # long, short, default   (reference main.py:68-78)
+    "min_softclip_length": ("-minlen", 8), "min_softclip_count": ("-mincount", 2),
+    "min_alignment_quality": ("-minq", 20), "min_alignment_inner_length": ("-minial", 21),
+    "min_distance_to_mate": ("-mindist", 22), "min_softclip_ratio": ("-minratio", 0.10),
+    "max_indel_ratio": ("-maxir", 0.03), "large_insertion_cutoff": ("-lins", 30),
+    "min_count_consensus": ("-mcc", 2), "sample_id": ("-id", None), "output_file": ("-o", "mustache.findflanks.tsv")}
+PAIRFLANKS_FLAGS = {  # reference main.py:102-107
+    "max_direct_repeat_length": ("-maxdr", 20), "min_alignment_quality": ("-minq", 20),
+    "min_alignment_inner_length": ("-minial", 21), "max_junction_spanning_prop": ("-maxjsp", 0.15),
+    "large_insertion_cutoff": ("-lins", 30), "output_file": ("-o", "mustache.pairflanks.tsv")}
+
+
+@pytest.mark.parametrize("cmd,flags", [(findflanks, FINDFLANKS_FLAGS), (pairflanks, PAIRFLANKS_FLAGS)])
+def test_flags_and_defaults(cmd, flags):
+    opts = {p.name: p for p in cmd.params if hasattr(p, "opts") and p.opts and p.opts[0].startswith("--")}
+    for name, (short, default) in flags.items():
+        assert name in opts, name
+        assert "--" + name in opts[name].opts and short in opts[name].opts
+        assert opts[name].default == default
+
+
+def test_help_runs():
+    r = CliRunner().invoke(cli, ["--help"])
+    assert r.exit_code == 0 and "findflanks" in r.output and "pairflanks" in r.output
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["sim_a", "quirks"])
+def test_cli_end_to_end_from_bam(tmp_path, name):
+    """BAM + FASTA on disk -> both commands -> the reference's TSVs byte for byte."""
+    case = util.load_json(name)
+    rs = util.case_readset(case)
+    bam, fa = os.path.join(tmp_path, "s.bam"), os.path.join(tmp_path, "g.fa")
+    bamio.write_bam(bam, rs)
+    bamio.write_fasta(fa, case["genome"])
+    ff, pf = os.path.join(tmp_path, "s.findflanks.tsv"), os.path.join(tmp_path, "s.pairflanks.tsv")
+    args = ["findflanks", bam, "-o", ff, "-id", "sample1"]
+    for k, v in case["findflanks_params"].items():
+        args += ["--" + k, str(v)]
+    r = CliRunner().invoke(cli, args, catch_exceptions=False)
+    assert r.exit_code == 0, r.output
+    assert open(ff).read() == case["findflanks_tsv"]
+    args = ["pairflanks", ff, bam, fa, "-o", pf]
+    for k, v in case["pairflanks_params"].items():
+        args += ["--" + k, str(v)]
+    r = CliRunner().invoke(cli, args, catch_exceptions=False)
+    assert r.exit_code == 0, r.output
+    assert open(pf).read() == case["pairflanks_tsv"]
