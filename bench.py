@@ -29,8 +29,8 @@ def algorithmic_bytes(kernel, meta):
     """Bytes one launch of `kernel` has to move for this workload (DESIGN.md "Kernels"); None = not a streaming kernel."""
     n, clipped, ev = meta["n_reads"], meta["clipped_reads"], meta["events"]
     if kernel.startswith("k_scan_clips"):
-        # flags of every read (1 B) + the rest of the 22-byte record of lenient-clipped reads; the write pass adds 8 B/event
-        return n * 1 + clipped * 21 + (ev * 8 if "true" in kernel else 0)
+        # flags of every read (1 B) + the rest of the 22-byte record of lenient-clipped reads + 8 B per event key written
+        return n * 1 + clipped * 21 + ev * 8
     if kernel == "k_classify":
         return meta["join_visits"] * 13  # ref_start, ref_end (8 B) + mapq, flags, link (5 B)... per (site, read) visit
     if kernel.startswith("rocprim::radix_sort_keys"):

@@ -131,8 +131,26 @@ void *arena_alloc(mfk_ctx *ctx, size_t bytes) {
     return p;
 }
 
+int read_back(mfk_ctx *ctx, const void *dev, void *host, size_t bytes) {
+    ReadBatch b(ctx);
+    b.add(dev, host, bytes);
+    return b.flush();
+}
+
+int ReadBatch::flush() {
+    if (items.empty()) return 0;
+    char *pin = (char *)pinned_buf(ctx, total);
+    if (!pin) { snprintf(ctx->err, sizeof ctx->err, "pinned allocation failed"); return 1; }
+    for (auto &it : items) HIPCHK(hipMemcpyAsync(pin + it.off, it.dev, it.bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    for (auto &it : items) memcpy(it.host, pin + it.off, it.bytes);
+    items.clear(); total = 0;
+    return 0;
+}
+
 void *pinned_buf(mfk_ctx *ctx, size_t bytes) {
     if (bytes > ctx->pinned_cap) {
+        (void)hipStreamSynchronize(ctx->stream);   // copies from / into the old buffer may still be queued
         if (ctx->pinned) (void)hipHostFree(ctx->pinned);
         ctx->pinned = nullptr;
         size_t cap = bytes < 4096 ? 4096 : bytes * 2;
@@ -184,7 +202,7 @@ int upload_reads(mfk_ctx *ctx, const mfk_reads *in, const mfk_params *pr, DevRea
     HIPCHK(hipMemcpyAsync(d_len, h_len, (size_t)nc * 4, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipMemcpyAsync(d_rs, h_rs, (size_t)(nc + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipMemcpyAsync(d_base, h_base, (size_t)nc * 4, hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(hipStreamSynchronize(ctx->stream));   // the pinned buffer is reused by later read-backs
+    // no synchronisation: later read-backs into the same pinned bytes are ordered behind these copies on the stream
     R->contig_len = d_len; R->contig_rs = d_rs; R->contig_base = d_base;
     P->minlen = pr->min_softclip_length; P->mincount = pr->min_softclip_count; P->minq = pr->min_alignment_quality;
     P->minial = pr->min_alignment_inner_length; P->mindist = pr->min_distance_to_mate; P->lins = pr->large_insertion_cutoff;

@@ -52,6 +52,7 @@ struct Jobs {
     uint64_t *adj_off;
     uint32_t *adj;
     uint32_t *best;                   // best representative slot or 0xFFFFFFFF
+    uint32_t *giant;                  // label of the largest component found by the pivot pass
 };
 
 __device__ __forceinline__ int d_lcp(const uint8_t *a, int la, const uint8_t *b, int lb) {
@@ -320,55 +321,97 @@ __device__ __forceinline__ int d_myers(const uint64_t (&plane)[4][NL], const uin
     return score;
 }
 
-// one block per leaf slot a; threads take the later leaves b of the same job
-template <int NL>
-__global__ __launch_bounds__(256) void k_leaf_pairs(Words W, Jobs J, uint32_t max_limbs) {
-    __shared__ uint64_t sh_plane[4][NL];
+#define N_PIVOTS 4
+
+// DFS order of the leaves (traverse_seqs, flanktrie.py:157-170): at the first differing depth the branch whose first word
+// came earlier is visited first.  One block per leaf slot a, threads over the later leaves b; rank = #leaves before.
+__global__ __launch_bounds__(256) void k_leaf_rank(Words W, Jobs J) {
     uint32_t slot = blockIdx.x;
     if (slot >= W.n) return;
-    uint32_t job = W.job[slot], w0 = J.w0[job], R = J.R[job], nl = J.nl[job];
+    uint32_t job = W.job[slot], w0 = J.w0[job], nl = J.nl[job];
     uint32_t ka = slot - w0;
     if (ka + 1 >= nl) return;
     uint32_t wa = w0 + W.leaf_word[slot];
     const uint8_t *a = W.ch + W.off[wa];
     const int la = (int)W.len[wa];
-    const int need = (la + 63) >> 6;
-    if (need > NL) return;   // cannot happen: NL is chosen from the longest word of the call
-    (void)max_limbs;
-    if (threadIdx.x < 4 * NL) {
-        int p = threadIdx.x / NL, i = threadIdx.x % NL;
-        uint64_t v = 0;
-        for (int b = 0; b < 64; b++) { int pos = i * 64 + b; if (pos < la && ((a[pos] >> p) & 1)) v |= 1ull << b; }
-        sh_plane[p][i] = v;
-    }
-    __syncthreads();
-    uint64_t plane[4][NL];
-#pragma unroll
-    for (int p = 0; p < 4; p++)
-#pragma unroll
-        for (int i = 0; i < NL; i++) plane[p][i] = sh_plane[p][i];
-    const uint32_t rw = (R + 31) >> 5;
-    uint32_t *adj = J.adj + J.adj_off[job];
     const uint32_t *ta = W.t + W.off[wa];
     uint32_t rank_a = 0;
     for (uint32_t kb = ka + 1 + threadIdx.x; kb < nl; kb += blockDim.x) {
         uint32_t wb = w0 + W.leaf_word[w0 + kb];
-        const uint8_t *b = W.ch + W.off[wb];
         const int lb = (int)W.len[wb];
         const int m = la < lb ? la : lb;
-        int d = d_myers<NL>(plane, b, m);
-        if (4 * d <= m) {   // similarity = 1 - d/m >= 0.75 (findflanks.py:1044-1048, quirk Q11)
-            atomicOr(&adj[(size_t)ka * rw + (kb >> 5)], 1u << (kb & 31));
-            atomicOr(&adj[(size_t)kb * rw + (ka >> 5)], 1u << (ka & 31));
-        }
-        // DFS order: at the first differing depth the branch whose first word came earlier is visited first
-        int k = d_lcp(a, la, b, lb);
+        int k = d_lcp(a, la, W.ch + W.off[wb], lb);
         if (k < m) {
             uint32_t tav = ta[k], tbv = W.t[W.off[wb] + k];
             if (tav < tbv) atomicAdd(&W.leaf_rank[w0 + kb], 1u); else rank_a++;
         }
     }
     if (rank_a) atomicAdd(&W.leaf_rank[slot], rank_a);
+}
+
+__device__ __forceinline__ int d_myers_any(const uint64_t (*sh_plane)[8], int need, const uint8_t *text, int m) {
+#define MYERS_CASE(NL_)                                                                                  \
+    {                                                                                                    \
+        uint64_t pl[4][NL_];                                                                             \
+        _Pragma("unroll") for (int p = 0; p < 4; p++) _Pragma("unroll") for (int i = 0; i < NL_; i++) pl[p][i] = sh_plane[p][i]; \
+        return d_myers<NL_>(pl, text, m);                                                                \
+    }
+    switch (need) {
+        case 1: MYERS_CASE(1)
+        case 2: MYERS_CASE(2)
+        case 3: MYERS_CASE(3)
+        case 4: MYERS_CASE(4)
+        default: MYERS_CASE(8)
+    }
+#undef MYERS_CASE
+}
+
+// Edit-distance tests between leaves (get_sequence_clusters, findflanks.py:1041-1053).  Only connectivity and "has any
+// match" are needed downstream, so pairs inside an already known component are never tested:
+//   mode 0: the first N_PIVOTS leaves of the job against every later leaf;
+//   mode 1: every leaf outside the giant component against every leaf of a different component.
+// Every pair across two components of the mode-0 graph is tested, so the final components are those of the full graph.
+// One block per leaf slot a (the bit-vector pattern), threads over the partners.
+__global__ __launch_bounds__(256) void k_leaf_myers(Words W, Jobs J, int mode) {
+    __shared__ uint64_t sh_plane[4][8];
+    uint32_t slot = blockIdx.x;
+    if (slot >= W.n) return;
+    uint32_t job = W.job[slot], w0 = J.w0[job], R = J.R[job], nl = J.nl[job];
+    uint32_t ka = slot - w0;
+    if (ka >= nl || nl < 2) return;
+    uint32_t my_label = 0, giant = 0;
+    if (mode == 0) { if (ka >= N_PIVOTS) return; }
+    else { my_label = W.label[slot]; giant = J.giant[job]; if (my_label == giant) return; }
+    uint32_t wa = w0 + W.leaf_word[slot];
+    const uint8_t *a = W.ch + W.off[wa];
+    const int la = (int)W.len[wa];
+    const int need = (la + 63) >> 6;
+    if (need > 8) return;   // cannot happen: words are capped at MAX_WORD_LEN
+    if (threadIdx.x < 32) {
+        int p = threadIdx.x >> 3, i = threadIdx.x & 7;
+        uint64_t v = 0;
+        if (i < need) for (int b = 0; b < 64; b++) { int pos = i * 64 + b; if (pos < la && ((a[pos] >> p) & 1)) v |= 1ull << b; }
+        sh_plane[p][i] = v;
+    }
+    __syncthreads();
+    const uint32_t rw = (R + 31) >> 5;
+    uint32_t *adj = J.adj + J.adj_off[job];
+    for (uint32_t kb = (mode == 0 ? ka + 1 : 0) + threadIdx.x; kb < nl; kb += blockDim.x) {
+        if (mode == 1) {
+            if (kb == ka) continue;
+            uint32_t lb_label = W.label[w0 + kb];
+            if (lb_label == my_label) continue;
+            if (lb_label != giant && kb < ka) continue;       // two outsiders: the lower slot's block takes the pair
+        }
+        uint32_t wb = w0 + W.leaf_word[w0 + kb];
+        const int lb = (int)W.len[wb];
+        const int m = la < lb ? la : lb;
+        int d = d_myers_any(sh_plane, need, W.ch + W.off[wb], m);
+        if (4 * d <= m) {   // similarity = 1 - d/m >= 0.75 (findflanks.py:1044-1048, quirk Q11)
+            atomicOr(&adj[(size_t)ka * rw + (kb >> 5)], 1u << (kb & 31));
+            atomicOr(&adj[(size_t)kb * rw + (ka >> 5)], 1u << (ka & 31));
+        }
+    }
 }
 
 // one block per job: connected components by label propagation over the adjacency bit matrix
@@ -402,6 +445,21 @@ __global__ __launch_bounds__(256) void k_components(Words W, Jobs J) {
         }
         __syncthreads();
         if (!changed) break;
+    }
+    // the largest component among those of the first N_PIVOTS leaves (k_leaf_myers mode 1 skips its members)
+    __shared__ uint32_t pc[N_PIVOTS];
+    if (threadIdx.x < N_PIVOTS) pc[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t np = nl < N_PIVOTS ? nl : N_PIVOTS;
+    for (uint32_t a = threadIdx.x; a < nl; a += blockDim.x) {
+        uint32_t l = label[a];
+        for (uint32_t p = 0; p < np; p++) if (label[p] == l) { atomicAdd(&pc[p], 1u); break; }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t best = 0;
+        for (uint32_t p = 1; p < np; p++) if (pc[p] > pc[best]) best = p;
+        J.giant[job] = label[best];
     }
 }
 
@@ -547,15 +605,6 @@ __global__ void k_job_best(DevParams P, Words W, Jobs J, ConsensusIO io) {
 }
 
 // =====================================================================================================================
-static int read_back_c(mfk_ctx *ctx, const void *dev, void *host, size_t bytes) {
-    void *pin = pinned_buf(ctx, bytes);
-    if (!pin) { snprintf(ctx->err, sizeof ctx->err, "pinned allocation failed"); return 1; }
-    HIPCHK(hipMemcpyAsync(pin, dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipStreamSynchronize(ctx->stream));
-    memcpy(host, pin, bytes);
-    return 0;
-}
-
 int run_consensus(mfk_ctx *ctx, const DevReads &R, const DevParams &P, ConsensusIO &io) {
     hipStream_t st = ctx->stream;
     const uint32_t E = io.n_events, n_act = io.n_act;
@@ -581,14 +630,13 @@ int run_consensus(mfk_ctx *ctx, const DevReads &R, const DevParams &P, Consensus
     Jobs J; memset(&J, 0, sizeof J);
     J.n = 2 * n_act;
     J.w0 = aalloc<uint32_t>(ctx, J.n); J.R = aalloc<uint32_t>(ctx, J.n); J.nl = aalloc<uint32_t>(ctx, J.n);
-    J.adj_words = aalloc<uint32_t>(ctx, J.n); J.adj_off = aalloc<uint64_t>(ctx, (size_t)J.n + 1); J.best = aalloc<uint32_t>(ctx, J.n);
-    if (!J.w0 || !J.R || !J.nl || !J.adj_words || !J.adj_off || !J.best) return 1;
+    J.adj_words = aalloc<uint32_t>(ctx, J.n); J.adj_off = aalloc<uint64_t>(ctx, (size_t)J.n + 1); J.best = aalloc<uint32_t>(ctx, J.n); J.giant = aalloc<uint32_t>(ctx, J.n);
+    if (!J.w0 || !J.R || !J.nl || !J.adj_words || !J.adj_off || !J.best || !J.giant) return 1;
     PROF_LAUNCH(k_job_meta, dim3(nblocks(J.n, 256)), dim3(256), 0, st, io, (const uint32_t *)wid, J, meta);
     KCHK();
     if (int rc = dev_excl_scan64(ctx, J.adj_words, J.adj_off, J.n)) return rc;
     uint32_t Wn = 0; uint64_t adj_total = 0;
-    if (int rc = read_back_c(ctx, wid + E, &Wn, 4)) return rc;
-    if (int rc = read_back_c(ctx, J.adj_off + J.n, &adj_total, 8)) return rc;
+    { ReadBatch rb(ctx); rb.add(wid + E, &Wn, 4); rb.add(J.adj_off + J.n, &adj_total, 8); if (int rc = rb.flush()) return rc; }
     if (Wn == 0) return 0;
     Words W; memset(&W, 0, sizeof W);
     W.n = Wn;
@@ -612,8 +660,7 @@ int run_consensus(mfk_ctx *ctx, const DevReads &R, const DevParams &P, Consensus
     KCHK();
     if (int rc = dev_excl_scan64(ctx, W.plen, W.off, Wn)) return rc;
     CMeta hm; uint64_t total_chars = 0;
-    if (int rc = read_back_c(ctx, meta, &hm, sizeof hm)) return rc;
-    if (int rc = read_back_c(ctx, W.off + Wn, &total_chars, 8)) return rc;
+    { ReadBatch rb(ctx); rb.add(meta, &hm, sizeof hm); rb.add(W.off + Wn, &total_chars, 8); if (int rc = rb.flush()) return rc; }
     if (hm.err & ERR_READ_NUMBER) { snprintf(ctx->err, sizeof ctx->err, "READ NUMBER ERROR - ZERO OR MORE THAN TWO READS ASSOCIATED WITH QUERY NAME"); return 3; }
     if (hm.err & ERR_WORD_TOO_LONG) { snprintf(ctx->err, sizeof ctx->err, "soft clip longer than %d bases: not supported by this build", MAX_WORD_LEN); return 6; }
     W.ch = aalloc<uint8_t>(ctx, (size_t)total_chars + 8); W.q = aalloc<uint8_t>(ctx, (size_t)total_chars + 8);
@@ -627,12 +674,13 @@ int run_consensus(mfk_ctx *ctx, const DevReads &R, const DevParams &P, Consensus
     KCHK();
     PROF_LAUNCH(k_leaf_first, dim3(Wn), dim3(64), 0, st, W, J);
     KCHK();
-    const uint32_t limbs = (hm.max_len + 63) / 64;
-    if (limbs <= 1) PROF_LAUNCH(k_leaf_pairs<1>, dim3(Wn), dim3(256), 0, st, W, J, limbs);
-    else if (limbs <= 2) PROF_LAUNCH(k_leaf_pairs<2>, dim3(Wn), dim3(256), 0, st, W, J, limbs);
-    else if (limbs <= 3) PROF_LAUNCH(k_leaf_pairs<3>, dim3(Wn), dim3(256), 0, st, W, J, limbs);
-    else if (limbs <= 4) PROF_LAUNCH(k_leaf_pairs<4>, dim3(Wn), dim3(256), 0, st, W, J, limbs);
-    else PROF_LAUNCH(k_leaf_pairs<8>, dim3(Wn), dim3(256), 0, st, W, J, limbs);
+    PROF_LAUNCH(k_leaf_rank, dim3(Wn), dim3(256), 0, st, W, J);
+    KCHK();
+    PROF_LAUNCH(k_leaf_myers, dim3(Wn), dim3(256), 0, st, W, J, 0);
+    KCHK();
+    PROF_LAUNCH(k_components, dim3(J.n), dim3(256), 0, st, W, J);
+    KCHK();
+    PROF_LAUNCH(k_leaf_myers, dim3(Wn), dim3(256), 0, st, W, J, 1);
     KCHK();
     PROF_LAUNCH(k_components, dim3(J.n), dim3(256), 0, st, W, J);
     KCHK();
@@ -654,7 +702,6 @@ int run_consensus(mfk_ctx *ctx, const DevReads &R, const DevParams &P, Consensus
     KCHK();
     PROF_LAUNCH(k_emit_best, dim3(J.n), dim3(64), 0, st, J, io, (const char *)cl_chars, io.cons_stride);
     KCHK();
-    if (int rc = read_back_c(ctx, meta, &hm, sizeof hm)) return rc;
-    if (hm.err & ERR_NO_SEQUENCE) { snprintf(ctx->err, sizeof ctx->err, "a clipped read at a surviving site has no sequence in the pool (pack with pool='clipped')"); return 2; }
+    io.err_dev = &meta->err;   // ERR_NO_SEQUENCE can still be raised by k_word_fill: the caller reads it with the results
     return 0;
 }

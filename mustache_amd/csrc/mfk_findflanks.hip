@@ -1,10 +1,10 @@
 // mfk_findflanks.hip -- the findflanks pipeline of libmfk.so (replaces SoftclipParser driven as in the reference's
 // _findflanks, findflanks.py:24-51).  Kernels, in call order:
 //
-//   k_scan_clips<false/true>  parse_softclips (findflanks.py:100-121): streams the flags column (1 B/read, 16 reads per
+//   k_scan_clips              parse_softclips (findflanks.py:100-121): streams the flags column (1 B/read, 16 reads per
 //                             lane per load), evaluates the read filters only for lenient-clipped reads and emits one
-//                             64-bit event key (gpos | side | read) per clip.  Two passes (count, then write at the
-//                             scanned offsets): deterministic order, no contended atomics.
+//                             64-bit event key (gpos | side | read) per clip, staged in LDS, one global reservation per
+//                             workgroup; the sort that follows makes the order deterministic (keys are unique).
 //   rocPRIM radix sort        events -> (site, side, BAM order)
 //   k_event_info              per event: site head, first-of-its-query-name (link-chain walk, quirk Q3), meets_minlength
 //   k_site_accumulate         per-site distinct-name counts and flags (SoftclipSite, findflanks.py:727-745, 797-801)
@@ -21,74 +21,57 @@
 #define SCAN_MAX_BLOCKS 2048
 
 // ---- K1: clip events -------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t d_emit_events(const DevReads &R, const DevParams &P, int64_t r, uint8_t f, uint64_t *out) {
-    // returns the number of events of read r; writes their keys when out != nullptr
-    if (!(f & 15)) return 0;
-    if (!d_passes(R, P, r, f)) return 0;
-    uint32_t c = 0;
-    uint32_t base = R.contig_base[R.contig_id[r]];
-    if (d_rkind(f)) {   // right clip -> 5p site (findflanks.py:117-118, 594-597)
-        if (out) out[c] = ((uint64_t)(base + (uint32_t)(d_rsite(R, r, f) + 1)) << 32) | (uint64_t)(uint32_t)r;
-        c++;
-    }
-    if (d_lkind(f)) {   // left clip -> 3p site (findflanks.py:120-121, 599-602)
-        if (out) out[c] = ((uint64_t)(base + (uint32_t)(d_lsite(R, r, f) + 1)) << 32) | (1ull << 31) | (uint64_t)(uint32_t)r;
-        c++;
-    }
-    return c;
+// parse_softclips (findflanks.py:100-121) in one pass.  Each lane loads the flags of 16 consecutive reads (one dwordx4);
+// only lenient-clipped reads (~1.5 %) gather the rest of their record, run passes_read_filters and emit one 64-bit key
+// (gpos | side | read) per clip.  Keys are staged in LDS and flushed with ONE global reservation per workgroup; their
+// order is arbitrary, which is fine because keys are unique and the radix sort that follows fixes the order.
+#define EV_STAGE 2048
+
+__device__ __forceinline__ void d_stage_event(uint64_t key, uint64_t *stage, uint32_t *s_n, uint64_t *ev, uint32_t *ev_count, uint32_t cap) {
+    uint32_t slot = atomicAdd(s_n, 1u);
+    if (slot < EV_STAGE) stage[slot] = key;
+    else { uint32_t g = atomicAdd(ev_count, 1u); if (g < cap) ev[g] = key; }   // deeper than the stage: rare slow path
 }
 
-template <bool WRITE>
-__global__ __launch_bounds__(SCAN_THREADS) void k_scan_clips(DevReads R, DevParams P, uint32_t *block_counts, const uint32_t *block_offsets, uint64_t *ev) {
-    __shared__ uint32_t sh[8];
+__global__ __launch_bounds__(SCAN_THREADS) void k_scan_clips(DevReads R, DevParams P, uint64_t *ev, uint32_t *ev_count, uint32_t cap) {
+    __shared__ uint64_t stage[EV_STAGE];
+    __shared__ uint32_t s_n, s_base;
+    if (threadIdx.x == 0) s_n = 0;
+    __syncthreads();
     const int64_t ngroups = (R.n + 15) >> 4;
     const int64_t per_block = (ngroups + gridDim.x - 1) / gridDim.x;
     const int64_t g0 = (int64_t)blockIdx.x * per_block;
     int64_t g1 = g0 + per_block;
     if (g1 > ngroups) g1 = ngroups;
-    uint32_t running = WRITE ? block_offsets[blockIdx.x] : 0;
-    for (int64_t gb = g0; gb < g1; gb += SCAN_THREADS) {
-        const int64_t g = gb + threadIdx.x;
-        uint32_t c = 0;
+    for (int64_t g = g0 + threadIdx.x; g < g1; g += SCAN_THREADS) {
         uint32_t w[4] = {0, 0, 0, 0};
-        int nvalid = 0;
-        if (g < g1) {
-            const int64_t r0 = g << 4;
-            if (r0 + 16 <= R.n) {
-                uint4 v = *reinterpret_cast<const uint4 *>(R.flags + r0);
-                w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w; nvalid = 16;
-            } else {
-                nvalid = (int)(R.n - r0);
-                for (int k = 0; k < nvalid; k++) w[k >> 2] |= (uint32_t)R.flags[r0 + k] << ((k & 3) * 8);
-            }
-            if ((w[0] | w[1] | w[2] | w[3]) & 0x0F0F0F0Fu) {
-                for (int k = 0; k < nvalid; k++) {
-                    uint8_t f = (uint8_t)(w[k >> 2] >> ((k & 3) * 8));
-                    if (f & 15) c += d_emit_events(R, P, r0 + k, f, nullptr);
-                }
-            }
-        }
-        if (WRITE) {
-            uint32_t tot;
-            uint32_t off = block_excl_scan(c, sh, &tot);
-            if (c) {
-                uint64_t *dst = ev + running + off;
-                const int64_t r0 = g << 4;
-                for (int k = 0; k < nvalid; k++) {
-                    uint8_t f = (uint8_t)(w[k >> 2] >> ((k & 3) * 8));
-                    if (f & 15) dst += d_emit_events(R, P, r0 + k, f, dst);
-                }
-            }
-            running += tot;
+        int nvalid = 16;
+        const int64_t r0 = g << 4;
+        if (r0 + 16 <= R.n) {
+            uint4 v = *reinterpret_cast<const uint4 *>(R.flags + r0);
+            w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
         } else {
-            running += c;
+            nvalid = (int)(R.n - r0);
+            for (int k = 0; k < nvalid; k++) w[k >> 2] |= (uint32_t)R.flags[r0 + k] << ((k & 3) * 8);
+        }
+        if (!((w[0] | w[1] | w[2] | w[3]) & 0x0F0F0F0Fu)) continue;
+        for (int k = 0; k < nvalid; k++) {
+            const uint8_t f = (uint8_t)(w[k >> 2] >> ((k & 3) * 8));
+            if (!(f & 15)) continue;
+            const int64_t r = r0 + k;
+            if (!d_passes(R, P, r, f)) continue;
+            const uint32_t base = R.contig_base[R.contig_id[r]];
+            if (d_rkind(f))   // right clip -> 5p site (findflanks.py:117-118, 594-597)
+                d_stage_event(((uint64_t)(base + (uint32_t)(d_rsite(R, r, f) + 1)) << 32) | (uint64_t)(uint32_t)r, stage, &s_n, ev, ev_count, cap);
+            if (d_lkind(f))   // left clip -> 3p site (findflanks.py:120-121, 599-602)
+                d_stage_event(((uint64_t)(base + (uint32_t)(d_lsite(R, r, f) + 1)) << 32) | (1ull << 31) | (uint64_t)(uint32_t)r, stage, &s_n, ev, ev_count, cap);
         }
     }
-    if (!WRITE) {
-        uint32_t tot;
-        (void)block_excl_scan(running, sh, &tot);
-        if (threadIdx.x == 0) block_counts[blockIdx.x] = tot;
-    }
+    __syncthreads();
+    const uint32_t n = s_n < EV_STAGE ? s_n : EV_STAGE;
+    if (threadIdx.x == 0 && n) s_base = atomicAdd(ev_count, n);
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < n; i += SCAN_THREADS) if (s_base + i < cap) ev[s_base + i] = stage[i];
 }
 
 // ---- K2: per-event information ---------------------------------------------------------------------------------
@@ -346,15 +329,6 @@ __global__ void k_consensus_filters(ActTab A, uint32_t n_act, const uint32_t *n_
 }
 
 // =====================================================================================================================
-static int read_back(mfk_ctx *ctx, const void *dev, void *host, size_t bytes) {
-    void *pin = pinned_buf(ctx, bytes);
-    if (!pin) { snprintf(ctx->err, sizeof ctx->err, "pinned allocation failed"); return 1; }
-    HIPCHK(hipMemcpyAsync(pin, dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipStreamSynchronize(ctx->stream));
-    memcpy(host, pin, bytes);
-    return 0;
-}
-
 static const char BASE_ASCII[] = "=ACMGRSVTWYHKDBN";
 
 extern "C" int mfk_findflanks(mfk_ctx *ctx, const mfk_reads *reads, const mfk_params *params, int stop_after, int64_t *n_sites_out, int64_t *n_flanks_out, int64_t *seq_bytes_out) {
@@ -381,13 +355,23 @@ extern "C" int mfk_findflanks(mfk_ctx *ctx, const mfk_reads *reads, const mfk_pa
     unsigned nblk = (unsigned)((ngroups + SCAN_THREADS - 1) / SCAN_THREADS);
     if (nblk > SCAN_MAX_BLOCKS) nblk = SCAN_MAX_BLOCKS;
     if (nblk < 1) nblk = 1;
-    uint32_t *blk_cnt = aalloc<uint32_t>(ctx, nblk), *blk_off = aalloc<uint32_t>(ctx, nblk + 1);
-    if (!blk_cnt || !blk_off) return 1;
-    PROF_LAUNCH(k_scan_clips<false>, dim3(nblk), dim3(SCAN_THREADS), 0, st, R, P, blk_cnt, (const uint32_t *)nullptr, (uint64_t *)nullptr);
-    KCHK();
-    if (int rc = dev_excl_scan32(ctx, blk_cnt, blk_off, nblk)) return rc;
+    uint32_t *ev_count = aalloc<uint32_t>(ctx, 1);
+    if (!ev_count) return 1;
     uint32_t E = 0;
-    if (int rc = read_back(ctx, blk_off + nblk, &E, 4)) return rc;
+    uint64_t *ev = nullptr;
+    uint64_t cap64 = (uint64_t)R.n / 8 + 65536;            // clips are a few percent of the reads; grown on overflow
+    for (int attempt = 0; attempt < 2; attempt++) {
+        if (cap64 > 2 * (uint64_t)R.n + 16) cap64 = 2 * (uint64_t)R.n + 16;
+        if (cap64 > 0xFFFFFFF0ull) { snprintf(ctx->err, sizeof ctx->err, "more than 2^32 soft-clip events in one call"); return 1; }
+        ev = aalloc<uint64_t>(ctx, (size_t)cap64);
+        if (!ev) return 1;
+        HIPCHK(hipMemsetAsync(ev_count, 0, 4, st));
+        PROF_LAUNCH(k_scan_clips, dim3(nblk), dim3(SCAN_THREADS), 0, st, R, P, ev, ev_count, (uint32_t)cap64);
+        KCHK();
+        if (int rc = read_back(ctx, ev_count, &E, 4)) return rc;
+        if ((uint64_t)E <= cap64) break;
+        cap64 = (uint64_t)E + 16;                            // every event was counted: exact size for the second try
+    }
     ctx->stats[10] = E;
 
     uint32_t n_act = 0;
@@ -396,11 +380,8 @@ extern "C" int mfk_findflanks(mfk_ctx *ctx, const mfk_reads *reads, const mfk_pa
     uint64_t *ev_sorted = nullptr; uint8_t *ev_info = nullptr;
     uint32_t *ascan = nullptr; const uint32_t *n_sites_p = nullptr;
     if (E > 0) {
-        uint64_t *ev = aalloc<uint64_t>(ctx, E);
         ev_sorted = aalloc<uint64_t>(ctx, E);
-        if (!ev || !ev_sorted) return 1;
-        PROF_LAUNCH(k_scan_clips<true>, dim3(nblk), dim3(SCAN_THREADS), 0, st, R, P, (uint32_t *)nullptr, (const uint32_t *)blk_off, ev);
-        KCHK();
+        if (!ev_sorted) return 1;
         if (int rc = dev_sort_keys64(ctx, ev, ev_sorted, E, 0, 64)) return rc;
         ev_info = aalloc<uint8_t>(ctx, E);
         uint32_t *head = aalloc<uint32_t>(ctx, E), *head_scan = aalloc<uint32_t>(ctx, (size_t)E + 1);
@@ -482,28 +463,33 @@ extern "C" int mfk_findflanks(mfk_ctx *ctx, const mfk_reads *reads, const mfk_pa
     HIPCHK(hipEventRecord(ctx->ev1, st));
     // ---- results to the host -------------------------------------------------------------------------------------
     uint32_t h_stats[MFK_N_STATS];
-    if (int rc = read_back(ctx, d_stats, h_stats, sizeof h_stats)) return rc;
+    std::vector<uint32_t> gpos(n_act), cnt2(2 * (size_t)n_act), stv(n_act), counts(8 * (size_t)n_act);
+    std::vector<int32_t> contig(n_act);
+    std::vector<int32_t> ccount, clen; std::vector<char> cchars;
+    const bool have_cons = stop_after >= MFK_STAGE_CONSENSUS && n_act > 0;
+    {
+        ReadBatch rb(ctx);
+        rb.add(d_stats, h_stats, sizeof h_stats);
+        if (io.err_dev) rb.add(io.err_dev, &io.err_flags, 4);
+        if (n_act > 0) {
+            rb.add(A.gpos, gpos.data(), n_act * 4); rb.add(A.contig, contig.data(), n_act * 4);
+            rb.add(A.cnt2, cnt2.data(), 2 * (size_t)n_act * 4); rb.add(A.st, stv.data(), n_act * 4);
+            rb.add(A.counts, counts.data(), 8 * (size_t)n_act * 4);
+        }
+        if (have_cons) {
+            ccount.resize(2 * (size_t)n_act); clen.resize(2 * (size_t)n_act);
+            cchars.resize((size_t)2 * n_act * io.cons_stride + 1);
+            rb.add(io.cons_count, ccount.data(), 2 * (size_t)n_act * 4); rb.add(io.cons_len, clen.data(), 2 * (size_t)n_act * 4);
+            if (io.cons_stride && io.cons_chars) rb.add(io.cons_chars, cchars.data(), (size_t)2 * n_act * io.cons_stride);
+        }
+        if (int rc = rb.flush()) return rc;
+    }
     for (int i = 0; i < 10; i++) ctx->stats[i] = h_stats[i];
     prof_collect(ctx);
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1) == hipSuccess) ctx->last_ms = ms;
+    if (io.err_flags & 2u) { snprintf(ctx->err, sizeof ctx->err, "a clipped read at a surviving site has no sequence in the pool (pack with pool='clipped')"); return 2; }
     if (n_act > 0) {
-        std::vector<uint32_t> gpos(n_act), cnt2(2 * (size_t)n_act), stv(n_act), counts(8 * (size_t)n_act);
-        std::vector<int32_t> contig(n_act);
-        if (int rc = read_back(ctx, A.gpos, gpos.data(), n_act * 4)) return rc;
-        if (int rc = read_back(ctx, A.contig, contig.data(), n_act * 4)) return rc;
-        if (int rc = read_back(ctx, A.cnt2, cnt2.data(), 2 * (size_t)n_act * 4)) return rc;
-        if (int rc = read_back(ctx, A.st, stv.data(), n_act * 4)) return rc;
-        if (int rc = read_back(ctx, A.counts, counts.data(), 8 * (size_t)n_act * 4)) return rc;
-        std::vector<int32_t> ccount, clen; std::vector<char> cchars;
-        const bool have_cons = stop_after >= MFK_STAGE_CONSENSUS;
-        if (have_cons) {
-            ccount.resize(2 * (size_t)n_act); clen.resize(2 * (size_t)n_act);
-            if (int rc = read_back(ctx, io.cons_count, ccount.data(), 2 * (size_t)n_act * 4)) return rc;
-            if (int rc = read_back(ctx, io.cons_len, clen.data(), 2 * (size_t)n_act * 4)) return rc;
-            cchars.resize((size_t)2 * n_act * io.cons_stride + 1);
-            if (io.cons_stride) if (int rc = read_back(ctx, io.cons_chars, cchars.data(), (size_t)2 * n_act * io.cons_stride)) return rc;
-        }
         // contig_base on the host (same formula as upload_reads)
         std::vector<int64_t> base(reads->n_contigs);
         { int64_t pad = (int64_t)params->min_distance_to_mate + params->max_direct_repeat_length + 64; if (pad < 64) pad = 64; int64_t b = 0; for (int c = 0; c < reads->n_contigs; c++) { base[c] = b; b += (int64_t)reads->h_contig_len[c] + 2 + pad; } }

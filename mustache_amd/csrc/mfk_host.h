@@ -67,7 +67,17 @@ void prof_collect(mfk_ctx *ctx);               // call after the stream has been
 void arena_reset(mfk_ctx *ctx);                       // frees nothing on the fast path; merges chunks after growth
 void *arena_alloc(mfk_ctx *ctx, size_t bytes);        // 256-byte aligned device memory valid until the next reset
 template <typename T> static inline T *aalloc(mfk_ctx *ctx, size_t n) { return (T *)arena_alloc(ctx, (n ? n : 1) * sizeof(T)); }
-void *pinned_buf(mfk_ctx *ctx, size_t bytes);
+void *pinned_buf(mfk_ctx *ctx, size_t bytes);      // grows (after draining the stream) and returns the staging buffer
+
+// device -> host read-backs: one stream synchronisation per batch
+int read_back(mfk_ctx *ctx, const void *dev, void *host, size_t bytes);
+struct ReadBatch {
+    struct Item { const void *dev; void *host; size_t bytes, off; };
+    mfk_ctx *ctx; std::vector<Item> items; size_t total;
+    explicit ReadBatch(mfk_ctx *c) : ctx(c), total(0) {}
+    void add(const void *dev, void *host, size_t bytes) { if (bytes) { items.push_back({dev, host, bytes, total}); total += (bytes + 15) & ~(size_t)15; } }
+    int flush();
+};
 
 int upload_reads(mfk_ctx *ctx, const mfk_reads *reads, const mfk_params *params, DevReads *R, DevParams *P);
 
@@ -90,5 +100,6 @@ struct ConsensusIO {
     // outputs, indexed by job = 2*k + side (side 0 = 5p, 1 = 3p)
     int32_t *cons_count, *cons_len; uint32_t *n_pass_len, *n_pass_both;
     char *cons_chars; uint32_t cons_stride;
+    const uint32_t *err_dev; uint32_t err_flags;   // device error word of the consensus stage, read back with the results
 };
 int run_consensus(mfk_ctx *ctx, const DevReads &R, const DevParams &P, ConsensusIO &io);

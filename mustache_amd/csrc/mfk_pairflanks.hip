@@ -27,15 +27,6 @@ struct FlankDev {
     const char *seqs;
 };
 
-static int read_back_p(mfk_ctx *ctx, const void *dev, void *host, size_t bytes) {
-    void *pin = pinned_buf(ctx, bytes);
-    if (!pin) { snprintf(ctx->err, sizeof ctx->err, "pinned allocation failed"); return 1; }
-    HIPCHK(hipMemcpyAsync(pin, dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipStreamSynchronize(ctx->stream));
-    memcpy(host, pin, bytes);
-    return 0;
-}
-
 // ---- pair_all_nearby_flanks ------------------------------------------------------------------------------------------
 template <bool FILL>
 __global__ void k_pair_window(FlankDev F, int maxdr, int sorted, uint32_t *count, const uint32_t *offset, uint32_t *c5, uint32_t *c3) {
@@ -301,12 +292,12 @@ __global__ void k_final_list(const uint32_t *kept, const uint32_t *flag, const u
 // ---- get_direct_repeats ---------------------------------------------------------------------------------------------------
 #define DR_WIN 50
 // per final pair: dr_out[k*stride ...] = reference repeat, dr_out[k*stride + half ...] = reads consensus
-__global__ __launch_bounds__(256) void k_direct_repeats(DevReads R, FlankDev F, const uint32_t *fin, const uint32_t *c5, const uint32_t *c3, uint32_t n,
+__global__ __launch_bounds__(1024) void k_direct_repeats(DevReads R, FlankDev F, const uint32_t *fin, const uint32_t *c5, const uint32_t *c3, uint32_t n,
                                                         const uint8_t *genome, const int64_t *goff, char *dr_out, uint32_t stride, int32_t *dr_meta /* 3 per pair: ref_len, reads_len, err */) {
     __shared__ uint32_t sum[DR_WIN][17];
     __shared__ uint32_t firstr[DR_WIN][17];
     __shared__ uint8_t refch[DR_WIN];
-    __shared__ int64_t range[2];
+    __shared__ int64_t range[2], prange[2];
     __shared__ int err;
     const char codes[17] = "=ACMGRSVTWYHKDBN";
     uint32_t k = blockIdx.x;
@@ -331,6 +322,12 @@ __global__ __launch_bounds__(256) void k_direct_repeats(DevReads R, FlankDev F, 
     if (threadIdx.x == 0) {
         err = 0;
         if (W > 0) d_fetch_range(R, contig, (int32_t)es, (int32_t)ee, &range[0], &range[1]); else { range[0] = 0; range[1] = 0; }
+        // pooled reads of that read range: the per-read lookups below search only this slice of pool_read
+        int64_t lo = 0, hi = R.n_pool;
+        while (lo < hi) { int64_t m = (lo + hi) >> 1; if ((int64_t)R.pool_read[m] < range[0]) lo = m + 1; else hi = m; }
+        prange[0] = lo; hi = R.n_pool;
+        while (lo < hi) { int64_t m = (lo + hi) >> 1; if ((int64_t)R.pool_read[m] < range[1]) lo = m + 1; else hi = m; }
+        prange[1] = lo;
     }
     __syncthreads();
     // reads of bam.fetch(contig, expanded_start, expanded_end): no read filter here (pairflanks.py:311)
@@ -338,7 +335,8 @@ __global__ __launch_bounds__(256) void k_direct_repeats(DevReads R, FlankDev F, 
         if (!d_overlaps(R, r, (int32_t)es)) continue;
         if (R.qlen[r] == 0) continue;
         uint8_t f = R.flags[r];
-        int64_t pi = d_pool_index(R, r);
+        int64_t pi = -1;
+        { int64_t lo = prange[0], hi = prange[1]; while (lo < hi) { int64_t m = (lo + hi) >> 1; if ((int64_t)R.pool_read[m] < r) lo = m + 1; else hi = m; } if (lo < prange[1] && (int64_t)R.pool_read[lo] == r) pi = lo; }
         if (pi < 0) { err = 1; continue; }
         uint64_t o0 = R.pool_off[pi];
         DevBlocks bl = d_blocks(R, r, f);
@@ -467,9 +465,11 @@ extern "C" int mfk_pairflanks(mfk_ctx *ctx, const mfk_reads *reads, const mfk_pa
     KCHK();
     if (int rc = dev_excl_scan32(ctx, cnt, coff, nF)) return rc;
     uint32_t nP = 0;
-    if (int rc = read_back_p(ctx, coff + nF, &nP, 4)) return rc;
+    if (int rc = read_back(ctx, coff + nF, &nP, 4)) return rc;
     ctx->pstats[0] = nP;
     uint32_t nK = 0, nFin = 0;
+    uint32_t h_ps[MFK_N_STATS]; memset(h_ps, 0, sizeof h_ps);
+    bool got_stats = false;
     std::vector<uint32_t> h_fin, h_span, h_c5, h_c3; std::vector<int32_t> h_ir, h_meta; std::vector<char> h_dr; uint32_t stride = 0;
     if (nP > 0) {
         uint32_t *c5 = aalloc<uint32_t>(ctx, nP), *c3 = aalloc<uint32_t>(ctx, nP);
@@ -493,7 +493,7 @@ extern "C" int mfk_pairflanks(mfk_ctx *ctx, const mfk_reads *reads, const mfk_pa
         PROF_LAUNCH(k_kept_flags, dim3(pb), dim3(256), 0, st, (const uint8_t *)state, nP, kflag);
         KCHK();
         if (int rc = dev_excl_scan32(ctx, kflag, kscan, nP)) return rc;
-        if (int rc = read_back_p(ctx, kscan + nP, &nK, 4)) return rc;
+        if (int rc = read_back(ctx, kscan + nP, &nK, 4)) return rc;
         ctx->pstats[1] = nK;
         if (nK > 0) {
             uint64_t *kk = aalloc<uint64_t>(ctx, nK), *kk2 = aalloc<uint64_t>(ctx, nK);
@@ -509,7 +509,7 @@ extern "C" int mfk_pairflanks(mfk_ctx *ctx, const mfk_reads *reads, const mfk_pa
             PROF_LAUNCH(k_junction_filter, dim3(kb), dim3(256), 0, st, F, (const uint32_t *)kept, (const uint32_t *)c5, (const uint32_t *)c3, (const uint32_t *)spanning, (const int32_t *)ir, nK, P.maxjsp, jflag, d_pstats);
             KCHK();
             if (int rc = dev_excl_scan32(ctx, jflag, jscan, nK)) return rc;
-            if (int rc = read_back_p(ctx, jscan + nK, &nFin, 4)) return rc;
+            if (int rc = read_back(ctx, jscan + nK, &nFin, 4)) return rc;
             if (nFin > 0) {
                 uint32_t *fin = aalloc<uint32_t>(ctx, nFin), *fin_span = aalloc<uint32_t>(ctx, nFin);
                 stride = 2 * (((uint32_t)P.maxdr + 1 + 15) & ~15u);
@@ -518,26 +518,23 @@ extern "C" int mfk_pairflanks(mfk_ctx *ctx, const mfk_reads *reads, const mfk_pa
                 HIPCHK(hipMemsetAsync(dr, 0, (size_t)nFin * stride, st));
                 PROF_LAUNCH(k_final_list, dim3(kb), dim3(256), 0, st, (const uint32_t *)kept, (const uint32_t *)jflag, (const uint32_t *)jscan, (const uint32_t *)spanning, nK, fin, fin_span);
                 KCHK();
-                PROF_LAUNCH(k_direct_repeats, dim3(nFin), dim3(256), 0, st, R, F, (const uint32_t *)fin, (const uint32_t *)c5, (const uint32_t *)c3, nFin, genome, (const int64_t *)d_goff, dr, stride, meta);
+                PROF_LAUNCH(k_direct_repeats, dim3(nFin), dim3(1024), 0, st, R, F, (const uint32_t *)fin, (const uint32_t *)c5, (const uint32_t *)c3, nFin, genome, (const int64_t *)d_goff, dr, stride, meta);
                 KCHK();
                 HIPCHK(hipEventRecord(ctx->ev1, st));
                 h_fin.resize(nFin); h_span.resize(nFin); h_meta.resize(3 * (size_t)nFin); h_dr.resize((size_t)nFin * stride);
-                if (int rc = read_back_p(ctx, fin, h_fin.data(), nFin * 4)) return rc;
-                if (int rc = read_back_p(ctx, fin_span, h_span.data(), nFin * 4)) return rc;
-                if (int rc = read_back_p(ctx, meta, h_meta.data(), 3 * (size_t)nFin * 4)) return rc;
-                if (int rc = read_back_p(ctx, dr, h_dr.data(), (size_t)nFin * stride)) return rc;
+                h_c5.resize(nP); h_c3.resize(nP); h_ir.resize(6 * (size_t)nP);
+                ReadBatch rb(ctx);
+                rb.add(fin, h_fin.data(), nFin * 4); rb.add(fin_span, h_span.data(), nFin * 4);
+                rb.add(meta, h_meta.data(), 3 * (size_t)nFin * 4); rb.add(dr, h_dr.data(), (size_t)nFin * stride);
+                rb.add(c5, h_c5.data(), nP * 4); rb.add(c3, h_c3.data(), nP * 4); rb.add(ir, h_ir.data(), 6 * (size_t)nP * 4);
+                rb.add(d_pstats, h_ps, sizeof h_ps);
+                if (int rc = rb.flush()) return rc;
+                got_stats = true;
             }
-        }
-        if (nFin > 0) {
-            h_c5.resize(nP); h_c3.resize(nP); h_ir.resize(6 * (size_t)nP);
-            if (int rc = read_back_p(ctx, c5, h_c5.data(), nP * 4)) return rc;
-            if (int rc = read_back_p(ctx, c3, h_c3.data(), nP * 4)) return rc;
-            if (int rc = read_back_p(ctx, ir, h_ir.data(), 6 * (size_t)nP * 4)) return rc;
         }
     }
     if (nFin == 0) HIPCHK(hipEventRecord(ctx->ev1, st));
-    uint32_t h_ps[MFK_N_STATS];
-    if (int rc = read_back_p(ctx, d_pstats, h_ps, sizeof h_ps)) return rc;
+    if (!got_stats) if (int rc = read_back(ctx, d_pstats, h_ps, sizeof h_ps)) return rc;
     ctx->pstats[2] = h_ps[2]; ctx->pstats[3] = h_ps[3]; ctx->pstats[4] = nFin;
     prof_collect(ctx);
     float ms = 0.f;
