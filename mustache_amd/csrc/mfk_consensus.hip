@@ -53,6 +53,7 @@ struct Jobs {
     uint32_t *adj;
     uint32_t *best;                   // best representative slot or 0xFFFFFFFF
     uint32_t *giant;                  // label of the largest component found by the pivot pass
+    uint32_t *longest;                // N_LONGEST longest words of the job (local indices)
 };
 
 __device__ __forceinline__ int d_lcp(const uint8_t *a, int la, const uint8_t *b, int lb) {
@@ -210,6 +211,35 @@ __global__ __launch_bounds__(256) void k_word_fill(DevReads R, Words W, CMeta *m
 }
 
 // ---- leaves -------------------------------------------------------------------------------------------------------
+// one block per job: its N_LONGEST longest words (ties: first).  A word without sequencing errors is a prefix of them,
+// so testing these first settles most words in k_leaf_flags without the all-pairs scan.
+#define N_LONGEST 4
+__global__ __launch_bounds__(256) void k_job_longest(Words W, Jobs J) {
+    __shared__ unsigned long long best;
+    uint32_t job = blockIdx.x;
+    if (job >= J.n) return;
+    uint32_t w0 = J.w0[job], R = J.R[job];
+    unsigned long long prev = ~0ull;
+    for (int k = 0; k < N_LONGEST; k++) {
+        if (threadIdx.x == 0) best = 0;
+        __syncthreads();
+        unsigned long long mine = 0;
+        for (uint32_t i = threadIdx.x; i < R; i += blockDim.x) {
+            unsigned long long key = ((unsigned long long)W.len[w0 + i] << 32) | (unsigned long long)(0xFFFFFFFFu - i);
+            if (key < prev && key > mine) mine = key;
+        }
+        for (int o = 32; o > 0; o >>= 1) {
+            unsigned long long other = ((unsigned long long)__shfl_xor((unsigned)(mine >> 32), o, 64) << 32) | (unsigned long long)__shfl_xor((unsigned)mine, o, 64);
+            if (other > mine) mine = other;
+        }
+        if ((threadIdx.x & 63) == 0 && mine) atomicMax(&best, mine);
+        __syncthreads();
+        prev = best;
+        if (threadIdx.x == 0) J.longest[job * N_LONGEST + k] = best ? 0xFFFFFFFFu - (uint32_t)(best & 0xFFFFFFFFull) : 0xFFFFFFFFu;
+        __syncthreads();
+    }
+}
+
 // one wave per word i: is some other word an extension of it (or an earlier copy)?
 __global__ __launch_bounds__(256) void k_leaf_flags(Words W, Jobs J) {
     uint32_t w = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -219,6 +249,15 @@ __global__ __launch_bounds__(256) void k_leaf_flags(Words W, Jobs J) {
     const uint8_t *a = W.ch + W.off[w];
     int la = (int)W.len[w];
     bool covered = false;
+    if (lane < N_LONGEST) {
+        uint32_t j = J.longest[job * N_LONGEST + lane];
+        if (j != 0xFFFFFFFFu) {
+            uint32_t v = w0 + j;
+            int lb = (int)W.len[v];
+            if (v != w && lb >= la && d_lcp(a, la, W.ch + W.off[v], lb) >= la && (lb > la || v < w)) covered = true;
+        }
+    }
+    if (__ballot(covered)) { if (lane == 0) W.is_leaf[w] = 0; return; }
     for (uint32_t j = lane; j < R && !covered; j += 64) {
         uint32_t v = w0 + j;
         if (v == w) continue;
@@ -249,7 +288,7 @@ __global__ __launch_bounds__(256) void k_leaf_compact(Words W, Jobs J) {
 }
 
 // one wave per leaf slot: t(a[:d+1]) = first word sharing d+1 characters with the leaf, for every depth d
-__global__ __launch_bounds__(64) void k_leaf_first(Words W, Jobs J) {
+__global__ __launch_bounds__(64) void k_leaf_first(Words W, Jobs J, uint16_t *lcpm) {
     __shared__ uint32_t tmin[MAX_WORD_LEN];
     uint32_t slot = blockIdx.x;
     int lane = threadIdx.x;
@@ -262,9 +301,11 @@ __global__ __launch_bounds__(64) void k_leaf_first(Words W, Jobs J) {
     int la = (int)W.len[wa];
     for (int d = lane; d < la; d += 64) tmin[d] = 0xFFFFFFFFu;
     __syncthreads();
+    uint16_t *mrow = lcpm + J.adj_off[job] * 32 + (size_t)k * ((R + 31) >> 5) * 32;   // LCP(leaf, word j), reused by k_reach
     for (uint32_t j = lane; j < R; j += 64) {
         uint32_t v = w0 + j;
         int l = d_lcp(a, la, W.ch + W.off[v], (int)W.len[v]);
+        mrow[j] = (uint16_t)l;
         if (l > 0) atomicMin(&tmin[l - 1], j);
     }
     __syncthreads();
@@ -481,32 +522,32 @@ __global__ __launch_bounds__(256) void k_reach_init(Words W, Jobs J, uint32_t *r
 }
 
 // one wave per leaf: reach_C(j) = max over the leaves l of cluster C of LCP(word j, l)
-__global__ __launch_bounds__(256) void k_reach(Words W, Jobs J, uint32_t *reach) {
+__global__ __launch_bounds__(256) void k_reach(Words W, Jobs J, uint32_t *reach, const uint16_t *lcpm) {
     uint32_t slot = blockIdx.x * 4 + (threadIdx.x >> 6);
     int lane = threadIdx.x & 63;
     if (slot >= W.n) return;
     uint32_t job = W.job[slot], w0 = J.w0[job], R = J.R[job], kl = slot - w0;
     if (kl >= J.nl[job]) return;
     uint32_t *row = d_reach_row(J, reach, job, W.label[slot]);
-    uint32_t wl = w0 + W.leaf_word[slot];
-    const uint8_t *l = W.ch + W.off[wl];
-    const int ll = (int)W.len[wl];
+    const uint16_t *mrow = lcpm + J.adj_off[job] * 32 + (size_t)kl * ((R + 31) >> 5) * 32;
     for (uint32_t j = lane; j < R; j += 64) {
-        uint32_t v = w0 + j;
-        int c = d_lcp(l, ll, W.ch + W.off[v], (int)W.len[v]);
-        if (c > 0) atomicMax(&row[j], (uint32_t)c);
+        uint32_t c = mrow[j];
+        if (c > 0) atomicMax(&row[j], c);
     }
 }
 
 // one block per representative leaf slot: column vote (make_consensus_word flanktrie.py:306-342), merged count
 // (make_subtrie 89-118) and the cluster's place in the reference's list order.
 // dynamic LDS: hq[max_len*16] (u32) | hc[max_len*16] (u32)
-__global__ __launch_bounds__(256) void k_cluster_vote(DevParams P, Words W, Jobs J, const uint32_t *reach, uint32_t max_len, char *cl_chars, uint32_t cl_stride) {
+#define VOTE_CHUNK 1024
+__global__ __launch_bounds__(512) void k_cluster_vote(DevParams P, Words W, Jobs J, const uint32_t *reach, uint32_t max_len, char *cl_chars, uint32_t cl_stride) {
     extern __shared__ __align__(16) unsigned char smem[];
     uint32_t *hq = reinterpret_cast<uint32_t *>(smem);
     uint32_t *hc = hq + (size_t)max_len * 16;
     __shared__ int s_maxd, s_stop;
     __shared__ uint32_t s_minrank, s_words;
+    __shared__ uint32_t m_rc[VOTE_CHUNK];
+    __shared__ uint64_t m_off[VOTE_CHUNK];
     const uint32_t slot = blockIdx.x;
     if (slot >= W.n) return;
     const uint32_t job = W.job[slot], w0 = J.w0[job], R = J.R[job], nl = J.nl[job], ka = slot - w0;
@@ -522,19 +563,34 @@ __global__ __launch_bounds__(256) void k_cluster_vote(DevParams P, Words W, Jobs
     }
     const uint32_t *row = reach + J.adj_off[job] * 32 + (size_t)ka * ((R + 31) >> 5) * 32;
     uint32_t words = 0;
-    for (uint32_t j = threadIdx.x; j < R; j += blockDim.x) {
-        const uint32_t v = w0 + j;
-        const int rc = (int)row[j], lj = (int)W.len[v];
-        if (rc == lj) words++;                       // the word is a prefix of a leaf of the cluster
-        if (rc == 0) continue;
-        const uint8_t *c = W.ch + W.off[v], *q = W.q + W.off[v];
-        int d = (int)((threadIdx.x * 7u) % (uint32_t)rc);   // staggered start: spreads the LDS atomics over the columns
-        for (int i = 0; i < rc; i++) {
-            uint32_t code = c[d] & 15;
-            atomicAdd(&hq[d * 16 + code], (uint32_t)q[d]);
-            atomicAdd(&hc[d * 16 + code], 1u);
-            if (++d == rc) d = 0;
+    // threads = (group g, depth d): a group walks one word at a time with its lanes on consecutive characters (coalesced
+    // byte loads), so the LDS atomics of a wave go to different columns; word metadata is staged in LDS per chunk
+    const uint32_t pad = (max_len + 63) & ~63u;
+    const uint32_t G = blockDim.x / pad ? blockDim.x / pad : 1;
+    const uint32_t g = threadIdx.x / pad, d = threadIdx.x % pad;
+    for (uint32_t j0 = 0; j0 < R; j0 += VOTE_CHUNK) {
+        const uint32_t nchunk = R - j0 < VOTE_CHUNK ? R - j0 : VOTE_CHUNK;
+        __syncthreads();
+        for (uint32_t t = threadIdx.x; t < nchunk; t += blockDim.x) {
+            const uint32_t v = w0 + j0 + t;
+            const uint32_t rc = row[j0 + t];
+            if (rc == W.len[v]) words++;                 // the word is a prefix of a leaf of the cluster
+            m_rc[t] = rc; m_off[t] = W.off[v];
         }
+        __syncthreads();
+        if (g < G)
+            for (uint32_t t = g; t < nchunk; t += 4 * G) {   // four words in flight per thread: the byte loads overlap
+                uint32_t code[4], qv[4]; bool on[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const uint32_t tt = t + u * G;
+                    on[u] = tt < nchunk && d < m_rc[tt];
+                    if (on[u]) { const uint64_t o = m_off[tt] + d; code[u] = W.ch[o] & 15; qv[u] = W.q[o]; }
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++)
+                    if (on[u]) { atomicAdd(&hq[d * 16 + code[u]], qv[u]); atomicAdd(&hc[d * 16 + code[u]], 1u); }
+            }
     }
     if (words) atomicAdd(&s_words, words);
     __syncthreads();
@@ -630,8 +686,8 @@ int run_consensus(mfk_ctx *ctx, const DevReads &R, const DevParams &P, Consensus
     Jobs J; memset(&J, 0, sizeof J);
     J.n = 2 * n_act;
     J.w0 = aalloc<uint32_t>(ctx, J.n); J.R = aalloc<uint32_t>(ctx, J.n); J.nl = aalloc<uint32_t>(ctx, J.n);
-    J.adj_words = aalloc<uint32_t>(ctx, J.n); J.adj_off = aalloc<uint64_t>(ctx, (size_t)J.n + 1); J.best = aalloc<uint32_t>(ctx, J.n); J.giant = aalloc<uint32_t>(ctx, J.n);
-    if (!J.w0 || !J.R || !J.nl || !J.adj_words || !J.adj_off || !J.best || !J.giant) return 1;
+    J.adj_words = aalloc<uint32_t>(ctx, J.n); J.adj_off = aalloc<uint64_t>(ctx, (size_t)J.n + 1); J.best = aalloc<uint32_t>(ctx, J.n); J.giant = aalloc<uint32_t>(ctx, J.n); J.longest = aalloc<uint32_t>(ctx, 4 * (size_t)J.n);
+    if (!J.w0 || !J.R || !J.nl || !J.adj_words || !J.adj_off || !J.best || !J.giant || !J.longest) return 1;
     PROF_LAUNCH(k_job_meta, dim3(nblocks(J.n, 256)), dim3(256), 0, st, io, (const uint32_t *)wid, J, meta);
     KCHK();
     if (int rc = dev_excl_scan64(ctx, J.adj_words, J.adj_off, J.n)) return rc;
@@ -668,11 +724,15 @@ int run_consensus(mfk_ctx *ctx, const DevReads &R, const DevParams &P, Consensus
     if (!W.ch || !W.q || !W.t) return 1;
     PROF_LAUNCH(k_word_fill, dim3(ww), dim3(256), 0, st, R, W, meta);
     KCHK();
+    PROF_LAUNCH(k_job_longest, dim3(J.n), dim3(256), 0, st, W, J);
+    KCHK();
     PROF_LAUNCH(k_leaf_flags, dim3(ww), dim3(256), 0, st, W, J);
     KCHK();
     PROF_LAUNCH(k_leaf_compact, dim3(J.n), dim3(256), 0, st, W, J);
     KCHK();
-    PROF_LAUNCH(k_leaf_first, dim3(Wn), dim3(64), 0, st, W, J);
+    uint16_t *lcpm = aalloc<uint16_t>(ctx, (size_t)adj_total * 32);
+    if (!lcpm) return 1;
+    PROF_LAUNCH(k_leaf_first, dim3(Wn), dim3(64), 0, st, W, J, lcpm);
     KCHK();
     PROF_LAUNCH(k_leaf_rank, dim3(Wn), dim3(256), 0, st, W, J);
     KCHK();
@@ -694,9 +754,9 @@ int run_consensus(mfk_ctx *ctx, const DevReads &R, const DevParams &P, Consensus
     if (!io.cons_chars || !cl_chars || !reach) return 1;
     PROF_LAUNCH(k_reach_init, dim3(Wn), dim3(256), 0, st, W, J, reach);
     KCHK();
-    PROF_LAUNCH(k_reach, dim3(ww), dim3(256), 0, st, W, J, reach);
+    PROF_LAUNCH(k_reach, dim3(ww), dim3(256), 0, st, W, J, reach, (const uint16_t *)lcpm);
     KCHK();
-    PROF_LAUNCH(k_cluster_vote, dim3(Wn), dim3(256), lds, st, P, W, J, (const uint32_t *)reach, max_len, cl_chars, io.cons_stride);
+    PROF_LAUNCH(k_cluster_vote, dim3(Wn), dim3(512), lds, st, P, W, J, (const uint32_t *)reach, max_len, cl_chars, io.cons_stride);
     KCHK();
     PROF_LAUNCH(k_job_best, dim3(nblocks(J.n, 256)), dim3(256), 0, st, P, W, J, io);
     KCHK();

@@ -291,6 +291,7 @@ __global__ void k_final_list(const uint32_t *kept, const uint32_t *flag, const u
 
 // ---- get_direct_repeats ---------------------------------------------------------------------------------------------------
 #define DR_WIN 50
+#define DR_SEGS 1536
 // per final pair: dr_out[k*stride ...] = reference repeat, dr_out[k*stride + half ...] = reads consensus
 __global__ __launch_bounds__(1024) void k_direct_repeats(DevReads R, FlankDev F, const uint32_t *fin, const uint32_t *c5, const uint32_t *c3, uint32_t n,
                                                         const uint8_t *genome, const int64_t *goff, char *dr_out, uint32_t stride, int32_t *dr_meta /* 3 per pair: ref_len, reads_len, err */) {
@@ -299,6 +300,9 @@ __global__ __launch_bounds__(1024) void k_direct_repeats(DevReads R, FlankDev F,
     __shared__ uint8_t refch[DR_WIN];
     __shared__ int64_t range[2], prange[2];
     __shared__ int err;
+    __shared__ uint64_t seg_q[DR_SEGS];
+    __shared__ int32_t seg_lo[DR_SEGS], seg_hi[DR_SEGS];
+    __shared__ uint32_t seg_r[DR_SEGS], nseg;
     const char codes[17] = "=ACMGRSVTWYHKDBN";
     uint32_t k = blockIdx.x;
     if (k >= n) return;
@@ -330,31 +334,66 @@ __global__ __launch_bounds__(1024) void k_direct_repeats(DevReads R, FlankDev F,
         prange[1] = lo;
     }
     __syncthreads();
-    // reads of bam.fetch(contig, expanded_start, expanded_end): no read filter here (pairflanks.py:311)
-    for (int64_t r = range[0] + threadIdx.x; r < range[1]; r += blockDim.x) {
-        if (!d_overlaps(R, r, (int32_t)es)) continue;
-        if (R.qlen[r] == 0) continue;
-        uint8_t f = R.flags[r];
-        int64_t pi = -1;
-        { int64_t lo = prange[0], hi = prange[1]; while (lo < hi) { int64_t m = (lo + hi) >> 1; if ((int64_t)R.pool_read[m] < r) lo = m + 1; else hi = m; } if (lo < prange[1] && (int64_t)R.pool_read[lo] == r) pi = lo; }
-        if (pi < 0) { err = 1; continue; }
-        uint64_t o0 = R.pool_off[pi];
-        DevBlocks bl = d_blocks(R, r, f);
-        int64_t qpos = d_lkind(f) == 1 ? R.first_op_len[r] : 0;
-        for (int bi = 0; bi < bl.n; bi++) {
-            qpos += bl.bi(bi);
-            int32_t bs = bl.bs(bi), be = bl.be(bi);
-            int32_t lo = bs > (int32_t)es ? bs : (int32_t)es, hi = be < (int32_t)ee ? be : (int32_t)ee;
-            for (int32_t rp = lo; rp < hi; rp++) {
-                uint64_t qi = o0 + (uint64_t)(qpos + (rp - bs));
-                uint32_t code = d_pool_base(R, qi);
-                atomicAdd(&sum[rp - es][code], (uint32_t)R.pool_quals[qi]);
-                atomicMin(&firstr[rp - es][code], (uint32_t)r);
+    // reads of bam.fetch(contig, expanded_start, expanded_end): no read filter here (pairflanks.py:311).
+    // Two phases per chunk of reads so that the LDS atomics of one wave instruction go to 50 different columns instead
+    // of 64 reads hammering the same column: (1) one thread per read resolves its pool offset and aligned blocks into
+    // window-clipped segments in LDS; (2) one wave per segment, lane = window position.
+    for (int64_t rbase = range[0]; rbase < range[1]; rbase += blockDim.x) {
+        if (threadIdx.x == 0) nseg = 0;
+        __syncthreads();
+        const int64_t r = rbase + threadIdx.x;
+        if (r < range[1] && d_overlaps(R, r, (int32_t)es) && R.qlen[r] != 0) {
+            const uint8_t f = R.flags[r];
+            int64_t pi = -1;
+            { int64_t lo = prange[0], hi = prange[1]; while (lo < hi) { int64_t m = (lo + hi) >> 1; if ((int64_t)R.pool_read[m] < r) lo = m + 1; else hi = m; } if (lo < prange[1] && (int64_t)R.pool_read[lo] == r) pi = lo; }
+            if (pi < 0) err = 1;
+            else {
+                const uint64_t o0 = R.pool_off[pi];
+                DevBlocks bl = d_blocks(R, r, f);
+                int64_t qpos = d_lkind(f) == 1 ? R.first_op_len[r] : 0;
+                for (int bi = 0; bi < bl.n; bi++) {
+                    qpos += bl.bi(bi);
+                    const int32_t bs = bl.bs(bi), be = bl.be(bi);
+                    const int32_t lo = bs > (int32_t)es ? bs : (int32_t)es, hi = be < (int32_t)ee ? be : (int32_t)ee;
+                    if (lo < hi) {
+                        const uint64_t q0 = o0 + (uint64_t)(qpos + (lo - bs));
+                        uint32_t slot = atomicAdd(&nseg, 1u);
+                        if (slot < DR_SEGS) { seg_q[slot] = q0; seg_lo[slot] = lo; seg_hi[slot] = hi; seg_r[slot] = (uint32_t)r; }
+                        else for (int32_t rp = lo; rp < hi; rp++) {   // segment list full: add it here (slow, rare)
+                            const uint64_t qi = q0 + (uint64_t)(rp - lo);
+                            const uint32_t code = d_pool_base(R, qi);
+                            atomicAdd(&sum[rp - es][code], (uint32_t)R.pool_quals[qi]);
+                            atomicMin(&firstr[rp - es][code], (uint32_t)r);
+                        }
+                    }
+                    qpos += be - bs;
+                }
             }
-            qpos += be - bs;
         }
+        __syncthreads();
+        const uint32_t ns = nseg < DR_SEGS ? nseg : DR_SEGS;
+        const int lane = threadIdx.x & 63;
+        const uint32_t nw = blockDim.x >> 6;
+        for (uint32_t sgi = threadIdx.x >> 6; sgi < ns; sgi += 4 * nw) {   // four segments in flight per wave
+            uint32_t code[4], qv[4], rr[4]; int col[4]; bool on[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const uint32_t sg = sgi + u * nw;
+                on[u] = false;
+                if (sg < ns) {
+                    const int32_t rp = seg_lo[sg] + lane;
+                    if (rp < seg_hi[sg]) {
+                        const uint64_t qi = seg_q[sg] + (uint64_t)lane;
+                        code[u] = d_pool_base(R, qi); qv[u] = R.pool_quals[qi]; rr[u] = seg_r[sg]; col[u] = (int)(rp - es); on[u] = true;
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+                if (on[u]) { atomicAdd(&sum[col[u]][code[u]], qv[u]); atomicMin(&firstr[col[u]][code[u]], rr[u]); }
+        }
+        __syncthreads();
     }
-    __syncthreads();
     int32_t *meta = dr_meta + 3 * (size_t)k;
     char *out_ref = dr_out + (size_t)k * stride, *out_reads = out_ref + stride / 2;
     // get_reference_direct_repeats pairflanks.py:356-367: genome[start+1:end] with Python slice clamping
