@@ -8,10 +8,12 @@
 //                 t(p) = index of the first word with prefix p
 //   clusters    = leaf pairs with levenshtein(prefixes of the shorter length) d, 4*d <= m  (== 1 - d/m >= 0.75 in
 //                 float64, tests/test_oracle_golden.py) -> connected components; unmatched leaves are singletons
-//   consensus   = column vote over every word j with reach_C(j) = max over leaves l of C of LCP(j, l): at depth d the
-//                 voters are the words with reach > d; stop when fewer than mcc voters; per-base sum of qualities,
-//                 unique maximum wins, tie -> 'N'                                       (make_consensus_word 306-342)
-//   count       = #words with reach == len(word)                                        (make_subtrie 89-118)
+//   node sums   = the trie node of prefix p is named by (t(p), len(p)-1), i.e. by a character position of its first word:
+//                 every word adds its quality / a counter / an end-of-word counter at the nodes along its path
+//   consensus   = column vote over the sub-trie of the cluster's leaves: at depth d the voters are the distinct nodes of
+//                 depth d on the paths to those leaves, each with its quality sum and counter; stop when fewer than mcc
+//                 voters; per-base sum of qualities, unique maximum wins, tie -> 'N' (make_consensus_word 306-342)
+//   count       = #words that end on a node of that sub-trie                            (make_subtrie 89-118)
 //
 // All pairwise work (LCP, bit-parallel Myers edit distance) is spread over the whole GPU; words live in an 8-byte
 // aligned byte pool so LCPs are 64-bit XOR + count-trailing-zeros.
@@ -26,16 +28,21 @@ struct CMeta {          // small device struct the host reads back once
     uint32_t err, max_len, max_R, pad;
 };
 
+struct NodeSum { uint32_t q, c, e; };   // quality sum, #words through the node, #words ending on it
+
 struct Words {
     uint32_t n;                       // number of words (active jobs only)
     int32_t *first, *second;          // reads
     uint32_t *nextra;                 // reads beyond the first with that name
     uint32_t *job;                    // job = 2*k + side
     uint32_t *len;                    // word length
-    uint32_t *plen;                   // padded to a multiple of 8
-    uint64_t *off;                    // byte offset into ch / q (multiple of 8)
+    uint32_t *plen;                   // padded to a multiple of 16
+    uint64_t *off;                    // byte offset into ch / q (multiple of 16)
     uint8_t *ch, *q;                  // characters (4-bit codes, one per byte) and qualities
-    uint32_t *t;                      // per character of a leaf: t(a[:d+1])
+    uint32_t *npos;                   // per character d of a leaf a: its trie node = position of character d of word t(a[:d+1])
+    uint32_t *cover;                  // per word: a leaf (local leaf index) the word is a prefix of
+    NodeSum *agg;                     // per character position = trie node
+    uint32_t *share;                  // per leaf slot: longest prefix shared with an earlier leaf of its cluster
     uint8_t *is_leaf;
     uint32_t *leaf_word;              // slot w0+k -> local word index of the k-th leaf (word order)
     uint32_t *leaf_rank;              // DFS rank of the leaf in slot
@@ -43,6 +50,9 @@ struct Words {
     uint8_t *has_match;
     int32_t *cl_count, *cl_len;       // per representative slot
     uint32_t *cl_key;                 // (is_component << 31) | min DFS rank
+    // device-side work lists (order arbitrary): the kernels that work per leaf / per cluster run a fixed grid over them
+    uint32_t *leaf_list, *rep_list;   // slots of the leaves / of the cluster representatives
+    uint32_t *n_list;                 // [0] = number of leaves, [1] = number of representatives
 };
 
 struct Jobs {
@@ -56,11 +66,20 @@ struct Jobs {
     uint32_t *longest;                // N_LONGEST longest words of the job (local indices)
 };
 
+// longest common prefix, 32 bytes per step (words start on 16-byte boundaries and the pool has 64 bytes of slack, so
+// reading past a word is harmless: the result is clamped to the shorter length)
 __device__ __forceinline__ int d_lcp(const uint8_t *a, int la, const uint8_t *b, int lb) {
-    int m = la < lb ? la : lb;
-    for (int o = 0; o < m; o += 8) {
-        uint64_t x = *reinterpret_cast<const uint64_t *>(a + o) ^ *reinterpret_cast<const uint64_t *>(b + o);
-        if (x) { int k = o + (__builtin_ctzll(x) >> 3); return k < m ? k : m; }
+    const int m = la < lb ? la : lb;
+    for (int o = 0; o < m; o += 32) {
+        const uint4 a0 = *reinterpret_cast<const uint4 *>(a + o), a1 = *reinterpret_cast<const uint4 *>(a + o + 16);
+        const uint4 b0 = *reinterpret_cast<const uint4 *>(b + o), b1 = *reinterpret_cast<const uint4 *>(b + o + 16);
+        const uint32_t x[8] = {a0.x ^ b0.x, a0.y ^ b0.y, a0.z ^ b0.z, a0.w ^ b0.w, a1.x ^ b1.x, a1.y ^ b1.y, a1.z ^ b1.z, a1.w ^ b1.w};
+        if (x[0] | x[1] | x[2] | x[3] | x[4] | x[5] | x[6] | x[7]) {
+            int k = m;
+#pragma unroll
+            for (int i = 7; i >= 0; i--) if (x[i]) k = o + 4 * i + (__builtin_ctz(x[i]) >> 3);
+            return k < m ? k : m;
+        }
     }
     return m;
 }
@@ -161,7 +180,7 @@ __global__ void k_word_len(DevReads R, Words W, CMeta *meta) {
     if (r2 >= 0) { uint8_t f2 = R.flags[r2]; int l2 = side == 0 ? d_rlen(R, r2, f2) : d_llen(R, r2, f2); if (l2 > len) len = l2; }
     if (len > MAX_WORD_LEN) { atomicOr(&meta->err, ERR_WORD_TOO_LONG); len = MAX_WORD_LEN; }
     W.len[w] = (uint32_t)len;
-    W.plen[w] = (uint32_t)((len + 7) & ~7);
+    W.plen[w] = (uint32_t)((len + 15) & ~15);
     atomicMax(&meta->max_len, (uint32_t)len);
 }
 
@@ -181,13 +200,13 @@ __global__ __launch_bounds__(256) void k_word_fill(DevReads R, Words W, CMeta *m
     int64_t r1 = W.first[w], r2 = W.second[w];
     uint8_t f1 = R.flags[r1];
     int l1 = side == 0 ? d_rlen(R, r1, f1) : d_llen(R, r1, f1), l2 = 0;
-    int64_t p1 = d_pool_index(R, r1), p2 = -1;
+    int64_t p1 = d_pool_index_wave(R, r1), p2 = -1;
     uint64_t o1 = p1 >= 0 ? R.pool_off[p1] : 0, o2 = 0;
     int q1len = R.qlen[r1], q2len = 0;
     if (r2 >= 0) {
         uint8_t f2 = R.flags[r2];
         l2 = side == 0 ? d_rlen(R, r2, f2) : d_llen(R, r2, f2);
-        p2 = d_pool_index(R, r2);
+        p2 = d_pool_index_wave(R, r2);
         o2 = p2 >= 0 ? R.pool_off[p2] : 0;
         q2len = R.qlen[r2];
     }
@@ -284,18 +303,22 @@ __global__ __launch_bounds__(256) void k_leaf_compact(Words W, Jobs J) {
         if (f) { W.leaf_word[w0 + running + off] = i; W.label[w0 + running + off] = running + off; }
         running += tot;
     }
-    if (threadIdx.x == 0) J.nl[job] = running;
+    __shared__ uint32_t s_base;
+    if (threadIdx.x == 0) { J.nl[job] = running; s_base = atomicAdd(&W.n_list[0], running); }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < running; i += blockDim.x) W.leaf_list[s_base + i] = w0 + i;
 }
 
 // one wave per leaf slot: t(a[:d+1]) = first word sharing d+1 characters with the leaf, for every depth d
 __global__ __launch_bounds__(64) void k_leaf_first(Words W, Jobs J, uint16_t *lcpm) {
     __shared__ uint32_t tmin[MAX_WORD_LEN];
-    uint32_t slot = blockIdx.x;
-    int lane = threadIdx.x;
-    if (slot >= W.n) return;
+    const int lane = threadIdx.x;
+    const uint32_t n_leaf = W.n_list[0];
+    for (uint32_t it = blockIdx.x; it < n_leaf; it += gridDim.x) {
+    __syncthreads();
+    uint32_t slot = W.leaf_list[it];
     uint32_t job = W.job[slot], w0 = J.w0[job], R = J.R[job];
     uint32_t k = slot - w0;
-    if (k >= J.nl[job]) return;
     uint32_t wa = w0 + W.leaf_word[slot];
     const uint8_t *a = W.ch + W.off[wa];
     int la = (int)W.len[wa];
@@ -304,15 +327,27 @@ __global__ __launch_bounds__(64) void k_leaf_first(Words W, Jobs J, uint16_t *lc
     uint16_t *mrow = lcpm + J.adj_off[job] * 32 + (size_t)k * ((R + 31) >> 5) * 32;   // LCP(leaf, word j), reused by k_reach
     for (uint32_t j = lane; j < R; j += 64) {
         uint32_t v = w0 + j;
-        int l = d_lcp(a, la, W.ch + W.off[v], (int)W.len[v]);
+        const int lv = (int)W.len[v];
+        int l = d_lcp(a, la, W.ch + W.off[v], lv);
         mrow[j] = (uint16_t)l;
         if (l > 0) atomicMin(&tmin[l - 1], j);
+        if (l == lv) atomicMin(&W.cover[v], k);   // word v is a prefix of this leaf
     }
     __syncthreads();
-    if (lane == 0) {   // suffix minimum over depth
-        uint32_t m = 0xFFFFFFFFu;
-        uint32_t *t = W.t + W.off[wa];
-        for (int d = la - 1; d >= 0; d--) { uint32_t v = tmin[d]; if (v < m) m = v; t[d] = m; }
+    // suffix minimum over depth: lane owns `per` consecutive depths, then a wave-wide suffix scan of the lane minima
+    const int per = (la + 63) >> 6, d0 = lane * per;
+    uint32_t mine = 0xFFFFFFFFu;
+    for (int d = d0 + per - 1; d >= d0; d--) if (d < la) { uint32_t v = tmin[d]; if (v < mine) mine = v; }
+    uint32_t suf = mine;   // inclusive suffix minimum over lanes >= lane
+    for (int o = 1; o < 64; o <<= 1) { uint32_t other = __shfl_down(suf, o, 64); if (lane + o < 64 && other < suf) suf = other; }
+    uint32_t after = __shfl_down(suf, 1, 64);   // minimum over the lanes behind
+    if (lane == 63) after = 0xFFFFFFFFu;
+    uint32_t *np = W.npos + W.off[wa];
+    uint32_t m = after;
+    for (int d = d0 + per - 1; d >= d0; d--) if (d < la) {
+        uint32_t v = tmin[d]; if (v < m) m = v;
+        np[d] = (uint32_t)(W.off[w0 + m] + (uint64_t)d);   // node of a[:d+1] = character d of the first word with that prefix
+    }
     }
 }
 
@@ -367,15 +402,16 @@ __device__ __forceinline__ int d_myers(const uint64_t (&plane)[4][NL], const uin
 // DFS order of the leaves (traverse_seqs, flanktrie.py:157-170): at the first differing depth the branch whose first word
 // came earlier is visited first.  One block per leaf slot a, threads over the later leaves b; rank = #leaves before.
 __global__ __launch_bounds__(256) void k_leaf_rank(Words W, Jobs J) {
-    uint32_t slot = blockIdx.x;
-    if (slot >= W.n) return;
+    const uint32_t n_leaf = W.n_list[0];
+    for (uint32_t it = blockIdx.x; it < n_leaf; it += gridDim.x) {
+    uint32_t slot = W.leaf_list[it];
     uint32_t job = W.job[slot], w0 = J.w0[job], nl = J.nl[job];
     uint32_t ka = slot - w0;
-    if (ka + 1 >= nl) return;
+    if (ka + 1 >= nl) continue;
     uint32_t wa = w0 + W.leaf_word[slot];
     const uint8_t *a = W.ch + W.off[wa];
     const int la = (int)W.len[wa];
-    const uint32_t *ta = W.t + W.off[wa];
+    const uint32_t *ta = W.npos + W.off[wa];
     uint32_t rank_a = 0;
     for (uint32_t kb = ka + 1 + threadIdx.x; kb < nl; kb += blockDim.x) {
         uint32_t wb = w0 + W.leaf_word[w0 + kb];
@@ -383,11 +419,12 @@ __global__ __launch_bounds__(256) void k_leaf_rank(Words W, Jobs J) {
         const int m = la < lb ? la : lb;
         int k = d_lcp(a, la, W.ch + W.off[wb], lb);
         if (k < m) {
-            uint32_t tav = ta[k], tbv = W.t[W.off[wb] + k];
+            uint32_t tav = ta[k], tbv = W.npos[W.off[wb] + k];   // same depth: positions order like first-word indices
             if (tav < tbv) atomicAdd(&W.leaf_rank[w0 + kb], 1u); else rank_a++;
         }
     }
     if (rank_a) atomicAdd(&W.leaf_rank[slot], rank_a);
+    }
 }
 
 __device__ __forceinline__ int d_myers_any(const uint64_t (*sh_plane)[8], int need, const uint8_t *text, int m) {
@@ -415,19 +452,22 @@ __device__ __forceinline__ int d_myers_any(const uint64_t (*sh_plane)[8], int ne
 // One block per leaf slot a (the bit-vector pattern), threads over the partners.
 __global__ __launch_bounds__(256) void k_leaf_myers(Words W, Jobs J, int mode) {
     __shared__ uint64_t sh_plane[4][8];
-    uint32_t slot = blockIdx.x;
-    if (slot >= W.n) return;
-    uint32_t job = W.job[slot], w0 = J.w0[job], R = J.R[job], nl = J.nl[job];
-    uint32_t ka = slot - w0;
-    if (ka >= nl || nl < 2) return;
+    // work items: mode 0 = (job, pivot) pairs, mode 1 = the leaf list
+    const uint32_t n_items = mode == 0 ? J.n * N_PIVOTS : W.n_list[0];
+    for (uint32_t it = blockIdx.x; it < n_items; it += gridDim.x) {
+    __syncthreads();
+    uint32_t job, ka, slot;
+    if (mode == 0) { job = it / N_PIVOTS; ka = it % N_PIVOTS; slot = J.w0[job] + ka; }
+    else { slot = W.leaf_list[it]; job = W.job[slot]; ka = slot - J.w0[job]; }
+    uint32_t w0 = J.w0[job], R = J.R[job], nl = J.nl[job];
+    if (ka >= nl || nl < 2) continue;
     uint32_t my_label = 0, giant = 0;
-    if (mode == 0) { if (ka >= N_PIVOTS) return; }
-    else { my_label = W.label[slot]; giant = J.giant[job]; if (my_label == giant) return; }
+    if (mode == 1) { my_label = W.label[slot]; giant = J.giant[job]; if (my_label == giant) continue; }
     uint32_t wa = w0 + W.leaf_word[slot];
     const uint8_t *a = W.ch + W.off[wa];
     const int la = (int)W.len[wa];
     const int need = (la + 63) >> 6;
-    if (need > 8) return;   // cannot happen: words are capped at MAX_WORD_LEN
+    if (need > 8) continue;   // cannot happen: words are capped at MAX_WORD_LEN
     if (threadIdx.x < 32) {
         int p = threadIdx.x >> 3, i = threadIdx.x & 7;
         uint64_t v = 0;
@@ -453,10 +493,11 @@ __global__ __launch_bounds__(256) void k_leaf_myers(Words W, Jobs J, int mode) {
             atomicOr(&adj[(size_t)kb * rw + (ka >> 5)], 1u << (ka & 31));
         }
     }
+    }
 }
 
 // one block per job: connected components by label propagation over the adjacency bit matrix
-__global__ __launch_bounds__(256) void k_components(Words W, Jobs J) {
+__global__ __launch_bounds__(256) void k_components(Words W, Jobs J, int final_pass) {
     __shared__ int changed;
     uint32_t job = blockIdx.x;
     if (job >= J.n) return;
@@ -502,96 +543,125 @@ __global__ __launch_bounds__(256) void k_components(Words W, Jobs J) {
         for (uint32_t p = 1; p < np; p++) if (pc[p] > pc[best]) best = p;
         J.giant[job] = label[best];
     }
+    if (final_pass)   // list of the cluster representatives for k_reach_init / k_cluster_vote
+        for (uint32_t a = threadIdx.x; a < nl; a += blockDim.x)
+            if (label[a] == a) W.rep_list[atomicAdd(&W.n_list[1], 1u)] = w0 + a;
 }
 
-// ---- clusters -------------------------------------------------------------------------------------------------------
-// reach rows: one row of R counters per representative leaf, at reach[(adj_off[job] * 32) + ka * (rw * 32) + j]
-__device__ __forceinline__ uint32_t *d_reach_row(const Jobs &J, uint32_t *reach, uint32_t job, uint32_t ka) {
-    const uint32_t rw = (J.R[job] + 31) >> 5;
-    return reach + J.adj_off[job] * 32 + (size_t)ka * rw * 32;
-}
-
-// one block per leaf slot: representatives clear their row
-__global__ __launch_bounds__(256) void k_reach_init(Words W, Jobs J, uint32_t *reach) {
-    uint32_t slot = blockIdx.x;
-    if (slot >= W.n) return;
-    uint32_t job = W.job[slot], w0 = J.w0[job], R = J.R[job], ka = slot - w0;
-    if (ka >= J.nl[job] || W.label[slot] != ka) return;
-    uint32_t *row = d_reach_row(J, reach, job, ka);
-    for (uint32_t j = threadIdx.x; j < R; j += blockDim.x) row[j] = 0;
-}
-
-// one wave per leaf: reach_C(j) = max over the leaves l of cluster C of LCP(word j, l)
-__global__ __launch_bounds__(256) void k_reach(Words W, Jobs J, uint32_t *reach, const uint16_t *lcpm) {
-    uint32_t slot = blockIdx.x * 4 + (threadIdx.x >> 6);
-    int lane = threadIdx.x & 63;
-    if (slot >= W.n) return;
-    uint32_t job = W.job[slot], w0 = J.w0[job], R = J.R[job], kl = slot - w0;
-    if (kl >= J.nl[job]) return;
-    uint32_t *row = d_reach_row(J, reach, job, W.label[slot]);
-    const uint16_t *mrow = lcpm + J.adj_off[job] * 32 + (size_t)kl * ((R + 31) >> 5) * 32;
-    for (uint32_t j = lane; j < R; j += 64) {
-        uint32_t c = mrow[j];
-        if (c > 0) atomicMax(&row[j], c);
+// ---- trie node sums ---------------------------------------------------------------------------------------------------
+// Every word adds its qualities / a counter / an end-of-word counter to the nodes along its path (Trie.add,
+// flanktrie.py:31-59); the covering leaf's npos row names them.  At a 1000x site ~900 words share the same trunk nodes,
+// so the sums are first combined in an LDS table (per depth NS_SLOTS nodes, keyed by position) per block of NS_WORDS
+// words and flushed with one global atomic per node; a depth with more distinct nodes than slots goes to HBM directly.
+#define NS_WORDS 128
+#define NS_SLOTS 8
+__global__ __launch_bounds__(1024) void k_node_sums(Words W, Jobs J, uint32_t max_len) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const uint32_t n = max_len * NS_SLOTS;
+    uint32_t *tk = reinterpret_cast<uint32_t *>(smem), *tq = tk + n, *tc = tq + n, *te = tc + n;   // [slot][depth]
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) { tk[i] = 0xFFFFFFFFu; tq[i] = 0; tc[i] = 0; te[i] = 0; }
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const uint32_t w_end = (blockIdx.x + 1) * NS_WORDS < W.n ? (blockIdx.x + 1) * NS_WORDS : W.n;
+    for (uint32_t w = blockIdx.x * NS_WORDS + (threadIdx.x >> 6); w < w_end; w += blockDim.x >> 6) {
+        const uint32_t job = W.job[w], w0 = J.w0[job];
+        const uint32_t k = W.cover[w];
+        if (k == 0xFFFFFFFFu) continue;   // cannot happen: every word is a prefix of a leaf
+        const uint32_t wl = w0 + W.leaf_word[w0 + k];
+        const uint32_t *np = W.npos + W.off[wl];
+        const uint8_t *q = W.q + W.off[w];
+        const int len = (int)W.len[w];
+        for (int d = lane; d < len; d += 64) {
+            const uint32_t pos = np[d], qv = q[d];
+            int sl = 0;
+            for (; sl < NS_SLOTS; sl++) { uint32_t old = atomicCAS(&tk[sl * max_len + d], 0xFFFFFFFFu, pos); if (old == 0xFFFFFFFFu || old == pos) break; }
+            if (sl < NS_SLOTS) {
+                const uint32_t i = sl * max_len + d;
+                atomicAdd(&tq[i], qv); atomicAdd(&tc[i], 1u);
+                if (d == len - 1) atomicAdd(&te[i], 1u);
+            } else {
+                atomicAdd(&W.agg[pos].q, qv); atomicAdd(&W.agg[pos].c, 1u);
+                if (d == len - 1) atomicAdd(&W.agg[pos].e, 1u);
+            }
+        }
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+        const uint32_t pos = tk[i];
+        if (pos == 0xFFFFFFFFu) continue;
+        atomicAdd(&W.agg[pos].q, tq[i]); atomicAdd(&W.agg[pos].c, tc[i]);
+        if (te[i]) atomicAdd(&W.agg[pos].e, te[i]);
     }
 }
 
-// one block per representative leaf slot: column vote (make_consensus_word flanktrie.py:306-342), merged count
-// (make_subtrie 89-118) and the cluster's place in the reference's list order.
-// dynamic LDS: hq[max_len*16] (u32) | hc[max_len*16] (u32)
-#define VOTE_CHUNK 1024
-__global__ __launch_bounds__(512) void k_cluster_vote(DevParams P, Words W, Jobs J, const uint32_t *reach, uint32_t max_len, char *cl_chars, uint32_t cl_stride) {
+// ---- clusters -------------------------------------------------------------------------------------------------------
+// one wave per leaf: share(l) = longest prefix shared with a leaf of the same cluster that comes before it.  The nodes
+// of its path above that depth are counted by that earlier leaf.
+__global__ __launch_bounds__(256) void k_leaf_share(Words W, Jobs J, const uint16_t *lcpm) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t n_leaf = W.n_list[0];
+    for (uint32_t it = blockIdx.x * 4 + (threadIdx.x >> 6); it < n_leaf; it += gridDim.x * 4) {
+        const uint32_t slot = W.leaf_list[it];
+        const uint32_t job = W.job[slot], w0 = J.w0[job], R = J.R[job], kl = slot - w0;
+        const uint32_t ka = W.label[slot], lw = W.leaf_word[slot];
+        const size_t rstride = (size_t)((R + 31) >> 5) * 32;
+        const uint16_t *lcp0 = lcpm + J.adj_off[job] * 32;
+        int share = 0;
+        for (uint32_t kp = lane; kp < kl; kp += 64)
+            if (W.label[w0 + kp] == ka) { int c = (int)lcp0[(size_t)kp * rstride + lw]; if (c > share) share = c; }
+        for (int o = 32; o > 0; o >>= 1) { int other = __shfl_xor(share, o, 64); if (other > share) share = other; }
+        if (lane == 0) W.share[slot] = (uint32_t)share;
+    }
+}
+
+// one block per cluster (representative leaf slot): column vote over the sub-trie of its leaves (make_consensus_word
+// flanktrie.py:306-342), merged count (make_subtrie 89-118) and the cluster's place in the reference's list order.
+// A member leaf adds the nodes of its path from depth share(l) on.  dynamic LDS: hq[max_len*16] (u32) | hc[max_len*16]
+__global__ __launch_bounds__(512) void k_cluster_vote(DevParams P, Words W, Jobs J, uint32_t max_len, char *cl_chars, uint32_t cl_stride) {
     extern __shared__ __align__(16) unsigned char smem[];
     uint32_t *hq = reinterpret_cast<uint32_t *>(smem);
     uint32_t *hc = hq + (size_t)max_len * 16;
     __shared__ int s_maxd, s_stop;
     __shared__ uint32_t s_minrank, s_words;
-    __shared__ uint32_t m_rc[VOTE_CHUNK];
-    __shared__ uint64_t m_off[VOTE_CHUNK];
-    const uint32_t slot = blockIdx.x;
-    if (slot >= W.n) return;
-    const uint32_t job = W.job[slot], w0 = J.w0[job], R = J.R[job], nl = J.nl[job], ka = slot - w0;
-    if (ka >= nl || W.label[slot] != ka) return;   // not a representative
+    const int lane = threadIdx.x & 63;
+    const uint32_t wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+    const uint32_t n_rep = W.n_list[1];
+    for (uint32_t it = blockIdx.x; it < n_rep; it += gridDim.x) {
+    __syncthreads();
+    const uint32_t slot = W.rep_list[it];
+    const uint32_t job = W.job[slot], w0 = J.w0[job], nl = J.nl[job], ka = slot - w0;
     for (uint32_t d = threadIdx.x; d < max_len * 16; d += blockDim.x) { hq[d] = 0; hc[d] = 0; }
     if (threadIdx.x == 0) { s_maxd = 0; s_minrank = 0xFFFFFFFFu; s_words = 0; }
     __syncthreads();
-    // members: longest leaf and first leaf in DFS order
-    for (uint32_t kl = threadIdx.x; kl < nl; kl += blockDim.x) {
-        if (W.label[w0 + kl] != ka) continue;
-        atomicMax(&s_maxd, (int)W.len[w0 + W.leaf_word[w0 + kl]]);
-        atomicMin(&s_minrank, W.leaf_rank[w0 + kl]);
-    }
-    const uint32_t *row = reach + J.adj_off[job] * 32 + (size_t)ka * ((R + 31) >> 5) * 32;
     uint32_t words = 0;
-    // threads = (group g, depth d): a group walks one word at a time with its lanes on consecutive characters (coalesced
-    // byte loads), so the LDS atomics of a wave go to different columns; word metadata is staged in LDS per chunk
-    const uint32_t pad = (max_len + 63) & ~63u;
-    const uint32_t G = blockDim.x / pad ? blockDim.x / pad : 1;
-    const uint32_t g = threadIdx.x / pad, d = threadIdx.x % pad;
-    for (uint32_t j0 = 0; j0 < R; j0 += VOTE_CHUNK) {
-        const uint32_t nchunk = R - j0 < VOTE_CHUNK ? R - j0 : VOTE_CHUNK;
-        __syncthreads();
-        for (uint32_t t = threadIdx.x; t < nchunk; t += blockDim.x) {
-            const uint32_t v = w0 + j0 + t;
-            const uint32_t rc = row[j0 + t];
-            if (rc == W.len[v]) words++;                 // the word is a prefix of a leaf of the cluster
-            m_rc[t] = rc; m_off[t] = W.off[v];
+    int maxlen = 0; uint32_t minrank = 0xFFFFFFFFu;
+    // lanes look at 64 leaves at a time; the members among them are then walked one by one by the whole wave
+    for (uint32_t k0 = wave * 64; k0 < nl; k0 += nwaves * 64) {
+        const uint32_t kl = k0 + lane;
+        const bool member = kl < nl && W.label[w0 + kl] == ka;
+        uint32_t m_wl = 0, m_len = 0, m_share = 0;
+        if (member) {
+            m_wl = w0 + W.leaf_word[w0 + kl]; m_len = W.len[m_wl]; m_share = W.share[w0 + kl];
+            if ((int)m_len > maxlen) maxlen = (int)m_len;
+            const uint32_t rk = W.leaf_rank[w0 + kl]; if (rk < minrank) minrank = rk;
         }
-        __syncthreads();
-        if (g < G)
-            for (uint32_t t = g; t < nchunk; t += 4 * G) {   // four words in flight per thread: the byte loads overlap
-                uint32_t code[4], qv[4]; bool on[4];
-#pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    const uint32_t tt = t + u * G;
-                    on[u] = tt < nchunk && d < m_rc[tt];
-                    if (on[u]) { const uint64_t o = m_off[tt] + d; code[u] = W.ch[o] & 15; qv[u] = W.q[o]; }
-                }
-#pragma unroll
-                for (int u = 0; u < 4; u++)
-                    if (on[u]) { atomicAdd(&hq[d * 16 + code[u]], qv[u]); atomicAdd(&hc[d * 16 + code[u]], 1u); }
+        unsigned long long todo = __ballot(member);
+        while (todo) {
+            const int src = __builtin_ctzll(todo); todo &= todo - 1;
+            const uint32_t wl = __shfl(m_wl, src, 64);
+            const int len = (int)__shfl(m_len, src, 64), share = (int)__shfl(m_share, src, 64);
+            const uint64_t o = W.off[wl];
+            for (int d = share + lane; d < len; d += 64) {
+                const NodeSum ns = W.agg[W.npos[o + d]];
+                const uint32_t code = W.ch[o + d] & 15;
+                atomicAdd(&hq[d * 16 + code], ns.q);
+                atomicAdd(&hc[d * 16 + code], ns.c);
+                words += ns.e;                               // words ending here: prefixes of a leaf of the cluster
             }
+        }
     }
+    if (maxlen) atomicMax(&s_maxd, maxlen);
+    if (minrank != 0xFFFFFFFFu) atomicMin(&s_minrank, minrank);
     if (words) atomicAdd(&s_words, words);
     __syncthreads();
     const int maxd = s_maxd;
@@ -622,6 +692,7 @@ __global__ __launch_bounds__(512) void k_cluster_vote(DevParams P, Words W, Jobs
         }
         char chv = nbest > 1 ? 'N' : codes[best < 0 ? 15 : best];   // get_best_qual_chars flanktrie.py:344-353
         out[side == 0 ? d : stop - 1 - d] = chv;                     // 3p consensus is reversed back (findflanks.py:894-895)
+    }
     }
 }
 
@@ -701,12 +772,14 @@ int run_consensus(mfk_ctx *ctx, const DevReads &R, const DevParams &P, Consensus
     W.off = aalloc<uint64_t>(ctx, (size_t)Wn + 1); W.is_leaf = aalloc<uint8_t>(ctx, Wn); W.leaf_word = aalloc<uint32_t>(ctx, Wn);
     W.leaf_rank = aalloc<uint32_t>(ctx, Wn); W.label = aalloc<uint32_t>(ctx, Wn); W.has_match = aalloc<uint8_t>(ctx, Wn);
     W.cl_count = aalloc<int32_t>(ctx, Wn); W.cl_len = aalloc<int32_t>(ctx, Wn); W.cl_key = aalloc<uint32_t>(ctx, Wn);
+    W.leaf_list = aalloc<uint32_t>(ctx, Wn); W.rep_list = aalloc<uint32_t>(ctx, Wn); W.n_list = aalloc<uint32_t>(ctx, 2);
     J.adj = aalloc<uint32_t>(ctx, (size_t)adj_total);
-    if (!W.first || !W.second || !W.nextra || !W.job || !W.len || !W.plen || !W.off || !W.is_leaf || !W.leaf_word || !W.leaf_rank || !W.label || !W.has_match || !W.cl_count || !W.cl_len || !W.cl_key || !J.adj) return 1;
+    if (!W.first || !W.second || !W.nextra || !W.job || !W.len || !W.plen || !W.off || !W.is_leaf || !W.leaf_word || !W.leaf_rank || !W.label || !W.has_match || !W.cl_count || !W.cl_len || !W.cl_key || !J.adj || !W.leaf_list || !W.rep_list || !W.n_list) return 1;
     HIPCHK(hipMemsetAsync(W.second, 0xFF, (size_t)Wn * 4, st));
     HIPCHK(hipMemsetAsync(W.nextra, 0, (size_t)Wn * 4, st));
     HIPCHK(hipMemsetAsync(W.leaf_rank, 0, (size_t)Wn * 4, st));
     HIPCHK(hipMemsetAsync(W.has_match, 0, (size_t)Wn, st));
+    HIPCHK(hipMemsetAsync(W.n_list, 0, 8, st));
     HIPCHK(hipMemsetAsync(W.label, 0xFF, (size_t)Wn * 4, st));
     HIPCHK(hipMemsetAsync(J.adj, 0, (size_t)(adj_total ? adj_total : 1) * 4, st));
     const unsigned wb = nblocks(Wn, 256), ww = nblocks(Wn, 4);
@@ -719,9 +792,14 @@ int run_consensus(mfk_ctx *ctx, const DevReads &R, const DevParams &P, Consensus
     { ReadBatch rb(ctx); rb.add(meta, &hm, sizeof hm); rb.add(W.off + Wn, &total_chars, 8); if (int rc = rb.flush()) return rc; }
     if (hm.err & ERR_READ_NUMBER) { snprintf(ctx->err, sizeof ctx->err, "READ NUMBER ERROR - ZERO OR MORE THAN TWO READS ASSOCIATED WITH QUERY NAME"); return 3; }
     if (hm.err & ERR_WORD_TOO_LONG) { snprintf(ctx->err, sizeof ctx->err, "soft clip longer than %d bases: not supported by this build", MAX_WORD_LEN); return 6; }
-    W.ch = aalloc<uint8_t>(ctx, (size_t)total_chars + 8); W.q = aalloc<uint8_t>(ctx, (size_t)total_chars + 8);
-    W.t = aalloc<uint32_t>(ctx, (size_t)total_chars + 8);
-    if (!W.ch || !W.q || !W.t) return 1;
+    W.ch = aalloc<uint8_t>(ctx, (size_t)total_chars + 64); W.q = aalloc<uint8_t>(ctx, (size_t)total_chars + 64);
+    if (total_chars >= 0xFFFFFFF0ull) { snprintf(ctx->err, sizeof ctx->err, "more than 2^32 clipped bases at the surviving sites of one call"); return 1; }
+    W.npos = aalloc<uint32_t>(ctx, (size_t)total_chars + 8);
+    W.agg = aalloc<NodeSum>(ctx, (size_t)total_chars + 8);
+    W.cover = aalloc<uint32_t>(ctx, Wn); W.share = aalloc<uint32_t>(ctx, Wn);
+    if (!W.ch || !W.q || !W.npos || !W.agg || !W.cover || !W.share) return 1;
+    HIPCHK(hipMemsetAsync(W.agg, 0, ((size_t)total_chars + 8) * sizeof(NodeSum), st));
+    HIPCHK(hipMemsetAsync(W.cover, 0xFF, (size_t)Wn * 4, st));
     PROF_LAUNCH(k_word_fill, dim3(ww), dim3(256), 0, st, R, W, meta);
     KCHK();
     PROF_LAUNCH(k_job_longest, dim3(J.n), dim3(256), 0, st, W, J);
@@ -732,31 +810,35 @@ int run_consensus(mfk_ctx *ctx, const DevReads &R, const DevParams &P, Consensus
     KCHK();
     uint16_t *lcpm = aalloc<uint16_t>(ctx, (size_t)adj_total * 32);
     if (!lcpm) return 1;
-    PROF_LAUNCH(k_leaf_first, dim3(Wn), dim3(64), 0, st, W, J, lcpm);
-    KCHK();
-    PROF_LAUNCH(k_leaf_rank, dim3(Wn), dim3(256), 0, st, W, J);
-    KCHK();
-    PROF_LAUNCH(k_leaf_myers, dim3(Wn), dim3(256), 0, st, W, J, 0);
-    KCHK();
-    PROF_LAUNCH(k_components, dim3(J.n), dim3(256), 0, st, W, J);
-    KCHK();
-    PROF_LAUNCH(k_leaf_myers, dim3(Wn), dim3(256), 0, st, W, J, 1);
-    KCHK();
-    PROF_LAUNCH(k_components, dim3(J.n), dim3(256), 0, st, W, J);
+    // per-leaf / per-cluster kernels: fixed grids over the device-side lists (the host never learns the list sizes)
+    const unsigned g_leaf1 = Wn < 8192 ? Wn : 8192, g_leaf4 = Wn < 2048 ? Wn : 2048, g_rep = Wn < 1024 ? Wn : 1024;
+    PROF_LAUNCH(k_leaf_first, dim3(g_leaf1), dim3(64), 0, st, W, J, lcpm);
     KCHK();
     const uint32_t max_len = hm.max_len ? hm.max_len : 1;
+    {
+        const size_t ns_lds = (size_t)max_len * NS_SLOTS * 16;   // <= 64 KB with MAX_WORD_LEN 512
+        PROF_LAUNCH(k_node_sums, dim3(nblocks(Wn, NS_WORDS)), dim3(1024), ns_lds, st, W, J, max_len);
+        KCHK();
+    }
+    PROF_LAUNCH(k_leaf_rank, dim3(g_leaf4), dim3(256), 0, st, W, J);
+    KCHK();
+    PROF_LAUNCH(k_leaf_myers, dim3(J.n * N_PIVOTS), dim3(256), 0, st, W, J, 0);
+    KCHK();
+    PROF_LAUNCH(k_components, dim3(J.n), dim3(256), 0, st, W, J, 0);
+    KCHK();
+    PROF_LAUNCH(k_leaf_myers, dim3(g_leaf4), dim3(256), 0, st, W, J, 1);
+    KCHK();
+    PROF_LAUNCH(k_components, dim3(J.n), dim3(256), 0, st, W, J, 1);
+    KCHK();
     size_t lds = (size_t)max_len * 16 * 8;
     if (lds > 64 * 1024) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_cluster_vote), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     io.cons_stride = (max_len + 7) & ~7u;
     io.cons_chars = aalloc<char>(ctx, (size_t)J.n * io.cons_stride);
     char *cl_chars = aalloc<char>(ctx, (size_t)Wn * io.cons_stride);
-    uint32_t *reach = aalloc<uint32_t>(ctx, (size_t)adj_total * 32);
-    if (!io.cons_chars || !cl_chars || !reach) return 1;
-    PROF_LAUNCH(k_reach_init, dim3(Wn), dim3(256), 0, st, W, J, reach);
+    if (!io.cons_chars || !cl_chars) return 1;
+    PROF_LAUNCH(k_leaf_share, dim3(g_leaf4), dim3(256), 0, st, W, J, (const uint16_t *)lcpm);
     KCHK();
-    PROF_LAUNCH(k_reach, dim3(ww), dim3(256), 0, st, W, J, reach, (const uint16_t *)lcpm);
-    KCHK();
-    PROF_LAUNCH(k_cluster_vote, dim3(Wn), dim3(512), lds, st, P, W, J, (const uint32_t *)reach, max_len, cl_chars, io.cons_stride);
+    PROF_LAUNCH(k_cluster_vote, dim3(g_rep), dim3(512), lds, st, P, W, J, max_len, cl_chars, io.cons_stride);
     KCHK();
     PROF_LAUNCH(k_job_best, dim3(nblocks(J.n, 256)), dim3(256), 0, st, P, W, J, io);
     KCHK();

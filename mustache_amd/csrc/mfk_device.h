@@ -151,6 +151,40 @@ __device__ inline void d_fetch_range(const DevReads &R, int32_t contig, int32_t 
     while (lo < hi) { int64_t m = (lo + hi) >> 1; if (R.ref_start[m] < end) lo = m + 1; else hi = m; }
     *lo_out = a; *hi_out = lo;
 }
+// Wave-cooperative lower bound: first index in [lo, hi) with a[idx] >= key (hi if none).  Every lane of one full wave
+// calls it with the same arguments.  Each round the 64 lanes probe 64 evenly spaced elements at once, so a search over
+// 2^24 reads costs 4-5 dependent HBM loads instead of the 24 of a one-lane binary search (the per-site searches of
+// k_classify / k_spanning / k_direct_repeats are pure memory latency).
+template <typename T, typename K>
+__device__ inline int64_t d_wave_lower_bound(const T *a, int64_t lo, int64_t hi, K key) {
+    const int lane = threadIdx.x & 63;
+    while (hi - lo > 64) {
+        const int64_t step = (hi - lo + 63) >> 6;
+        const int64_t p = lo + (int64_t)(lane + 1) * step - 1;
+        const bool less = p < hi && (K)a[p] < key;
+        const int c = __popcll(__ballot(less));          // sorted: lanes 0 .. c-1 see "less"
+        int64_t nlo = lo + (int64_t)c * step;
+        if (nlo > hi) nlo = hi;
+        int64_t nhi = nlo + step - 1;                    // a[nhi] >= key when nhi < hi
+        if (nhi > hi) nhi = hi;
+        lo = nlo; hi = nhi;
+    }
+    const int64_t p = lo + lane;
+    const bool less = p < hi && (K)a[p] < key;
+    return lo + __popcll(__ballot(less));
+}
+// d_fetch_range by one full wave (all 64 lanes call it; all get the result)
+__device__ inline void d_fetch_range_wave(const DevReads &R, int32_t contig, int32_t start, int32_t end, int64_t *lo_out, int64_t *hi_out) {
+    const int64_t r0 = R.contig_rs[contig], r1 = R.contig_rs[contig + 1];
+    const int64_t a = d_wave_lower_bound<int32_t, int32_t>(R.ref_start, r0, r1, start - R.max_span);
+    *lo_out = a;
+    *hi_out = d_wave_lower_bound<int32_t, int32_t>(R.ref_start, a, r1, end);
+}
+__device__ inline int64_t d_pool_index_wave(const DevReads &R, int64_t r) {
+    const int64_t lo = d_wave_lower_bound<uint32_t, int64_t>(R.pool_read, 0, R.n_pool, r);
+    if (lo >= R.n_pool || (int64_t)R.pool_read[lo] != r) return -1;
+    return lo;
+}
 // htslib overlap test for a read already known to have ref_start < end
 __device__ __forceinline__ bool d_overlaps(const DevReads &R, int64_t r, int32_t start) {
     int32_t rs = R.ref_start[r], re = R.ref_end[r];

@@ -21,11 +21,15 @@
 #define SCAN_MAX_BLOCKS 2048
 
 // ---- K1: clip events -------------------------------------------------------------------------------------------
-// parse_softclips (findflanks.py:100-121) in one pass.  Each lane loads the flags of 16 consecutive reads (one dwordx4);
-// only lenient-clipped reads (~1.5 %) gather the rest of their record, run passes_read_filters and emit one 64-bit key
-// (gpos | side | read) per clip.  Keys are staged in LDS and flushed with ONE global reservation per workgroup; their
+// parse_softclips (findflanks.py:100-121) in one pass over tiles of 4096 reads.  Phase 1: each lane loads the flags of 16
+// consecutive reads (one dwordx4) and pushes the lenient-clipped ones (~1.5 %) to a list in LDS.  Phase 2: one thread
+// per listed read gathers the rest of its record (all column loads issued together), runs passes_read_filters and
+// emits one 64-bit key (gpos | side | read) per clip.  Clipped reads pile up at the insertion sites (a 1000x site puts
+// ~500 of them into one tile); the list spreads them over the whole workgroup instead of leaving one lane with eight
+// dependent gathers in a row.  Keys are staged in LDS and flushed with ONE global reservation per workgroup; their
 // order is arbitrary, which is fine because keys are unique and the radix sort that follows fixes the order.
 #define EV_STAGE 2048
+#define SCAN_TILE (SCAN_THREADS * 16)
 
 __device__ __forceinline__ void d_stage_event(uint64_t key, uint64_t *stage, uint32_t *s_n, uint64_t *ev, uint32_t *ev_count, uint32_t cap) {
     uint32_t slot = atomicAdd(s_n, 1u);
@@ -35,39 +39,69 @@ __device__ __forceinline__ void d_stage_event(uint64_t key, uint64_t *stage, uin
 
 __global__ __launch_bounds__(SCAN_THREADS) void k_scan_clips(DevReads R, DevParams P, uint64_t *ev, uint32_t *ev_count, uint32_t cap) {
     __shared__ uint64_t stage[EV_STAGE];
-    __shared__ uint32_t s_n, s_base;
-    if (threadIdx.x == 0) s_n = 0;
+    __shared__ uint32_t cl_r[SCAN_TILE];
+    __shared__ uint8_t cl_f[SCAN_TILE];
+    __shared__ uint32_t s_n, s_base, s_ncl;
+    if (threadIdx.x == 0) { s_n = 0; s_ncl = 0; }
     __syncthreads();
     const int64_t ngroups = (R.n + 15) >> 4;
-    const int64_t per_block = (ngroups + gridDim.x - 1) / gridDim.x;
-    const int64_t g0 = (int64_t)blockIdx.x * per_block;
-    int64_t g1 = g0 + per_block;
-    if (g1 > ngroups) g1 = ngroups;
-    for (int64_t g = g0 + threadIdx.x; g < g1; g += SCAN_THREADS) {
-        uint32_t w[4] = {0, 0, 0, 0};
-        int nvalid = 16;
-        const int64_t r0 = g << 4;
-        if (r0 + 16 <= R.n) {
-            uint4 v = *reinterpret_cast<const uint4 *>(R.flags + r0);
-            w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
-        } else {
-            nvalid = (int)(R.n - r0);
-            for (int k = 0; k < nvalid; k++) w[k >> 2] |= (uint32_t)R.flags[r0 + k] << ((k & 3) * 8);
+    const int64_t ntiles = (ngroups + SCAN_THREADS - 1) / SCAN_THREADS;
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int64_t g = tile * SCAN_THREADS + threadIdx.x;
+        if (g < ngroups) {
+            uint32_t w[4] = {0, 0, 0, 0};
+            int nvalid = 16;
+            const int64_t r0 = g << 4;
+            if (r0 + 16 <= R.n) {
+                uint4 v = *reinterpret_cast<const uint4 *>(R.flags + r0);
+                w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
+            } else {
+                nvalid = (int)(R.n - r0);
+                for (int k = 0; k < nvalid; k++) w[k >> 2] |= (uint32_t)R.flags[r0 + k] << ((k & 3) * 8);
+            }
+            if ((w[0] | w[1] | w[2] | w[3]) & 0x0F0F0F0Fu)
+                for (int k = 0; k < nvalid; k++) {
+                    const uint8_t f = (uint8_t)(w[k >> 2] >> ((k & 3) * 8));
+                    if (!(f & 15)) continue;
+                    const uint32_t slot = atomicAdd(&s_ncl, 1u);
+                    cl_r[slot] = (uint32_t)(r0 + k); cl_f[slot] = f;
+                }
         }
-        if (!((w[0] | w[1] | w[2] | w[3]) & 0x0F0F0F0Fu)) continue;
-        for (int k = 0; k < nvalid; k++) {
-            const uint8_t f = (uint8_t)(w[k >> 2] >> ((k & 3) * 8));
-            if (!(f & 15)) continue;
-            const int64_t r = r0 + k;
-            if (!d_passes(R, P, r, f)) continue;
+        __syncthreads();
+        const uint32_t ncl = s_ncl;
+        for (uint32_t i = threadIdx.x; i < ncl; i += SCAN_THREADS) {
+            const int64_t r = cl_r[i];
+            const uint8_t f = cl_f[i];
+            // the whole record at once: these loads do not depend on each other
+            const int mq = R.mapq[r], ql = R.qlen[r], fo = R.first_op_len[r], lo = R.last_op_len[r];
+            const int32_t rs = R.ref_start[r], re = R.ref_end[r];
             const uint32_t base = R.contig_base[R.contig_id[r]];
-            if (d_rkind(f))   // right clip -> 5p site (findflanks.py:117-118, 594-597)
-                d_stage_event(((uint64_t)(base + (uint32_t)(d_rsite(R, r, f) + 1)) << 32) | (uint64_t)(uint32_t)r, stage, &s_n, ev, ev_count, cap);
-            if (d_lkind(f))   // left clip -> 3p site (findflanks.py:120-121, 599-602)
-                d_stage_event(((uint64_t)(base + (uint32_t)(d_lsite(R, r, f) + 1)) << 32) | (1ull << 31) | (uint64_t)(uint32_t)r, stage, &s_n, ev, ev_count, cap);
+            const int lk = d_lkind(f), rk = d_rkind(f);
+            const int llen = lk == 1 ? fo : (lk == 2 ? 1 : 0), rlen = rk == 1 ? lo : (rk == 2 ? 1 : 0);   // d_llen / d_rlen
+            if (mq < P.minq) continue;                                                                  // d_passes
+            if (lk && rk && ql - rlen - llen < P.minial) continue;
+            if (rk) {   // right clip -> 5p site (findflanks.py:117-118, 594-597); d_rsite
+                const int32_t site = rk == 1 ? re : re - 1;
+                d_stage_event(((uint64_t)(base + (uint32_t)(site + 1)) << 32) | (uint64_t)(uint32_t)r, stage, &s_n, ev, ev_count, cap);
+            }
+            if (lk) {   // left clip -> 3p site (findflanks.py:120-121, 599-602); d_lsite
+                const int32_t site = lk == 1 ? rs - 1 : rs;
+                d_stage_event(((uint64_t)(base + (uint32_t)(site + 1)) << 32) | (1ull << 31) | (uint64_t)(uint32_t)r, stage, &s_n, ev, ev_count, cap);
+            }
         }
+        __syncthreads();
+        if (threadIdx.x == 0) s_ncl = 0;
+        // the stage fills up at deep sites: flush it between tiles once it is half full
+        if (s_n >= EV_STAGE / 2) {
+            const uint32_t n = s_n < EV_STAGE ? s_n : EV_STAGE;
+            if (threadIdx.x == 0) s_base = atomicAdd(ev_count, n);
+            __syncthreads();
+            for (uint32_t i = threadIdx.x; i < n; i += SCAN_THREADS) if (s_base + i < cap) ev[s_base + i] = stage[i];
+            __syncthreads();
+            if (threadIdx.x == 0) s_n = 0;
+        }
+        __syncthreads();
     }
-    __syncthreads();
     const uint32_t n = s_n < EV_STAGE ? s_n : EV_STAGE;
     if (threadIdx.x == 0 && n) s_base = atomicAdd(ev_count, n);
     __syncthreads();
@@ -254,9 +288,10 @@ __global__ __launch_bounds__(256) void k_classify(DevReads R, DevParams P, ActTa
     if (start < 0) start = 0;
     if (end > clen) end = clen;
     if (threadIdx.x < 8) cnt[threadIdx.x] = 0;
-    if (threadIdx.x == 0) {
-        if (start < end) d_fetch_range(R, contig, start, end, &range[0], &range[1]);
-        else { range[0] = 0; range[1] = 0; }
+    if (threadIdx.x < 64) {   // first wave: cooperative search of the read range
+        int64_t a = 0, b = 0;
+        if (start < end) d_fetch_range_wave(R, contig, start, end, &a, &b);
+        if (threadIdx.x == 0) { range[0] = a; range[1] = b; }
     }
     __syncthreads();
     const int64_t lo = range[0], hi = range[1];

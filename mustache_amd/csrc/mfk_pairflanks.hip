@@ -67,28 +67,58 @@ __device__ void d_ir_detect(const uint8_t *code, int L, int16_t *S, uint8_t *mas
     for (int i = lane; i < L; i += 64) mask[i] = 0;
     __syncthreads();
     int nrep = 0;
+    // Anti-diagonal wavefront held in registers: lane owns rows iA = lane and iB = lane + 64 (L <= 100) and keeps its
+    // cells of the last two diagonals; the cells of row i+1 come from the next lane by a shuffle.  S is still written to
+    // LDS, but only the traceback reads it, so a diagonal costs a few shuffles instead of three LDS round trips + a barrier.
+    const int iA = lane, iB = lane + 64;
     while (nrep < IR_MAXREP) {
         for (int i = lane; i < L; i += 64) S[i * L + i] = 0;
-        __syncthreads();
+        const int cA = iA < L ? code[iA] : 4, cB = iB < L ? code[iB] : 4;
+        const bool mA = iA < L ? mask[iA] != 0 : true, mB = iB < L ? mask[iB] != 0 : true;
+        int p1A = 0, p2A = 0, p1B = 0, p2B = 0;   // S(i, i+d-1) and S(i, i+d-2)
+        int cjA = iA + 1 < L ? code[iA + 1] : 4, cjB = iB + 1 < L ? code[iB + 1] : 4;
+        bool mjA = iA + 1 < L ? mask[iA + 1] != 0 : true, mjB = iB + 1 < L ? mask[iB + 1] != 0 : true;
         unsigned bestkey = 0;   // score << 16 | (255 - j) << 8 | i : highest score, then smallest j, then largest i
         for (int d = 1; d < L; d++) {
-            for (int i = lane; i + d < L; i += 64) {
-                int j = i + d, v = 0;
-                if (!mask[i] && !mask[j]) {
-                    int diag = d >= 2 ? S[(i + 1) * L + (j - 1)] : 0;
-                    int m = (code[i] < 4 && code[j] < 4 && code[i] + code[j] == 3) ? MATCH : MISMATCH;
-                    v = diag + m;
-                    int up = S[(i + 1) * L + j] - GAP, left = S[i * L + (j - 1)] - GAP;
-                    if (up > v) v = up;
-                    if (left > v) v = left;
-                    if (v < 0) v = 0;
+            int n1A = __shfl_down(p1A, 1, 64), n2A = __shfl_down(p2A, 1, 64);
+            const int n1B = __shfl_down(p1B, 1, 64), n2B = __shfl_down(p2B, 1, 64);
+            const int b1 = __shfl(p1B, 0, 64), b2 = __shfl(p2B, 0, 64);
+            if (lane == 63) { n1A = b1; n2A = b2; }   // row 64 lives in lane 0's second slot
+            // next diagonal's column characters: issued now, used in the next iteration
+            const int ncjA = iA + d + 1 < L ? code[iA + d + 1] : 4, ncjB = iB + d + 1 < L ? code[iB + d + 1] : 4;
+            const bool nmjA = iA + d + 1 < L ? mask[iA + d + 1] != 0 : true, nmjB = iB + d + 1 < L ? mask[iB + d + 1] != 0 : true;
+            int vA = 0, vB = 0;
+            const int jA = iA + d, jB = iB + d;
+            if (jA < L) {
+                if (!mA && !mjA) {
+                    const int m = (cA < 4 && cjA < 4 && cA + cjA == 3) ? MATCH : MISMATCH;
+                    vA = (d >= 2 ? n2A : 0) + m;
+                    const int up = n1A - GAP, left = p1A - GAP;
+                    if (up > vA) vA = up;
+                    if (left > vA) vA = left;
+                    if (vA < 0) vA = 0;
                 }
-                S[i * L + j] = (int16_t)v;
-                unsigned key = ((unsigned)v << 16) | ((unsigned)(255 - j) << 8) | (unsigned)i;
-                if (v > 0 && key > bestkey) bestkey = key;
+                S[iA * L + jA] = (int16_t)vA;
+                const unsigned key = ((unsigned)vA << 16) | ((unsigned)(255 - jA) << 8) | (unsigned)iA;
+                if (vA > 0 && key > bestkey) bestkey = key;
             }
-            __syncthreads();
+            if (jB < L) {
+                if (!mB && !mjB) {
+                    const int m = (cB < 4 && cjB < 4 && cB + cjB == 3) ? MATCH : MISMATCH;
+                    vB = (d >= 2 ? n2B : 0) + m;
+                    const int up = n1B - GAP, left = p1B - GAP;
+                    if (up > vB) vB = up;
+                    if (left > vB) vB = left;
+                    if (vB < 0) vB = 0;
+                }
+                S[iB * L + jB] = (int16_t)vB;
+                const unsigned key = ((unsigned)vB << 16) | ((unsigned)(255 - jB) << 8) | (unsigned)iB;
+                if (vB > 0 && key > bestkey) bestkey = key;
+            }
+            p2A = p1A; p1A = vA; p2B = p1B; p1B = vB;
+            cjA = ncjA; cjB = ncjB; mjA = nmjA; mjB = nmjB;
         }
+        __syncthreads();
         for (int o = 32; o > 0; o >>= 1) { unsigned other = __shfl_xor(bestkey, o, 64); if (other > bestkey) bestkey = other; }
         int best = (int)(bestkey >> 16);
         if (best < THRESHOLD) break;
@@ -248,9 +278,10 @@ __global__ __launch_bounds__(256) void k_spanning(DevReads R, DevParams P, Flank
     int32_t start = pos3 - 1, end = pos5 + 2;
     if (start < 0) start = 0;
     if (end > clen) end = clen;
-    if (threadIdx.x == 0) {
-        cnt = 0;
-        if (start < end) d_fetch_range(R, contig, start, end, &range[0], &range[1]); else { range[0] = 0; range[1] = 0; }
+    if (threadIdx.x < 64) {   // first wave: cooperative search of the read range
+        int64_t a = 0, b = 0;
+        if (start < end) d_fetch_range_wave(R, contig, start, end, &a, &b);
+        if (threadIdx.x == 0) { cnt = 0; range[0] = a; range[1] = b; }
     }
     __syncthreads();
     for (int64_t r = range[0] + threadIdx.x; r < range[1]; r += blockDim.x) {
@@ -323,15 +354,13 @@ __global__ __launch_bounds__(1024) void k_direct_repeats(DevReads R, FlankDev F,
         int64_t idx = threadIdx.x;
         refch[threadIdx.x] = idx < add_start_n ? (uint8_t)'N' : ((es + idx - add_start_n) < glen ? g[es + idx - add_start_n] : (uint8_t)'N');
     }
-    if (threadIdx.x == 0) {
-        err = 0;
-        if (W > 0) d_fetch_range(R, contig, (int32_t)es, (int32_t)ee, &range[0], &range[1]); else { range[0] = 0; range[1] = 0; }
+    if (threadIdx.x < 64) {   // first wave: cooperative searches
+        int64_t a = 0, b = 0;
+        if (W > 0) d_fetch_range_wave(R, contig, (int32_t)es, (int32_t)ee, &a, &b);
         // pooled reads of that read range: the per-read lookups below search only this slice of pool_read
-        int64_t lo = 0, hi = R.n_pool;
-        while (lo < hi) { int64_t m = (lo + hi) >> 1; if ((int64_t)R.pool_read[m] < range[0]) lo = m + 1; else hi = m; }
-        prange[0] = lo; hi = R.n_pool;
-        while (lo < hi) { int64_t m = (lo + hi) >> 1; if ((int64_t)R.pool_read[m] < range[1]) lo = m + 1; else hi = m; }
-        prange[1] = lo;
+        const int64_t pa = d_wave_lower_bound<uint32_t, int64_t>(R.pool_read, 0, R.n_pool, a);
+        const int64_t pb = d_wave_lower_bound<uint32_t, int64_t>(R.pool_read, pa, R.n_pool, b);
+        if (threadIdx.x == 0) { err = 0; range[0] = a; range[1] = b; prange[0] = pa; prange[1] = pb; }
     }
     __syncthreads();
     // reads of bam.fetch(contig, expanded_start, expanded_end): no read filter here (pairflanks.py:311).
