@@ -137,14 +137,53 @@ int read_back(mfk_ctx *ctx, const void *dev, void *host, size_t bytes) {
     return b.flush();
 }
 
+// up to GATHER_MAX pieces of device memory -> one staging buffer in pinned host memory, written by the kernel itself
+// (zero-copy): a read-back of many small result arrays is one launch instead of one copy per array
+#define GATHER_MAX 16
+struct GatherArgs { const uint8_t *src[GATHER_MAX]; uint32_t bytes[GATHER_MAX], off[GATHER_MAX]; int n; };
+__global__ __launch_bounds__(256) void k_gather(GatherArgs g, uint8_t *dst) {
+    for (int i = blockIdx.y; i < g.n; i += gridDim.y) {
+        const uint8_t *src = g.src[i];
+        uint8_t *out = dst + g.off[i];
+        const uint32_t nb = g.bytes[i];
+        if ((((uintptr_t)src | (uintptr_t)out) & 3) == 0) {
+            const uint32_t nw = nb >> 2;
+            for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < nw; k += gridDim.x * blockDim.x)
+                reinterpret_cast<uint32_t *>(out)[k] = reinterpret_cast<const uint32_t *>(src)[k];
+            for (uint32_t k = (nw << 2) + blockIdx.x * blockDim.x + threadIdx.x; k < nb; k += gridDim.x * blockDim.x) out[k] = src[k];
+        } else
+            for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < nb; k += gridDim.x * blockDim.x) out[k] = src[k];
+    }
+}
+
 int ReadBatch::flush() {
     if (items.empty()) return 0;
     char *pin = (char *)pinned_buf(ctx, total);
     if (!pin) { snprintf(ctx->err, sizeof ctx->err, "pinned allocation failed"); return 1; }
-    for (auto &it : items) HIPCHK(hipMemcpyAsync(pin + it.off, it.dev, it.bytes, hipMemcpyDeviceToHost, ctx->stream));
+    bool small = items.size() > 1 && items.size() <= GATHER_MAX && total < ((size_t)1 << 24);
+    void *dpin = nullptr;
+    if (small && hipHostGetDevicePointer(&dpin, pin, 0) != hipSuccess) small = false;
+    if (small) {
+        GatherArgs g; g.n = (int)items.size();
+        size_t biggest = 0;
+        for (int i = 0; i < g.n; i++) { g.src[i] = (const uint8_t *)items[i].dev; g.bytes[i] = (uint32_t)items[i].bytes; g.off[i] = (uint32_t)items[i].off; if (items[i].bytes > biggest) biggest = items[i].bytes; }
+        unsigned bx = (unsigned)((biggest / 4 + 255) / 256); if (bx < 1) bx = 1; if (bx > 64) bx = 64;
+        hipLaunchKernelGGL(k_gather, dim3(bx, g.n), dim3(256), 0, ctx->stream, g, (uint8_t *)dpin);
+        KCHK();
+    } else
+        for (auto &it : items) HIPCHK(hipMemcpyAsync(pin + it.off, it.dev, it.bytes, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     for (auto &it : items) memcpy(it.host, pin + it.off, it.bytes);
     items.clear(); total = 0;
+    return 0;
+}
+
+int FillGroup::commit() {
+    if (reqs.empty()) return 0;
+    char *p = (char *)arena_alloc(ctx, total);
+    if (!p) return 1;
+    for (auto &r : reqs) *r.out = p + r.off;
+    HIPCHK(hipMemsetAsync(p, value, total, ctx->stream));
     return 0;
 }
 
@@ -154,7 +193,7 @@ void *pinned_buf(mfk_ctx *ctx, size_t bytes) {
         if (ctx->pinned) (void)hipHostFree(ctx->pinned);
         ctx->pinned = nullptr;
         size_t cap = bytes < 4096 ? 4096 : bytes * 2;
-        if (hipHostMalloc(&ctx->pinned, cap, hipHostMallocDefault) != hipSuccess) { ctx->pinned_cap = 0; return nullptr; }
+        if (hipHostMalloc(&ctx->pinned, cap, hipHostMallocMapped) != hipSuccess) { ctx->pinned_cap = 0; return nullptr; }
         ctx->pinned_cap = cap;
     }
     return ctx->pinned;
@@ -164,6 +203,8 @@ void *pinned_buf(mfk_ctx *ctx, size_t bytes) {
 // The flat coordinate "gpos": contig c occupies [base[c], base[c] + len[c] + 2) (site positions run from -1 to len),
 // contigs are separated by a gap wider than any neighbourhood the filters look at, so one sorted u32 axis serves all
 // contigs and no neighbour search can cross a contig boundary.
+size_t upload_reads_pinned_bytes(int nc) { return (((size_t)(nc + 1) * 8 + (size_t)nc * 8) + 255) & ~(size_t)255; }
+
 int upload_reads(mfk_ctx *ctx, const mfk_reads *in, const mfk_params *pr, DevReads *R, DevParams *P) {
     if (in->n_reads < 0 || in->n_reads >= ((int64_t)1 << 31)) { snprintf(ctx->err, sizeof ctx->err, "n_reads %lld out of range (max 2^31-1 per call)", (long long)in->n_reads); return 1; }
     if (in->n_contigs <= 0 || in->n_contigs > 65535) { snprintf(ctx->err, sizeof ctx->err, "n_contigs %d out of range", in->n_contigs); return 1; }
@@ -184,10 +225,11 @@ int upload_reads(mfk_ctx *ctx, const mfk_reads *in, const mfk_params *pr, DevRea
     int nc = in->n_contigs;
     int64_t pad = (int64_t)pr->min_distance_to_mate + pr->max_direct_repeat_length + 64;
     if (pad < 64) pad = 64;
-    size_t bytes = (size_t)nc * 4 + (size_t)(nc + 1) * 8 + (size_t)nc * 4;
-    char *h = (char *)pinned_buf(ctx, bytes + 64);
+    // header arrays: [read starts i64 x (nc+1) | lengths i32 x nc | bases u32 x nc] staged in pinned memory, one copy
+    const size_t bytes = upload_reads_pinned_bytes(nc);
+    char *h = (char *)pinned_buf(ctx, bytes);
     if (!h) { snprintf(ctx->err, sizeof ctx->err, "pinned allocation failed"); return 1; }
-    int32_t *h_len = (int32_t *)h; int64_t *h_rs = (int64_t *)(h + (((size_t)nc * 4 + 7) & ~(size_t)7)); uint32_t *h_base = (uint32_t *)(h_rs + nc + 1);
+    int64_t *h_rs = (int64_t *)h; int32_t *h_len = (int32_t *)(h_rs + nc + 1); uint32_t *h_base = (uint32_t *)(h_len + nc);
     int64_t base = 0;
     for (int c = 0; c < nc; c++) {
         h_len[c] = in->h_contig_len[c];
@@ -197,12 +239,12 @@ int upload_reads(mfk_ctx *ctx, const mfk_reads *in, const mfk_params *pr, DevRea
     }
     if (base >= ((int64_t)1 << 32)) { snprintf(ctx->err, sizeof ctx->err, "total reference length %lld does not fit the 32-bit site axis", (long long)base); return 1; }
     for (int c = 0; c <= nc; c++) h_rs[c] = in->h_contig_read_start[c];
-    int32_t *d_len = aalloc<int32_t>(ctx, nc); int64_t *d_rs = aalloc<int64_t>(ctx, nc + 1); uint32_t *d_base = aalloc<uint32_t>(ctx, nc);
-    if (!d_len || !d_rs || !d_base) return 1;
-    HIPCHK(hipMemcpyAsync(d_len, h_len, (size_t)nc * 4, hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(hipMemcpyAsync(d_rs, h_rs, (size_t)(nc + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(hipMemcpyAsync(d_base, h_base, (size_t)nc * 4, hipMemcpyHostToDevice, ctx->stream));
-    // no synchronisation: later read-backs into the same pinned bytes are ordered behind these copies on the stream
+    R->gpos_span = (uint32_t)base;
+    char *d_hdr = aalloc<char>(ctx, bytes);
+    if (!d_hdr) return 1;
+    HIPCHK(hipMemcpyAsync(d_hdr, h, bytes, hipMemcpyHostToDevice, ctx->stream));
+    // no synchronisation: later read-backs into the same pinned bytes are ordered behind this copy on the stream
+    int64_t *d_rs = (int64_t *)d_hdr; int32_t *d_len = (int32_t *)(d_rs + nc + 1); uint32_t *d_base = (uint32_t *)(d_len + nc);
     R->contig_len = d_len; R->contig_rs = d_rs; R->contig_base = d_base;
     P->minlen = pr->min_softclip_length; P->mincount = pr->min_softclip_count; P->minq = pr->min_alignment_quality;
     P->minial = pr->min_alignment_inner_length; P->mindist = pr->min_distance_to_mate; P->lins = pr->large_insertion_cutoff;
@@ -236,36 +278,67 @@ int dev_sort_pairs64(mfk_ctx *ctx, uint64_t *kin, uint64_t *kout, uint32_t *vin,
     return 0;
 }
 
-__global__ void k_write_total32(const uint32_t *in, uint32_t *out, size_t n) { out[n] = out[n - 1] + in[n - 1]; }
-__global__ void k_write_total64(const uint32_t *in, uint64_t *out, size_t n) { out[n] = out[n - 1] + in[n - 1]; }
+// ---- exclusive scans with the total appended: out has n+1 entries ----------------------------------------------------
+// n <= SCAN_SMALL: one workgroup walks the array (one launch).  Larger: rocPRIM's look-back scan over n+1 elements whose
+// last input is a virtual zero, so the total lands in out[n] without an extra kernel.
+#define SCAN_SMALL (96 * 1024)
+#define SCAN_ITEMS 8
+template <typename TOut>
+__global__ __launch_bounds__(1024) void k_scan_small(const uint32_t *in, TOut *out, uint32_t n) {
+    __shared__ TOut wsum[16];
+    __shared__ TOut carry_s;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    TOut carry = 0;
+    for (uint32_t base = 0; base < n; base += 1024 * SCAN_ITEMS) {
+        const uint32_t i0 = base + threadIdx.x * SCAN_ITEMS;
+        uint32_t v[SCAN_ITEMS];
+        TOut tsum = 0;
+#pragma unroll
+        for (int k = 0; k < SCAN_ITEMS; k++) { v[k] = i0 + k < n ? in[i0 + k] : 0u; tsum += v[k]; }
+        TOut inc = tsum;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { TOut t = __shfl_up(inc, d, 64); if (lane >= d) inc += t; }
+        if (lane == 63) wsum[wave] = inc;
+        __syncthreads();
+        TOut wbase = 0, tot = 0;
+#pragma unroll
+        for (int w = 0; w < 16; w++) { TOut s = wsum[w]; if (w < wave) wbase += s; tot += s; }
+        TOut run = carry + wbase + inc - tsum;
+#pragma unroll
+        for (int k = 0; k < SCAN_ITEMS; k++) { if (i0 + k < n) out[i0 + k] = run; run += v[k]; }
+        carry += tot;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[n] = carry;
+    (void)carry_s;
+}
 
-int dev_excl_scan32(mfk_ctx *ctx, const uint32_t *in, uint32_t *out, size_t n) {
-    if (n == 0) { HIPCHK(hipMemsetAsync(out, 0, 4, ctx->stream)); return 0; }
+template <typename TOut>
+struct PaddedIn {
+    const uint32_t *in; size_t n;
+    __device__ TOut operator()(size_t i) const { return i < n ? (TOut)in[i] : (TOut)0; }
+};
+
+template <typename TOut>
+static int dev_excl_scan(mfk_ctx *ctx, const uint32_t *in, TOut *out, size_t n) {
+    if (n == 0) { HIPCHK(hipMemsetAsync(out, 0, sizeof(TOut), ctx->stream)); return 0; }
+    if (n <= SCAN_SMALL) {
+        prof_begin(ctx, "k_scan_small");
+        hipLaunchKernelGGL(k_scan_small<TOut>, dim3(1), dim3(1024), 0, ctx->stream, in, out, (uint32_t)n);
+        prof_end(ctx);
+        KCHK();
+        return 0;
+    }
     size_t tb = 0;
-    HIPCHK(rocprim::exclusive_scan(nullptr, tb, in, out, (uint32_t)0, n, rocprim::plus<uint32_t>(), ctx->stream));
+    auto it = rocprim::make_transform_iterator(rocprim::make_counting_iterator<size_t>(0), PaddedIn<TOut>{in, n});
+    HIPCHK(rocprim::exclusive_scan(nullptr, tb, it, out, (TOut)0, n + 1, rocprim::plus<TOut>(), ctx->stream));
     void *tmp = arena_alloc(ctx, tb ? tb : 1);
     if (!tmp) return 1;
     prof_begin(ctx, "rocprim::exclusive_scan");
-    HIPCHK(rocprim::exclusive_scan(tmp, tb, in, out, (uint32_t)0, n, rocprim::plus<uint32_t>(), ctx->stream));
+    HIPCHK(rocprim::exclusive_scan(tmp, tb, it, out, (TOut)0, n + 1, rocprim::plus<TOut>(), ctx->stream));
     prof_end(ctx);
-    hipLaunchKernelGGL(k_write_total32, dim3(1), dim3(1), 0, ctx->stream, in, out, n);
-    KCHK();
     return 0;
 }
 
-struct U32ToU64 { __device__ uint64_t operator()(uint32_t v) const { return (uint64_t)v; } };
-
-int dev_excl_scan64(mfk_ctx *ctx, const uint32_t *in, uint64_t *out, size_t n) {
-    if (n == 0) { HIPCHK(hipMemsetAsync(out, 0, 8, ctx->stream)); return 0; }
-    size_t tb = 0;
-    auto it = rocprim::make_transform_iterator(in, U32ToU64());
-    HIPCHK(rocprim::exclusive_scan(nullptr, tb, it, out, (uint64_t)0, n, rocprim::plus<uint64_t>(), ctx->stream));
-    void *tmp = arena_alloc(ctx, tb ? tb : 1);
-    if (!tmp) return 1;
-    prof_begin(ctx, "rocprim::exclusive_scan");
-    HIPCHK(rocprim::exclusive_scan(tmp, tb, it, out, (uint64_t)0, n, rocprim::plus<uint64_t>(), ctx->stream));
-    prof_end(ctx);
-    hipLaunchKernelGGL(k_write_total64, dim3(1), dim3(1), 0, ctx->stream, in, out, n);
-    KCHK();
-    return 0;
-}
+int dev_excl_scan32(mfk_ctx *ctx, const uint32_t *in, uint32_t *out, size_t n) { return dev_excl_scan<uint32_t>(ctx, in, out, n); }
+int dev_excl_scan64(mfk_ctx *ctx, const uint32_t *in, uint64_t *out, size_t n) { return dev_excl_scan<uint64_t>(ctx, in, out, n); }

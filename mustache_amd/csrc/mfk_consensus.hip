@@ -85,31 +85,17 @@ __device__ __forceinline__ int d_lcp(const uint8_t *a, int la, const uint8_t *b,
 }
 
 // ---- words ------------------------------------------------------------------------------------------------------
-__global__ void k_site_act_map(const uint32_t *act_site, uint32_t n_act, int32_t *site_act) {
-    uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k < n_act) site_act[act_site[k]] = (int32_t)k;
-}
-
-__global__ void k_fill_ev_site(const uint32_t *act_site, uint32_t n_act, const uint32_t *ev_begin, const uint32_t *ev_end, uint32_t *ev_site) {
-    // one block per active site: mark its events (events of inactive sites keep 0xFFFFFFFF)
-    uint32_t k = blockIdx.x;
-    if (k >= n_act) return;
-    uint32_t s = act_site[k];
-    for (uint32_t e = ev_begin[s] + threadIdx.x; e < ev_end[s]; e += blockDim.x) ev_site[e] = s;
-}
-
-__global__ void k_word_flags(const uint8_t *info, const uint32_t *ev_site, const int32_t *site_act, const uint32_t *act_st, uint32_t E, uint32_t *flag) {
-    uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= E) return;
-    uint32_t s = ev_site[e];
-    uint32_t f = 0;
-    if (s != 0xFFFFFFFFu) {
-        uint8_t in = info[e];
-        int32_t k = site_act[s];
-        int side = (in >> 3) & 1;
-        if (k >= 0 && (act_st[k] & 4) && (act_st[k] & (1u << side)) && (in & 2)) f = 1;
+// one block per active site: which of its events start a word (first read of its query name on a kept side)
+__global__ __launch_bounds__(256) void k_word_flags(ConsensusIO io, uint32_t *flag) {
+    const uint32_t k = blockIdx.x;
+    if (k >= io.n_act) return;
+    const uint32_t st = io.act_st[k];
+    if (!(st & 4)) return;
+    const uint32_t s = io.act_site[k], mid = io.site_ev_mid[s];
+    for (uint32_t e = io.site_ev_begin[s] + threadIdx.x; e < io.site_ev_end[s]; e += blockDim.x) {
+        const uint32_t side = e >= mid ? 1u : 0u;
+        if ((st & (1u << side)) && (io.ev_info[e] & 2)) flag[e] = 1;
     }
-    flag[e] = f;
 }
 
 __global__ void k_job_meta(ConsensusIO io, const uint32_t *wid, Jobs J, CMeta *meta) {
@@ -129,49 +115,52 @@ __global__ void k_job_meta(ConsensusIO io, const uint32_t *wid, Jobs J, CMeta *m
     if (R) atomicMax(&meta->max_R, R);
 }
 
-// first / second read of every word (combine_softclip_seq_quals_*: one or two reads per name, findflanks.py:932-1027)
-__global__ void k_word_reads(DevReads R, DevParams P, ConsensusIO io, const uint32_t *ev_site, const uint32_t *wflag, const uint32_t *wid, const int32_t *site_act, Words W) {
-    uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= io.n_events) return;
-    uint32_t s = ev_site[e];
-    if (s == 0xFFFFFFFFu) return;
-    uint8_t in = io.ev_info[e];
-    int side = (in >> 3) & 1;
-    int32_t k = site_act[s];
-    if (k < 0 || !(io.act_st[k] & 4) || !(io.act_st[k] & (1u << side))) return;
-    uint64_t key = io.ev_keys[e];
-    int64_t r = (int64_t)(key & 0x7fffffffu);
-    if (in & 2) {
-        uint32_t w = wid[e];
-        W.first[w] = (int32_t)r;
-        W.job[w] = 2u * (uint32_t)k + (uint32_t)side;
-        return;
+// first / second read of every word (combine_softclip_seq_quals_*: one or two reads per name, findflanks.py:932-1027);
+// one block per active site
+__global__ __launch_bounds__(256) void k_word_reads(DevReads R, DevParams P, ConsensusIO io, const uint32_t *wflag, const uint32_t *wid, Words W) {
+    const uint32_t k = blockIdx.x;
+    if (k >= io.n_act) return;
+    const uint32_t st = io.act_st[k];
+    if (!(st & 4)) return;
+    const uint32_t s = io.act_site[k], ev_mid = io.site_ev_mid[s];
+    for (uint32_t e = io.site_ev_begin[s] + threadIdx.x; e < io.site_ev_end[s]; e += blockDim.x) {
+        const int side = e >= ev_mid ? 1 : 0;
+        if (!(st & (1u << side))) continue;
+        const uint8_t in = io.ev_info[e];
+        const uint64_t key = io.ev_keys[e];
+        const int64_t r = (int64_t)(key & 0x7fffffffu);
+        if (in & 2) {
+            const uint32_t w = wid[e];
+            W.first[w] = (int32_t)r;
+            W.job[w] = 2u * k + (uint32_t)side;
+            continue;
+        }
+        // not the first read of its name here: find the first one (earliest read of the chain with the same event)
+        const uint32_t gpos = (uint32_t)(key >> 32);
+        const uint16_t contig = R.contig_id[r];
+        const uint32_t base = R.contig_base[contig];
+        int64_t root = -1, prev = r;
+        for (int64_t q = R.link[r]; q >= 0 && q < prev; prev = q, q = R.link[q]) {
+            int32_t site;
+            if (R.contig_id[q] == contig && d_clip_event(R, P, q, side, &site) && base + (uint32_t)(site + 1) == gpos) root = q;
+        }
+        if (root < 0) continue;   // cannot happen: info bit 2 is clear exactly when such a read exists
+        // its event: binary search by key in this site-side's range
+        uint32_t lo = side == 0 ? io.site_ev_begin[s] : ev_mid;
+        uint32_t hi = side == 0 ? ev_mid : io.site_ev_end[s];
+        const uint32_t hi0 = hi;
+        const uint64_t want = (key & ~(uint64_t)0x7fffffffu) | (uint64_t)root;
+        while (lo < hi) { uint32_t m = (lo + hi) >> 1; if (io.ev_keys[m] < want) lo = m + 1; else hi = m; }
+        if (lo >= hi0 || io.ev_keys[lo] != want || !wflag[lo]) continue;
+        const uint32_t w = wid[lo];
+        atomicAdd(&W.nextra[w], 1u);
+        W.second[w] = (int32_t)r;
     }
-    // not the first read of its name here: find the first one (earliest read of the chain with the same event)
-    uint32_t gpos = (uint32_t)(key >> 32);
-    uint16_t contig = R.contig_id[r];
-    uint32_t base = R.contig_base[contig];
-    int64_t root = -1, prev = r;
-    for (int64_t q = R.link[r]; q >= 0 && q < prev; prev = q, q = R.link[q]) {
-        int32_t site;
-        if (R.contig_id[q] == contig && d_clip_event(R, P, q, side, &site) && base + (uint32_t)(site + 1) == gpos) root = q;
-    }
-    if (root < 0) return;   // cannot happen: info bit 2 is clear exactly when such a read exists
-    // its event: binary search by key in this site-side's range
-    uint32_t lo = side == 0 ? io.site_ev_begin[s] : io.site_ev_mid[s];
-    uint32_t hi = side == 0 ? io.site_ev_mid[s] : io.site_ev_end[s];
-    const uint32_t hi0 = hi;
-    uint64_t want = (key & ~(uint64_t)0x7fffffffu) | (uint64_t)root;
-    while (lo < hi) { uint32_t m = (lo + hi) >> 1; if (io.ev_keys[m] < want) lo = m + 1; else hi = m; }
-    if (lo >= hi0 || io.ev_keys[lo] != want || !wflag[lo]) return;
-    uint32_t w = wid[lo];
-    atomicAdd(&W.nextra[w], 1u);
-    W.second[w] = (int32_t)r;
 }
 
-__global__ void k_word_len(DevReads R, Words W, CMeta *meta) {
+__global__ void k_word_len(DevReads R, Words W, const uint32_t *n_words, CMeta *meta) {
     uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
-    if (w >= W.n) return;
+    if (w >= *n_words) return;
     int side = (int)(W.job[w] & 1);
     int64_t r1 = W.first[w], r2 = W.second[w];
     if (W.nextra[w] > 1) atomicOr(&meta->err, ERR_READ_NUMBER);      // findflanks.py:976-978 / 1025-1027
@@ -696,39 +685,63 @@ __global__ __launch_bounds__(512) void k_cluster_vote(DevParams P, Words W, Jobs
     }
 }
 
-__global__ __launch_bounds__(64) void k_emit_best(Jobs J, ConsensusIO io, const char *cl_chars, uint32_t cl_stride) {
-    uint32_t job = blockIdx.x;
+// one block per job: filters + best consensus (findflanks.py:241-346): max by (count, len), the last in list order
+// wins ties; list order = singletons in leaf (DFS) order, then components by their first leaf (quirk Q12 build rule),
+// which is the order of cl_key.  Then the winner's characters are copied to the job's output row.
+__global__ __launch_bounds__(256) void k_job_best(DevParams P, Words W, Jobs J, ConsensusIO io, const char *cl_chars, uint32_t cl_stride) {
+    __shared__ uint32_t s_npl, s_npb;
+    __shared__ unsigned long long s_hi;   // (count << 32) | len of the best
+    __shared__ uint32_t s_key, s_slot;
+    const uint32_t job = blockIdx.x;
     if (job >= J.n) return;
-    uint32_t slot = J.best[job];
-    if (slot == 0xFFFFFFFFu) return;
-    int len = io.cons_len[job];
-    const char *src = cl_chars + (size_t)slot * cl_stride;
-    char *dst = io.cons_chars + (size_t)job * io.cons_stride;
-    for (int d = threadIdx.x; d < len; d += blockDim.x) dst[d] = src[d];
-}
-
-// one thread per job: filters + best consensus (findflanks.py:241-346): max by (count, len), the last in list order
-// wins ties; list order = singletons in leaf (DFS) order, then components by their first leaf (quirk Q12 build rule)
-__global__ void k_job_best(DevParams P, Words W, Jobs J, ConsensusIO io) {
-    uint32_t job = blockIdx.x * blockDim.x + threadIdx.x;
-    if (job >= J.n) return;
-    uint32_t w0 = J.w0[job], nl = J.nl[job];
-    uint32_t npl = 0, npb = 0, best = 0xFFFFFFFFu;
-    int32_t bc = 0, bl = 0; uint32_t bk = 0;
-    for (uint32_t k = 0; k < nl; k++) {
-        uint32_t slot = w0 + k;
+    const uint32_t w0 = J.w0[job], nl = J.nl[job];
+    if (threadIdx.x == 0) { s_npl = 0; s_npb = 0; s_hi = 0; s_key = 0; s_slot = 0xFFFFFFFFu; }
+    __syncthreads();
+    uint32_t npl = 0, npb = 0;
+    for (uint32_t k = threadIdx.x; k < nl; k += blockDim.x) {
+        const uint32_t slot = w0 + k;
         if (W.label[slot] != k) continue;
-        int32_t cnt = W.cl_count[slot], len = W.cl_len[slot];
-        uint32_t key = W.cl_key[slot];
+        const int32_t cnt = W.cl_count[slot], len = W.cl_len[slot];
         if (len < P.minlen) continue;
         npl++;
         if (cnt < P.mincount) continue;
         npb++;
-        if (best == 0xFFFFFFFFu || cnt > bc || (cnt == bc && (len > bl || (len == bl && key > bk)))) { best = slot; bc = cnt; bl = len; bk = key; }
+        atomicMax(&s_hi, ((unsigned long long)(uint32_t)cnt << 32) | (unsigned long long)(uint32_t)len);
     }
-    io.n_pass_len[job] = npl; io.n_pass_both[job] = npb;
-    J.best[job] = best;
-    if (best != 0xFFFFFFFFu) { io.cons_count[job] = bc; io.cons_len[job] = bl; }
+    if (npl) atomicAdd(&s_npl, npl);
+    if (npb) atomicAdd(&s_npb, npb);
+    __syncthreads();
+    const unsigned long long hi = s_hi;
+    const bool any = s_npb > 0;
+    if (any)
+        for (uint32_t k = threadIdx.x; k < nl; k += blockDim.x) {
+            const uint32_t slot = w0 + k;
+            if (W.label[slot] != k) continue;
+            const int32_t cnt = W.cl_count[slot], len = W.cl_len[slot];
+            if (len < P.minlen || cnt < P.mincount) continue;
+            if ((((unsigned long long)(uint32_t)cnt << 32) | (unsigned long long)(uint32_t)len) == hi) atomicMax(&s_key, W.cl_key[slot] + 1u);   // +1: key 0 is a valid key
+        }
+    __syncthreads();
+    if (any)
+        for (uint32_t k = threadIdx.x; k < nl; k += blockDim.x) {
+            const uint32_t slot = w0 + k;
+            if (W.label[slot] != k) continue;
+            const int32_t cnt = W.cl_count[slot], len = W.cl_len[slot];
+            if (len < P.minlen || cnt < P.mincount) continue;
+            if ((((unsigned long long)(uint32_t)cnt << 32) | (unsigned long long)(uint32_t)len) == hi && W.cl_key[slot] + 1u == s_key) s_slot = slot;
+        }
+    __syncthreads();
+    const uint32_t best = s_slot;
+    if (threadIdx.x == 0) {
+        io.n_pass_len[job] = s_npl; io.n_pass_both[job] = s_npb;
+        J.best[job] = best;
+        if (best != 0xFFFFFFFFu) { io.cons_count[job] = (int32_t)(hi >> 32); io.cons_len[job] = (int32_t)(hi & 0xFFFFFFFFull); }
+    }
+    if (best == 0xFFFFFFFFu) return;
+    const int len = (int)(hi & 0xFFFFFFFFull);
+    const char *src = cl_chars + (size_t)best * cl_stride;
+    char *dst = io.cons_chars + (size_t)job * io.cons_stride;
+    for (int d = threadIdx.x; d < len; d += blockDim.x) dst[d] = src[d];
 }
 
 // =====================================================================================================================
@@ -737,69 +750,55 @@ int run_consensus(mfk_ctx *ctx, const DevReads &R, const DevParams &P, Consensus
     const uint32_t E = io.n_events, n_act = io.n_act;
     io.cons_chars = nullptr; io.cons_stride = 0;
     if (!E || !n_act) return 0;
-    const unsigned eb = nblocks(E, 256);
-    // site -> active index, event -> site
-    // (site table capacity is E)
-    int32_t *site_act = aalloc<int32_t>(ctx, E);
-    uint32_t *ev_site = aalloc<uint32_t>(ctx, E), *wflag = aalloc<uint32_t>(ctx, E), *wid = aalloc<uint32_t>(ctx, (size_t)E + 1);
-    CMeta *meta = aalloc<CMeta>(ctx, 1);
-    if (!site_act || !ev_site || !wflag || !wid || !meta) return 1;
-    HIPCHK(hipMemsetAsync(site_act, 0xFF, (size_t)E * 4, st));
-    HIPCHK(hipMemsetAsync(ev_site, 0xFF, (size_t)E * 4, st));
-    HIPCHK(hipMemsetAsync(meta, 0, sizeof(CMeta), st));
-    PROF_LAUNCH(k_site_act_map, dim3(nblocks(n_act, 256)), dim3(256), 0, st, io.act_site, n_act, site_act);
-    KCHK();
-    PROF_LAUNCH(k_fill_ev_site, dim3(n_act), dim3(64), 0, st, io.act_site, n_act, io.site_ev_begin, io.site_ev_end, ev_site);
-    KCHK();
-    PROF_LAUNCH(k_word_flags, dim3(eb), dim3(256), 0, st, io.ev_info, (const uint32_t *)ev_site, (const int32_t *)site_act, io.act_st, E, wflag);
-    KCHK();
-    if (int rc = dev_excl_scan32(ctx, wflag, wid, E)) return rc;
+    // words of the active sites: flags -> ids.  The word tables are sized by the event count (an upper bound), so the
+    // host reads the sizes it needs (words, adjacency words, characters, longest word) back in ONE batch.
+    uint32_t *wflag = nullptr, *wid = aalloc<uint32_t>(ctx, (size_t)E + 1);
+    CMeta *meta = nullptr;
+    Words W; memset(&W, 0, sizeof W);
     Jobs J; memset(&J, 0, sizeof J);
     J.n = 2 * n_act;
     J.w0 = aalloc<uint32_t>(ctx, J.n); J.R = aalloc<uint32_t>(ctx, J.n); J.nl = aalloc<uint32_t>(ctx, J.n);
     J.adj_words = aalloc<uint32_t>(ctx, J.n); J.adj_off = aalloc<uint64_t>(ctx, (size_t)J.n + 1); J.best = aalloc<uint32_t>(ctx, J.n); J.giant = aalloc<uint32_t>(ctx, J.n); J.longest = aalloc<uint32_t>(ctx, 4 * (size_t)J.n);
-    if (!J.w0 || !J.R || !J.nl || !J.adj_words || !J.adj_off || !J.best || !J.giant || !J.longest) return 1;
+    W.first = aalloc<int32_t>(ctx, E); W.job = aalloc<uint32_t>(ctx, E); W.len = aalloc<uint32_t>(ctx, E);
+    W.off = aalloc<uint64_t>(ctx, (size_t)E + 1); W.is_leaf = aalloc<uint8_t>(ctx, E); W.leaf_word = aalloc<uint32_t>(ctx, E);
+    W.cl_count = aalloc<int32_t>(ctx, E); W.cl_len = aalloc<int32_t>(ctx, E); W.cl_key = aalloc<uint32_t>(ctx, E);
+    W.leaf_list = aalloc<uint32_t>(ctx, E); W.rep_list = aalloc<uint32_t>(ctx, E); W.share = aalloc<uint32_t>(ctx, E);
+    {
+        FillGroup z(ctx, 0), f(ctx, 0xFF);
+        z.want(&wflag, E); z.want(&meta, 1); z.want(&W.nextra, E); z.want(&W.plen, E); z.want(&W.leaf_rank, E);
+        z.want(&W.has_match, E); z.want(&W.n_list, 2);
+        f.want(&W.second, E); f.want(&W.label, E); f.want(&W.cover, E);
+        if (!wid || !J.w0 || !J.R || !J.nl || !J.adj_words || !J.adj_off || !J.best || !J.giant || !J.longest || !W.first || !W.job || !W.len || !W.off ||
+            !W.is_leaf || !W.leaf_word || !W.cl_count || !W.cl_len || !W.cl_key || !W.leaf_list || !W.rep_list || !W.share || z.commit() || f.commit()) return 1;
+    }
+    PROF_LAUNCH(k_word_flags, dim3(n_act), dim3(256), 0, st, io, wflag);
+    KCHK();
+    if (int rc = dev_excl_scan32(ctx, wflag, wid, E)) return rc;
     PROF_LAUNCH(k_job_meta, dim3(nblocks(J.n, 256)), dim3(256), 0, st, io, (const uint32_t *)wid, J, meta);
     KCHK();
     if (int rc = dev_excl_scan64(ctx, J.adj_words, J.adj_off, J.n)) return rc;
+    PROF_LAUNCH(k_word_reads, dim3(n_act), dim3(256), 0, st, R, P, io, (const uint32_t *)wflag, (const uint32_t *)wid, W);
+    KCHK();
+    PROF_LAUNCH(k_word_len, dim3(nblocks(E, 256)), dim3(256), 0, st, R, W, (const uint32_t *)(wid + E), meta);
+    KCHK();
+    if (int rc = dev_excl_scan64(ctx, W.plen, W.off, E)) return rc;   // plen is 0 beyond the last word: off[E] = all characters
     uint32_t Wn = 0; uint64_t adj_total = 0;
-    { ReadBatch rb(ctx); rb.add(wid + E, &Wn, 4); rb.add(J.adj_off + J.n, &adj_total, 8); if (int rc = rb.flush()) return rc; }
-    if (Wn == 0) return 0;
-    Words W; memset(&W, 0, sizeof W);
-    W.n = Wn;
-    W.first = aalloc<int32_t>(ctx, Wn); W.second = aalloc<int32_t>(ctx, Wn); W.nextra = aalloc<uint32_t>(ctx, Wn);
-    W.job = aalloc<uint32_t>(ctx, Wn); W.len = aalloc<uint32_t>(ctx, Wn); W.plen = aalloc<uint32_t>(ctx, Wn);
-    W.off = aalloc<uint64_t>(ctx, (size_t)Wn + 1); W.is_leaf = aalloc<uint8_t>(ctx, Wn); W.leaf_word = aalloc<uint32_t>(ctx, Wn);
-    W.leaf_rank = aalloc<uint32_t>(ctx, Wn); W.label = aalloc<uint32_t>(ctx, Wn); W.has_match = aalloc<uint8_t>(ctx, Wn);
-    W.cl_count = aalloc<int32_t>(ctx, Wn); W.cl_len = aalloc<int32_t>(ctx, Wn); W.cl_key = aalloc<uint32_t>(ctx, Wn);
-    W.leaf_list = aalloc<uint32_t>(ctx, Wn); W.rep_list = aalloc<uint32_t>(ctx, Wn); W.n_list = aalloc<uint32_t>(ctx, 2);
-    J.adj = aalloc<uint32_t>(ctx, (size_t)adj_total);
-    if (!W.first || !W.second || !W.nextra || !W.job || !W.len || !W.plen || !W.off || !W.is_leaf || !W.leaf_word || !W.leaf_rank || !W.label || !W.has_match || !W.cl_count || !W.cl_len || !W.cl_key || !J.adj || !W.leaf_list || !W.rep_list || !W.n_list) return 1;
-    HIPCHK(hipMemsetAsync(W.second, 0xFF, (size_t)Wn * 4, st));
-    HIPCHK(hipMemsetAsync(W.nextra, 0, (size_t)Wn * 4, st));
-    HIPCHK(hipMemsetAsync(W.leaf_rank, 0, (size_t)Wn * 4, st));
-    HIPCHK(hipMemsetAsync(W.has_match, 0, (size_t)Wn, st));
-    HIPCHK(hipMemsetAsync(W.n_list, 0, 8, st));
-    HIPCHK(hipMemsetAsync(W.label, 0xFF, (size_t)Wn * 4, st));
-    HIPCHK(hipMemsetAsync(J.adj, 0, (size_t)(adj_total ? adj_total : 1) * 4, st));
-    const unsigned wb = nblocks(Wn, 256), ww = nblocks(Wn, 4);
-    PROF_LAUNCH(k_word_reads, dim3(eb), dim3(256), 0, st, R, P, io, (const uint32_t *)ev_site, (const uint32_t *)wflag, (const uint32_t *)wid, (const int32_t *)site_act, W);
-    KCHK();
-    PROF_LAUNCH(k_word_len, dim3(wb), dim3(256), 0, st, R, W, meta);
-    KCHK();
-    if (int rc = dev_excl_scan64(ctx, W.plen, W.off, Wn)) return rc;
     CMeta hm; uint64_t total_chars = 0;
-    { ReadBatch rb(ctx); rb.add(meta, &hm, sizeof hm); rb.add(W.off + Wn, &total_chars, 8); if (int rc = rb.flush()) return rc; }
+    { ReadBatch rb(ctx); rb.add(wid + E, &Wn, 4); rb.add(J.adj_off + J.n, &adj_total, 8); rb.add(meta, &hm, sizeof hm); rb.add(W.off + E, &total_chars, 8); if (int rc = rb.flush()) return rc; }
+    if (Wn == 0) return 0;
+    W.n = Wn;
+    const unsigned ww = nblocks(Wn, 4);
     if (hm.err & ERR_READ_NUMBER) { snprintf(ctx->err, sizeof ctx->err, "READ NUMBER ERROR - ZERO OR MORE THAN TWO READS ASSOCIATED WITH QUERY NAME"); return 3; }
     if (hm.err & ERR_WORD_TOO_LONG) { snprintf(ctx->err, sizeof ctx->err, "soft clip longer than %d bases: not supported by this build", MAX_WORD_LEN); return 6; }
+    {
+        FillGroup z(ctx, 0);
+        z.want(&J.adj, (size_t)adj_total); z.want(&W.agg, (size_t)total_chars + 8);
+        if (z.commit()) return 1;
+    }
     W.ch = aalloc<uint8_t>(ctx, (size_t)total_chars + 64); W.q = aalloc<uint8_t>(ctx, (size_t)total_chars + 64);
     if (total_chars >= 0xFFFFFFF0ull) { snprintf(ctx->err, sizeof ctx->err, "more than 2^32 clipped bases at the surviving sites of one call"); return 1; }
     W.npos = aalloc<uint32_t>(ctx, (size_t)total_chars + 8);
-    W.agg = aalloc<NodeSum>(ctx, (size_t)total_chars + 8);
-    W.cover = aalloc<uint32_t>(ctx, Wn); W.share = aalloc<uint32_t>(ctx, Wn);
-    if (!W.ch || !W.q || !W.npos || !W.agg || !W.cover || !W.share) return 1;
-    HIPCHK(hipMemsetAsync(W.agg, 0, ((size_t)total_chars + 8) * sizeof(NodeSum), st));
-    HIPCHK(hipMemsetAsync(W.cover, 0xFF, (size_t)Wn * 4, st));
+    if (!W.ch || !W.q || !W.npos) return 1;
     PROF_LAUNCH(k_word_fill, dim3(ww), dim3(256), 0, st, R, W, meta);
     KCHK();
     PROF_LAUNCH(k_job_longest, dim3(J.n), dim3(256), 0, st, W, J);
@@ -840,9 +839,7 @@ int run_consensus(mfk_ctx *ctx, const DevReads &R, const DevParams &P, Consensus
     KCHK();
     PROF_LAUNCH(k_cluster_vote, dim3(g_rep), dim3(512), lds, st, P, W, J, max_len, cl_chars, io.cons_stride);
     KCHK();
-    PROF_LAUNCH(k_job_best, dim3(nblocks(J.n, 256)), dim3(256), 0, st, P, W, J, io);
-    KCHK();
-    PROF_LAUNCH(k_emit_best, dim3(J.n), dim3(64), 0, st, J, io, (const char *)cl_chars, io.cons_stride);
+    PROF_LAUNCH(k_job_best, dim3(J.n), dim3(256), 0, st, P, W, J, io, (const char *)cl_chars, io.cons_stride);
     KCHK();
     io.err_dev = &meta->err;   // ERR_NO_SEQUENCE can still be raised by k_word_fill: the caller reads it with the results
     return 0;

@@ -16,6 +16,7 @@ struct DevReads {
     const uint16_t *contig_id, *qlen, *first_op_len, *last_op_len;
     const uint8_t *mapq, *flags;
     int32_t n_contigs, max_span;
+    uint32_t gpos_span;              // length of the flat site axis (all contigs + gaps)
     const int32_t *contig_len;       // n_contigs
     const int64_t *contig_rs;        // n_contigs + 1
     const uint32_t *contig_base;     // n_contigs: offset of the contig in the flat "gpos" coordinate (see mfk.hip)

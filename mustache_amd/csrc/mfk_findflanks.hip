@@ -31,18 +31,30 @@
 #define EV_STAGE 2048
 #define SCAN_TILE (SCAN_THREADS * 16)
 
+// Site bitmaps over the gpos axis.  `all`: a site exists (its first setter counts it: "sites after parse").  `strong`:
+// some clip at the site meets min_softclip_length on its side, i.e. the site survives filter_softclips_minlength
+// (findflanks.py:124-145).  Only the events of strong sites go on to the sort and the site table: at 1000x they are
+// ~8 % of all events, the rest are single mismatches at read ends scattered over the genome.
+struct SiteMaps { uint32_t *all, *strong; };
+
 __device__ __forceinline__ void d_stage_event(uint64_t key, uint64_t *stage, uint32_t *s_n, uint64_t *ev, uint32_t *ev_count, uint32_t cap) {
     uint32_t slot = atomicAdd(s_n, 1u);
     if (slot < EV_STAGE) stage[slot] = key;
     else { uint32_t g = atomicAdd(ev_count, 1u); if (g < cap) ev[g] = key; }   // deeper than the stage: rare slow path
 }
 
-__global__ __launch_bounds__(SCAN_THREADS) void k_scan_clips(DevReads R, DevParams P, uint64_t *ev, uint32_t *ev_count, uint32_t cap) {
+__device__ __forceinline__ void d_mark_site(const SiteMaps &M, uint32_t gpos, bool strong, uint32_t *s_new) {
+    const uint32_t bit = 1u << (gpos & 31);
+    if (!(atomicOr(&M.all[gpos >> 5], bit) & bit)) atomicAdd(s_new, 1u);
+    if (strong && M.strong) atomicOr(&M.strong[gpos >> 5], bit);
+}
+
+__global__ __launch_bounds__(SCAN_THREADS) void k_scan_clips(DevReads R, DevParams P, uint64_t *ev, uint32_t *ev_count, uint32_t cap, SiteMaps M, uint32_t *n_sites_all) {
     __shared__ uint64_t stage[EV_STAGE];
     __shared__ uint32_t cl_r[SCAN_TILE];
     __shared__ uint8_t cl_f[SCAN_TILE];
-    __shared__ uint32_t s_n, s_base, s_ncl;
-    if (threadIdx.x == 0) { s_n = 0; s_ncl = 0; }
+    __shared__ uint32_t s_n, s_base, s_ncl, s_new;
+    if (threadIdx.x == 0) { s_n = 0; s_ncl = 0; s_new = 0; }
     __syncthreads();
     const int64_t ngroups = (R.n + 15) >> 4;
     const int64_t ntiles = (ngroups + SCAN_THREADS - 1) / SCAN_THREADS;
@@ -82,11 +94,15 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_clips(DevReads R, DevPara
             if (lk && rk && ql - rlen - llen < P.minial) continue;
             if (rk) {   // right clip -> 5p site (findflanks.py:117-118, 594-597); d_rsite
                 const int32_t site = rk == 1 ? re : re - 1;
-                d_stage_event(((uint64_t)(base + (uint32_t)(site + 1)) << 32) | (uint64_t)(uint32_t)r, stage, &s_n, ev, ev_count, cap);
+                const uint32_t gpos = base + (uint32_t)(site + 1);
+                d_mark_site(M, gpos, lo >= P.minlen, &s_new);   // meets_minlength_right: raw length of the last CIGAR op (quirk Q1)
+                d_stage_event(((uint64_t)gpos << 32) | (uint64_t)(uint32_t)r, stage, &s_n, ev, ev_count, cap);
             }
             if (lk) {   // left clip -> 3p site (findflanks.py:120-121, 599-602); d_lsite
                 const int32_t site = lk == 1 ? rs - 1 : rs;
-                d_stage_event(((uint64_t)(base + (uint32_t)(site + 1)) << 32) | (1ull << 31) | (uint64_t)(uint32_t)r, stage, &s_n, ev, ev_count, cap);
+                const uint32_t gpos = base + (uint32_t)(site + 1);
+                d_mark_site(M, gpos, fo >= P.minlen, &s_new);   // meets_minlength_left: raw length of the first CIGAR op
+                d_stage_event(((uint64_t)gpos << 32) | (1ull << 31) | (uint64_t)(uint32_t)r, stage, &s_n, ev, ev_count, cap);
             }
         }
         __syncthreads();
@@ -104,8 +120,40 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_clips(DevReads R, DevPara
     }
     const uint32_t n = s_n < EV_STAGE ? s_n : EV_STAGE;
     if (threadIdx.x == 0 && n) s_base = atomicAdd(ev_count, n);
+    if (threadIdx.x == 0 && s_new) atomicAdd(n_sites_all, s_new);
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < n; i += SCAN_THREADS) if (s_base + i < cap) ev[s_base + i] = stage[i];
+}
+
+// events of strong sites -> ev2 (order arbitrary, the sort follows)
+__global__ __launch_bounds__(256) void k_keep_strong(const uint64_t *ev, const uint32_t *ev_count, uint32_t cap, const uint32_t *strong, uint64_t *ev2, uint32_t *ev2_count) {
+    __shared__ uint64_t stage[EV_STAGE];
+    __shared__ uint32_t s_n, s_base;
+    const uint32_t E = *ev_count < cap ? *ev_count : cap;
+    if (threadIdx.x == 0) s_n = 0;
+    __syncthreads();
+    for (uint32_t base = blockIdx.x * 256; base < E; base += gridDim.x * 256) {
+        const uint32_t i = base + threadIdx.x;
+        if (i < E) {
+            const uint64_t key = ev[i];
+            const uint32_t g = (uint32_t)(key >> 32);
+            if ((strong[g >> 5] >> (g & 31)) & 1) stage[atomicAdd(&s_n, 1u)] = key;   // at most 256 per round: the stage has room
+        }
+        __syncthreads();
+        if (s_n > EV_STAGE - 256) {
+            const uint32_t n = s_n;
+            if (threadIdx.x == 0) s_base = atomicAdd(ev2_count, n);
+            __syncthreads();
+            for (uint32_t k = threadIdx.x; k < n; k += 256) ev2[s_base + k] = stage[k];
+            __syncthreads();
+            if (threadIdx.x == 0) s_n = 0;
+        }
+        __syncthreads();
+    }
+    const uint32_t n = s_n;
+    if (threadIdx.x == 0 && n) s_base = atomicAdd(ev2_count, n);
+    __syncthreads();
+    for (uint32_t k = threadIdx.x; k < n; k += 256) ev2[s_base + k] = stage[k];
 }
 
 // ---- K2: per-event information ---------------------------------------------------------------------------------
@@ -159,60 +207,41 @@ __global__ void k_site_accumulate(DevReads R, const uint64_t *keys, const uint8_
     if (in & 4) atomicOr(&T.sflags[s], 1u << side);
 }
 
-__global__ void k_site_init(SiteTab T, const uint32_t *n_sites_p, uint32_t *stats) {
+// site state + filter_softclips_minlength (findflanks.py:124-145) + filter_softclips_mincount (148-169) in one pass;
+// `upto`: 0 = state only, 1 = + minlength, 2 = + mincount
+__global__ void k_site_filters(SiteTab T, const uint32_t *n_sites_p, int mincount, int upto, uint32_t *stats) {
     uint32_t n = *n_sites_p;
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    int alive1 = 0, alive2 = 0;
     if (i < n) {
-        T.st[i] = 7;
         if (T.ev_mid[i] == 0xFFFFFFFFu) T.ev_mid[i] = T.ev_end[i];
-    }
-    if (i == 0) stats[0] = n;
-}
-
-// filter_softclips_minlength findflanks.py:124-145
-__global__ void k_filter_minlength(SiteTab T, const uint32_t *n_sites_p, uint32_t *stats) {
-    uint32_t n = *n_sites_p;
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    int alive = 0;
-    if (i < n) {
-        uint32_t s = T.st[i];
-        if (s & 4) {
+        uint32_t s = 7;
+        if (upto >= 1) {
             uint32_t m = T.sflags[i];
             if (!(m & 1)) s &= ~1u;
             if (!(m & 2)) s &= ~2u;
             if (!(s & 3)) s &= ~4u;
-            T.st[i] = s;
-            alive = (s >> 2) & 1;
+            alive1 = (s >> 2) & 1;
         }
-    }
-    int c = __syncthreads_count(alive);
-    if (threadIdx.x == 0 && c) atomicAdd(&stats[1], (uint32_t)c);
-}
-
-// filter_softclips_mincount findflanks.py:148-169
-__global__ void k_filter_mincount(SiteTab T, const uint32_t *n_sites_p, int mincount, uint32_t *stats) {
-    uint32_t n = *n_sites_p;
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    int alive = 0;
-    if (i < n) {
-        uint32_t s = T.st[i];
-        if (s & 4) {
+        if (upto >= 2 && (s & 4)) {
             if ((int64_t)T.cnt2[2 * i] < (int64_t)mincount) s &= ~1u;
             if ((int64_t)T.cnt2[2 * i + 1] < (int64_t)mincount) s &= ~2u;
             if (!(s & 3)) s &= ~4u;
-            T.st[i] = s;
-            alive = (s >> 2) & 1;
+            alive2 = (s >> 2) & 1;
         }
+        T.st[i] = s;
     }
-    int c = __syncthreads_count(alive);
-    if (threadIdx.x == 0 && c) atomicAdd(&stats[2], (uint32_t)c);
+    int c1 = __syncthreads_count(alive1);
+    int c2 = __syncthreads_count(alive2);
+    if (threadIdx.x == 0 && c1) atomicAdd(&stats[1], (uint32_t)c1);
+    if (threadIdx.x == 0 && c2) atomicAdd(&stats[2], (uint32_t)c2);
 }
 
 // filter_softclips_mindistance findflanks.py:171-200.  A site with 5p clips needs a surviving site with 3p clips at a
 // strictly smaller position within mindist (misc.takeClosestSmaller, has_nearby_3p_mate 551-558); a site with 3p clips
 // needs a surviving 5p site strictly to the right (has_nearby_5p_mate 542-549).  Counts decide, not keep flags (Q5).
 // The table is sorted by gpos with distinct positions; dead sites are skipped (they left the dict in an earlier round).
-__global__ void k_mindistance(const uint32_t *gpos, const uint32_t *cnt2, const uint32_t *st_in, uint32_t *st_out, const uint32_t *n_p, uint32_t n_val, int mindist, uint32_t *stat) {
+__global__ void k_mindistance(const uint32_t *gpos, const uint32_t *cnt2, const uint32_t *st_in, uint32_t *st_out, const uint32_t *n_p, uint32_t n_val, int mindist, uint32_t *stat, uint32_t *alive_flag) {
     uint32_t n = n_p ? *n_p : n_val;
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     int alive = 0;
@@ -239,6 +268,7 @@ __global__ void k_mindistance(const uint32_t *gpos, const uint32_t *cnt2, const 
             alive = (s >> 2) & 1;
         }
         st_out[i] = s;
+        if (alive_flag) alive_flag[i] = (s >> 2) & 1;
     }
     int c = __syncthreads_count(alive);
     if (threadIdx.x == 0 && c) atomicAdd(stat, (uint32_t)c);
@@ -381,33 +411,42 @@ extern "C" int mfk_findflanks(mfk_ctx *ctx, const mfk_reads *reads, const mfk_pa
     if (int rc = upload_reads(ctx, reads, params, &R, &P)) return rc;
     hipStream_t st = ctx->stream;
     HIPCHK(hipEventRecord(ctx->ev0, st));
-    uint32_t *d_stats = aalloc<uint32_t>(ctx, MFK_N_STATS);
-    if (!d_stats) return 1;
-    HIPCHK(hipMemsetAsync(d_stats, 0, MFK_N_STATS * 4, st));
-
-    // ---- stage 1: parse_softclips -------------------------------------------------------------------------------
+    // (stage 1 below) -------------------------------------------------------------------------------
     const int64_t ngroups = (R.n + 15) >> 4;
     unsigned nblk = (unsigned)((ngroups + SCAN_THREADS - 1) / SCAN_THREADS);
     if (nblk > SCAN_MAX_BLOCKS) nblk = SCAN_MAX_BLOCKS;
     if (nblk < 1) nblk = 1;
-    uint32_t *ev_count = aalloc<uint32_t>(ctx, 1);
-    if (!ev_count) return 1;
-    uint32_t E = 0;
+    // from the minlength filter on only strong sites matter: their events alone are sorted (k_keep_strong)
+    const bool prefilter = stop_after >= MFK_STAGE_MINLENGTH;
+    const size_t bm_words = ((size_t)R.gpos_span >> 5) + 2;
+    uint32_t *d_stats = nullptr, *ev_count = nullptr;
+    SiteMaps M; M.all = nullptr; M.strong = nullptr;
+    uint32_t E_all = 0, E = 0;
     uint64_t *ev = nullptr;
     uint64_t cap64 = (uint64_t)R.n / 8 + 65536;            // clips are a few percent of the reads; grown on overflow
     for (int attempt = 0; attempt < 2; attempt++) {
         if (cap64 > 2 * (uint64_t)R.n + 16) cap64 = 2 * (uint64_t)R.n + 16;
         if (cap64 > 0xFFFFFFF0ull) { snprintf(ctx->err, sizeof ctx->err, "more than 2^32 soft-clip events in one call"); return 1; }
-        ev = aalloc<uint64_t>(ctx, (size_t)cap64);
-        if (!ev) return 1;
-        HIPCHK(hipMemsetAsync(ev_count, 0, 4, st));
-        PROF_LAUNCH(k_scan_clips, dim3(nblk), dim3(SCAN_THREADS), 0, st, R, P, ev, ev_count, (uint32_t)cap64);
+        uint64_t *ev_all = aalloc<uint64_t>(ctx, (size_t)cap64);
+        ev = prefilter ? aalloc<uint64_t>(ctx, (size_t)cap64) : ev_all;
+        if (!ev_all || !ev) return 1;
+        FillGroup z(ctx, 0);
+        z.want(&d_stats, MFK_N_STATS); z.want(&ev_count, 4); z.want(&M.all, bm_words);
+        if (prefilter) z.want(&M.strong, bm_words);
+        if (z.commit()) return 1;
+        PROF_LAUNCH(k_scan_clips, dim3(nblk), dim3(SCAN_THREADS), 0, st, R, P, ev_all, ev_count, (uint32_t)cap64, M, d_stats);
         KCHK();
-        if (int rc = read_back(ctx, ev_count, &E, 4)) return rc;
-        if ((uint64_t)E <= cap64) break;
-        cap64 = (uint64_t)E + 16;                            // every event was counted: exact size for the second try
+        if (prefilter) {
+            PROF_LAUNCH(k_keep_strong, dim3(256), dim3(256), 0, st, (const uint64_t *)ev_all, (const uint32_t *)ev_count, (uint32_t)cap64, (const uint32_t *)M.strong, ev, ev_count + 1);
+            KCHK();
+        }
+        uint32_t h_cnt[2] = {0, 0};
+        if (int rc = read_back(ctx, ev_count, h_cnt, 8)) return rc;
+        E_all = h_cnt[0]; E = prefilter ? h_cnt[1] : h_cnt[0];
+        if ((uint64_t)E_all <= cap64) break;
+        cap64 = (uint64_t)E_all + 16;                        // every event was counted: exact size for the second try
     }
-    ctx->stats[10] = E;
+    ctx->stats[10] = E_all;
 
     uint32_t n_act = 0;
     ActTab A; memset(&A, 0, sizeof A);
@@ -420,15 +459,14 @@ extern "C" int mfk_findflanks(mfk_ctx *ctx, const mfk_reads *reads, const mfk_pa
         if (int rc = dev_sort_keys64(ctx, ev, ev_sorted, E, 0, 64)) return rc;
         ev_info = aalloc<uint8_t>(ctx, E);
         uint32_t *head = aalloc<uint32_t>(ctx, E), *head_scan = aalloc<uint32_t>(ctx, (size_t)E + 1);
-        T.gpos = aalloc<uint32_t>(ctx, E); T.contig = aalloc<int32_t>(ctx, E); T.cnt2 = aalloc<uint32_t>(ctx, 2 * (size_t)E);
-        T.sflags = aalloc<uint32_t>(ctx, E); T.ev_begin = aalloc<uint32_t>(ctx, E); T.ev_mid = aalloc<uint32_t>(ctx, E);
-        T.ev_end = aalloc<uint32_t>(ctx, E); T.st = aalloc<uint32_t>(ctx, E);
-        uint32_t *st2 = aalloc<uint32_t>(ctx, E);
+        T.gpos = aalloc<uint32_t>(ctx, E); T.contig = aalloc<int32_t>(ctx, E);
+        T.ev_begin = aalloc<uint32_t>(ctx, E); T.ev_end = aalloc<uint32_t>(ctx, E); T.st = aalloc<uint32_t>(ctx, E);
+        uint32_t *st2 = aalloc<uint32_t>(ctx, E), *alive = nullptr;
         ascan = aalloc<uint32_t>(ctx, (size_t)E + 1);
-        if (!ev_info || !head || !head_scan || !T.gpos || !T.contig || !T.cnt2 || !T.sflags || !T.ev_begin || !T.ev_mid || !T.ev_end || !T.st || !st2 || !ascan) return 1;
-        HIPCHK(hipMemsetAsync(T.cnt2, 0, 2 * (size_t)E * 4, st));
-        HIPCHK(hipMemsetAsync(T.sflags, 0, (size_t)E * 4, st));
-        HIPCHK(hipMemsetAsync(T.ev_mid, 0xFF, (size_t)E * 4, st));
+        FillGroup z(ctx, 0), f(ctx, 0xFF);
+        z.want(&T.cnt2, 2 * (size_t)E); z.want(&T.sflags, E); z.want(&alive, E);
+        f.want(&T.ev_mid, E);
+        if (!ev_info || !head || !head_scan || !T.gpos || !T.contig || !T.ev_begin || !T.ev_end || !T.st || !st2 || !ascan || z.commit() || f.commit()) return 1;
         const unsigned eb = nblocks(E, 256);
         PROF_LAUNCH(k_event_info, dim3(eb), dim3(256), 0, st, R, P, (const uint64_t *)ev_sorted, E, ev_info, head);
         KCHK();
@@ -436,28 +474,33 @@ extern "C" int mfk_findflanks(mfk_ctx *ctx, const mfk_reads *reads, const mfk_pa
         n_sites_p = head_scan + E;
         PROF_LAUNCH(k_site_accumulate, dim3(eb), dim3(256), 0, st, R, (const uint64_t *)ev_sorted, (const uint8_t *)ev_info, (const uint32_t *)head_scan, E, T);
         KCHK();
-        PROF_LAUNCH(k_site_init, dim3(eb), dim3(256), 0, st, T, n_sites_p, d_stats);
+        const int upto = stop_after >= MFK_STAGE_MINCOUNT ? 2 : (stop_after >= MFK_STAGE_MINLENGTH ? 1 : 0);
+        PROF_LAUNCH(k_site_filters, dim3(eb), dim3(256), 0, st, T, n_sites_p, P.mincount, upto, d_stats);
         KCHK();
-        if (stop_after >= MFK_STAGE_MINLENGTH) { PROF_LAUNCH(k_filter_minlength, dim3(eb), dim3(256), 0, st, T, n_sites_p, d_stats); KCHK(); }
-        if (stop_after >= MFK_STAGE_MINCOUNT) { PROF_LAUNCH(k_filter_mincount, dim3(eb), dim3(256), 0, st, T, n_sites_p, P.mincount, d_stats); KCHK(); }
         if (stop_after >= MFK_STAGE_MINDIST1) {
-            PROF_LAUNCH(k_mindistance, dim3(eb), dim3(256), 0, st, (const uint32_t *)T.gpos, (const uint32_t *)T.cnt2, (const uint32_t *)T.st, st2, n_sites_p, 0u, P.mindist, d_stats + 3);
+            PROF_LAUNCH(k_mindistance, dim3(eb), dim3(256), 0, st, (const uint32_t *)T.gpos, (const uint32_t *)T.cnt2, (const uint32_t *)T.st, st2, n_sites_p, 0u, P.mindist, d_stats + 3, alive);
             KCHK();
             T.st = st2;
+        } else {
+            PROF_LAUNCH(k_alive_flags, dim3(eb), dim3(256), 0, st, (const uint32_t *)T.st, n_sites_p, E, alive);
+            KCHK();
         }
         // surviving sites -> dense active table
-        PROF_LAUNCH(k_alive_flags, dim3(eb), dim3(256), 0, st, (const uint32_t *)T.st, n_sites_p, E, head);
-        KCHK();
-        if (int rc = dev_excl_scan32(ctx, head, ascan, E)) return rc;
+        if (int rc = dev_excl_scan32(ctx, alive, ascan, E)) return rc;
         if (int rc = read_back(ctx, ascan + E, &n_act, 4)) return rc;
     }
     ConsensusIO io; memset(&io, 0, sizeof io);
     if (n_act > 0) {
         A.site = aalloc<uint32_t>(ctx, n_act); A.gpos = aalloc<uint32_t>(ctx, n_act); A.contig = aalloc<int32_t>(ctx, n_act);
-        A.cnt2 = aalloc<uint32_t>(ctx, 2 * (size_t)n_act); A.st = aalloc<uint32_t>(ctx, n_act); A.counts = aalloc<uint32_t>(ctx, 8 * (size_t)n_act);
+        A.cnt2 = aalloc<uint32_t>(ctx, 2 * (size_t)n_act); A.st = aalloc<uint32_t>(ctx, n_act);
         uint32_t *st2 = aalloc<uint32_t>(ctx, n_act);
-        if (!A.site || !A.gpos || !A.contig || !A.cnt2 || !A.st || !A.counts || !st2) return 1;
-        HIPCHK(hipMemsetAsync(A.counts, 0, 8 * (size_t)n_act * 4, st));
+        FillGroup z(ctx, 0);
+        z.want(&A.counts, 8 * (size_t)n_act);
+        if (stop_after >= MFK_STAGE_CONSENSUS) {
+            z.want(&io.cons_count, 2 * (size_t)n_act); z.want(&io.cons_len, 2 * (size_t)n_act);
+            z.want(&io.n_pass_len, 2 * (size_t)n_act); z.want(&io.n_pass_both, 2 * (size_t)n_act);
+        }
+        if (!A.site || !A.gpos || !A.contig || !A.cnt2 || !A.st || !st2 || z.commit()) return 1;
         const unsigned eb = nblocks(E, 256), ab = nblocks(n_act, 256);
         PROF_LAUNCH(k_compact_sites, dim3(eb), dim3(256), 0, st, T, n_sites_p, (const uint32_t *)ascan, A);
         KCHK();
@@ -470,7 +513,7 @@ extern "C" int mfk_findflanks(mfk_ctx *ctx, const mfk_reads *reads, const mfk_pa
             KCHK();
         }
         if (stop_after >= MFK_STAGE_MINDIST2) {
-            PROF_LAUNCH(k_mindistance, dim3(ab), dim3(256), 0, st, (const uint32_t *)A.gpos, (const uint32_t *)A.cnt2, (const uint32_t *)A.st, st2, (const uint32_t *)nullptr, n_act, P.mindist, d_stats + 5);
+            PROF_LAUNCH(k_mindistance, dim3(ab), dim3(256), 0, st, (const uint32_t *)A.gpos, (const uint32_t *)A.cnt2, (const uint32_t *)A.st, st2, (const uint32_t *)nullptr, n_act, P.mindist, d_stats + 5, (uint32_t *)nullptr);
             KCHK();
             uint32_t *t = A.st; A.st = st2; st2 = t;
         }
@@ -478,19 +521,12 @@ extern "C" int mfk_findflanks(mfk_ctx *ctx, const mfk_reads *reads, const mfk_pa
             io.ev_keys = ev_sorted; io.ev_info = ev_info; io.n_events = E;
             io.n_act = n_act; io.act_site = A.site; io.act_st = A.st;
             io.site_ev_begin = T.ev_begin; io.site_ev_mid = T.ev_mid; io.site_ev_end = T.ev_end;
-            io.cons_count = aalloc<int32_t>(ctx, 2 * (size_t)n_act); io.cons_len = aalloc<int32_t>(ctx, 2 * (size_t)n_act);
-            io.n_pass_len = aalloc<uint32_t>(ctx, 2 * (size_t)n_act); io.n_pass_both = aalloc<uint32_t>(ctx, 2 * (size_t)n_act);
-            if (!io.cons_count || !io.cons_len || !io.n_pass_len || !io.n_pass_both) return 1;
-            HIPCHK(hipMemsetAsync(io.cons_count, 0, 2 * (size_t)n_act * 4, st));
-            HIPCHK(hipMemsetAsync(io.cons_len, 0, 2 * (size_t)n_act * 4, st));
-            HIPCHK(hipMemsetAsync(io.n_pass_len, 0, 2 * (size_t)n_act * 4, st));
-            HIPCHK(hipMemsetAsync(io.n_pass_both, 0, 2 * (size_t)n_act * 4, st));
             if (int rc = run_consensus(ctx, R, P, io)) return rc;
             PROF_LAUNCH(k_consensus_filters, dim3(ab), dim3(256), 0, st, A, n_act, (const uint32_t *)io.n_pass_len, (const uint32_t *)io.n_pass_both, d_stats);
             KCHK();
         }
         if (stop_after >= MFK_STAGE_ALL) {
-            PROF_LAUNCH(k_mindistance, dim3(ab), dim3(256), 0, st, (const uint32_t *)A.gpos, (const uint32_t *)A.cnt2, (const uint32_t *)A.st, st2, (const uint32_t *)nullptr, n_act, P.mindist, d_stats + 9);
+            PROF_LAUNCH(k_mindistance, dim3(ab), dim3(256), 0, st, (const uint32_t *)A.gpos, (const uint32_t *)A.cnt2, (const uint32_t *)A.st, st2, (const uint32_t *)nullptr, n_act, P.mindist, d_stats + 9, (uint32_t *)nullptr);
             KCHK();
             uint32_t *t = A.st; A.st = st2; st2 = t;
         }

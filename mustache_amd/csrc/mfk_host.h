@@ -79,6 +79,16 @@ struct ReadBatch {
     int flush();
 };
 
+// several arrays that start out filled with one byte value (0x00 or 0xFF): one arena block, one fill
+struct FillGroup {
+    struct Req { void **out; size_t bytes, off; };
+    mfk_ctx *ctx; int value; std::vector<Req> reqs; size_t total;
+    FillGroup(mfk_ctx *c, int v) : ctx(c), value(v), total(0) {}
+    template <typename T> void want(T **out, size_t n) { size_t b = ((n ? n : 1) * sizeof(T) + 255) & ~(size_t)255; reqs.push_back({(void **)out, b, total}); total += b; }
+    int commit();    // allocates, assigns the pointers, queues the fill; non-zero on failure
+};
+
+size_t upload_reads_pinned_bytes(int n_contigs);
 int upload_reads(mfk_ctx *ctx, const mfk_reads *reads, const mfk_params *params, DevReads *R, DevParams *P);
 
 static inline unsigned nblocks(int64_t n, int threads) { int64_t b = (n + threads - 1) / threads; return (unsigned)(b < 1 ? 1 : b); }

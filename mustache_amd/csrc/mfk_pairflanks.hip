@@ -177,7 +177,16 @@ __global__ __launch_bounds__(64) void k_ir_seqs(const char *seqs, const int64_t 
 }
 
 // candidate pairs: combined = seq5[:40] + 'N'*20 + seq3[-40:]  (pairflanks.py:183-186, truncate_sequence 268-275)
-__global__ __launch_bounds__(64) void k_inverted_repeat(FlankDev F, const uint32_t *c5, const uint32_t *c3, uint32_t n, int32_t *out) {
+__device__ __forceinline__ uint64_t d_assign_key(const FlankDev &F, uint32_t a, uint32_t b, const int32_t *ir) {
+    int irlen = ir[1] ? ir[4] - ir[3] + 1 : 0;      // IR_length = len(IR_5p) = arm2 (pairflanks.py:212-213, 225)
+    int64_t dc = (int64_t)F.ccount[a] - (int64_t)F.ccount[b]; if (dc < 0) dc = -dc;   // diffcount (226)
+    int dl = F.seq_len[a] - F.seq_len[b]; if (dl < 0) dl = -dl;             // difflength (227)
+    if (dl > 65535) dl = 65535;
+    return ((uint64_t)(127 - irlen) << 48) | ((uint64_t)(dc & 0xFFFFFFFFll) << 16) | (uint64_t)dl;
+}
+
+// also writes the candidate's sort key for assign_pairs (stable order by IR_length desc, diffcount asc, difflength asc)
+__global__ __launch_bounds__(64) void k_inverted_repeat(FlankDev F, const uint32_t *c5, const uint32_t *c3, uint32_t n, int32_t *out, uint64_t *keys, uint32_t *vals) {
     __shared__ int16_t S[IR_MAXLEN * IR_MAXLEN];
     __shared__ uint8_t code[IR_MAXLEN + 4], mask[IR_MAXLEN + 4];
     __shared__ int32_t rep[4 * IR_MAXREP + 8];
@@ -194,24 +203,13 @@ __global__ __launch_bounds__(64) void k_inverted_repeat(FlankDev F, const uint32
     }
     __syncthreads();
     d_ir_detect(code, L, S, mask, rep, out + 6 * (size_t)k);
+    if (threadIdx.x == 0) { keys[k] = d_assign_key(F, a, b, out + 6 * (size_t)k); vals[k] = k; }
 }
 
 // ---- assign_pairs ------------------------------------------------------------------------------------------------------
-__global__ void k_assign_keys(FlankDev F, const uint32_t *c5, const uint32_t *c3, const int32_t *ir, uint32_t n, uint64_t *keys, uint32_t *vals) {
-    uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= n) return;
-    uint32_t a = c5[k], b = c3[k];
-    int irlen = ir[6 * k + 1] ? ir[6 * k + 4] - ir[6 * k + 3] + 1 : 0;      // IR_length = len(IR_5p) = arm2 (pairflanks.py:212-213, 225)
-    int64_t dc = (int64_t)F.ccount[a] - (int64_t)F.ccount[b]; if (dc < 0) dc = -dc;   // diffcount (226)
-    int dl = F.seq_len[a] - F.seq_len[b]; if (dl < 0) dl = -dl;             // difflength (227)
-    if (dl > 65535) dl = 65535;
-    keys[k] = ((uint64_t)(127 - irlen) << 48) | ((uint64_t)(dc & 0xFFFFFFFFll) << 16) | (uint64_t)dl;
-    vals[k] = k;
-}
-
 // greedy exclusion (pairflanks.py:233-245) in parallel rounds, one workgroup.  order[p] = candidate at sorted position p.
 __global__ __launch_bounds__(1024) void k_assign(const uint32_t *order, const uint32_t *c5, const uint32_t *c3, uint32_t n, uint32_t nF,
-                                                 uint32_t *best5, uint32_t *best3, uint8_t *used5, uint8_t *used3, uint8_t *state /* by sorted position */) {
+                                                 uint32_t *best5, uint32_t *best3, uint8_t *used5, uint8_t *used3, uint8_t *state /* by sorted position */, uint32_t *kflag) {
     __shared__ int undecided;
     for (uint32_t i = threadIdx.x; i < nF; i += blockDim.x) { best5[i] = 0xFFFFFFFFu; best3[i] = 0xFFFFFFFFu; used5[i] = 0; used3[i] = 0; }
     for (uint32_t p = threadIdx.x; p < n; p += blockDim.x) state[p] = 0;
@@ -241,11 +239,8 @@ __global__ __launch_bounds__(1024) void k_assign(const uint32_t *order, const ui
         }
         __syncthreads();
     }
-}
-
-__global__ void k_kept_flags(const uint8_t *state, uint32_t n, uint32_t *flag) {
-    uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p < n) flag[p] = state[p] == 1 ? 1u : 0u;
+    __syncthreads();
+    for (uint32_t p = threadIdx.x; p < n; p += blockDim.x) kflag[p] = state[p] == 1 ? 1u : 0u;
 }
 
 // kept pairs in sorted_pairs order -> keys for sort_values(['contig','pos_5p','pos_3p']) (pairflanks.py:248)
@@ -267,11 +262,13 @@ __device__ __forceinline__ bool d_spans(const DevReads &R, const DevParams &P, i
            !(d_large_insertion_at(R, P, r, f, pos3) || d_large_insertion_at(R, P, r, f, pos5));
 }
 
-__global__ __launch_bounds__(256) void k_spanning(DevReads R, DevParams P, FlankDev F, const uint32_t *kept, const uint32_t *c5, const uint32_t *c3, uint32_t n, uint32_t *spanning) {
+// + filter_junction_spanning pairflanks.py:421-431 (float64, strict <, quirk P9) by the block's first thread
+__global__ __launch_bounds__(256) void k_spanning(DevReads R, DevParams P, FlankDev F, const uint32_t *kept, const uint32_t *c5, const uint32_t *c3, const uint32_t *n_kept,
+                                                  const int32_t *ir, uint32_t *spanning, uint32_t *jflag, uint32_t *pstats) {
     __shared__ uint32_t cnt;
     __shared__ int64_t range[2];
     uint32_t k = blockIdx.x;
-    if (k >= n) return;
+    if (k >= *n_kept) return;
     uint32_t c = kept[k];
     const int32_t contig = F.contig[c5[c]], pos5 = F.pos[c5[c]], pos3 = F.pos[c3[c]];
     const int32_t clen = R.contig_len[contig];
@@ -299,32 +296,23 @@ __global__ __launch_bounds__(256) void k_spanning(DevReads R, DevParams P, Flank
         if (!dup) atomicAdd(&cnt, 1u);
     }
     __syncthreads();
-    if (threadIdx.x == 0) spanning[k] = cnt;
-}
-
-// filter_junction_spanning pairflanks.py:421-431 (float64, strict <, quirk P9)
-__global__ void k_junction_filter(FlankDev F, const uint32_t *kept, const uint32_t *c5, const uint32_t *c3, const uint32_t *spanning, const int32_t *ir, uint32_t n, double maxjsp, uint32_t *flag, uint32_t *pstats) {
-    uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= n) return;
-    uint32_t c = kept[k];
-    double total = (double)((int64_t)F.total[c5[c]] + (int64_t)F.total[c3[c]]) / 2;
-    double prop = (double)spanning[k] / total;
-    flag[k] = prop < maxjsp ? 1u : 0u;
-    if (ir[6 * c]) atomicAdd(&pstats[2], 1u);
-    if (spanning[k] > 0) atomicAdd(&pstats[3], 1u);
-}
-
-__global__ void k_final_list(const uint32_t *kept, const uint32_t *flag, const uint32_t *scan, const uint32_t *spanning, uint32_t n, uint32_t *fin, uint32_t *fin_span) {
-    uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= n || !flag[k]) return;
-    fin[scan[k]] = kept[k]; fin_span[scan[k]] = spanning[k];
+    if (threadIdx.x == 0) {
+        spanning[k] = cnt;
+        double total = (double)((int64_t)F.total[c5[c]] + (int64_t)F.total[c3[c]]) / 2;
+        double prop = (double)cnt / total;
+        jflag[k] = prop < P.maxjsp ? 1u : 0u;
+        if (ir[6 * c]) atomicAdd(&pstats[2], 1u);
+        if (cnt > 0) atomicAdd(&pstats[3], 1u);
+    }
 }
 
 // ---- get_direct_repeats ---------------------------------------------------------------------------------------------------
 #define DR_WIN 50
 #define DR_SEGS 1536
 // per final pair: dr_out[k*stride ...] = reference repeat, dr_out[k*stride + half ...] = reads consensus
-__global__ __launch_bounds__(1024) void k_direct_repeats(DevReads R, FlankDev F, const uint32_t *fin, const uint32_t *c5, const uint32_t *c3, uint32_t n,
+// one block per kept pair; pairs that fail the junction filter are skipped, the others write output row jscan[k]
+__global__ __launch_bounds__(1024) void k_direct_repeats(DevReads R, FlankDev F, const uint32_t *kept, const uint32_t *n_kept, const uint32_t *jflag, const uint32_t *jscan,
+                                                        const uint32_t *spanning, const uint32_t *c5, const uint32_t *c3, uint32_t *fin, uint32_t *fin_span,
                                                         const uint8_t *genome, const int64_t *goff, char *dr_out, uint32_t stride, int32_t *dr_meta /* 3 per pair: ref_len, reads_len, err */) {
     __shared__ uint32_t sum[DR_WIN][17];
     __shared__ uint32_t firstr[DR_WIN][17];
@@ -335,9 +323,10 @@ __global__ __launch_bounds__(1024) void k_direct_repeats(DevReads R, FlankDev F,
     __shared__ int32_t seg_lo[DR_SEGS], seg_hi[DR_SEGS];
     __shared__ uint32_t seg_r[DR_SEGS], nseg;
     const char codes[17] = "=ACMGRSVTWYHKDBN";
-    uint32_t k = blockIdx.x;
-    if (k >= n) return;
-    uint32_t c = fin[k];
+    if (blockIdx.x >= *n_kept || !jflag[blockIdx.x]) return;
+    const uint32_t k = jscan[blockIdx.x];      // output row
+    const uint32_t c = kept[blockIdx.x];
+    if (threadIdx.x == 0) { fin[k] = c; fin_span[k] = spanning[blockIdx.x]; }
     const int32_t contig = F.contig[c5[c]], end = F.pos[c5[c]], start = F.pos[c3[c]];
     const int64_t glen = goff[contig + 1] - goff[contig];
     const uint8_t *g = genome + goff[contig];
@@ -497,31 +486,39 @@ extern "C" int mfk_pairflanks(mfk_ctx *ctx, const mfk_reads *reads, const mfk_pa
     arena_reset(ctx);
     DevReads R; DevParams P;
     if (int rc = upload_reads(ctx, reads, params, &R, &P)) return rc;
+    const size_t pin_off = upload_reads_pinned_bytes(reads->n_contigs);   // the flank staging block goes behind upload_reads' bytes
     hipStream_t st = ctx->stream;
     const uint32_t nF = (uint32_t)n_flanks;
     const int nc = reads->n_contigs;
-    // ---- flank table to the device ---------------------------------------------------------------------------------
-    std::vector<int32_t> h(6 * (size_t)nF); std::vector<int64_t> hoff(nF);
+    // ---- flank table to the device: one staging block in pinned memory, one copy --------------------------------------
     int sorted = 1; int64_t seq_total = 0;
     for (uint32_t i = 0; i < nF; i++) {
         const mfk_flank &f = flanks[i];
         if (f.contig_id < 0 || f.contig_id >= nc) { snprintf(ctx->err, sizeof ctx->err, "flank %u: contig id %d out of range", i, f.contig_id); return 1; }
-        h[i] = f.contig_id; h[nF + i] = f.pos; h[2 * (size_t)nF + i] = f.orient; h[3 * (size_t)nF + i] = f.consensus_softclip_count;
-        h[4 * (size_t)nF + i] = f.total_count; h[5 * (size_t)nF + i] = f.seq_len; hoff[i] = f.seq_off;
+        if (f.seq_off < 0 || f.seq_len < 0) { snprintf(ctx->err, sizeof ctx->err, "flank %u: negative sequence offset or length", i); return 1; }
         if (f.seq_off + f.seq_len > seq_total) seq_total = f.seq_off + f.seq_len;
         if (i && (flanks[i - 1].contig_id > f.contig_id || (flanks[i - 1].contig_id == f.contig_id && flanks[i - 1].pos > f.pos))) sorted = 0;
     }
-    int32_t *d_tab = aalloc<int32_t>(ctx, 6 * (size_t)nF); int64_t *d_soff = aalloc<int64_t>(ctx, nF); char *d_seqs = aalloc<char>(ctx, (size_t)seq_total + 1);
-    int32_t *d_rank = aalloc<int32_t>(ctx, nc); int64_t *d_goff = aalloc<int64_t>(ctx, (size_t)nc + 1);
-    uint32_t *d_pstats = aalloc<uint32_t>(ctx, MFK_N_STATS);
-    if (!d_tab || !d_soff || !d_seqs || !d_rank || !d_goff || !d_pstats) return 1;
-    HIPCHK(hipMemcpyAsync(d_tab, h.data(), h.size() * 4, hipMemcpyHostToDevice, st));
-    HIPCHK(hipMemcpyAsync(d_soff, hoff.data(), hoff.size() * 8, hipMemcpyHostToDevice, st));
-    if (seq_total) HIPCHK(hipMemcpyAsync(d_seqs, flank_seqs, (size_t)seq_total, hipMemcpyHostToDevice, st));
-    HIPCHK(hipMemcpyAsync(d_rank, h_contig_rank, (size_t)nc * 4, hipMemcpyHostToDevice, st));
-    HIPCHK(hipMemcpyAsync(d_goff, h_genome_off, ((size_t)nc + 1) * 8, hipMemcpyHostToDevice, st));
-    HIPCHK(hipMemsetAsync(d_pstats, 0, MFK_N_STATS * 4, st));
-    HIPCHK(hipStreamSynchronize(st));   // host vectors go out of use
+    const size_t o_soff = 0, o_goff = o_soff + (size_t)nF * 8, o_tab = o_goff + ((size_t)nc + 1) * 8, o_rank = o_tab + 6 * (size_t)nF * 4;
+    const size_t o_seqs = o_rank + (size_t)nc * 4, up_bytes = ((o_seqs + (size_t)seq_total + 1) + 255) & ~(size_t)255;
+    char *hp = (char *)pinned_buf(ctx, pin_off + up_bytes);
+    char *d_up = aalloc<char>(ctx, up_bytes);
+    if (!hp || !d_up) return 1;
+    hp += pin_off;
+    {
+        int64_t *hoff = (int64_t *)(hp + o_soff); int32_t *h = (int32_t *)(hp + o_tab);
+        for (uint32_t i = 0; i < nF; i++) {
+            const mfk_flank &f = flanks[i];
+            h[i] = f.contig_id; h[nF + i] = f.pos; h[2 * (size_t)nF + i] = f.orient; h[3 * (size_t)nF + i] = f.consensus_softclip_count;
+            h[4 * (size_t)nF + i] = f.total_count; h[5 * (size_t)nF + i] = f.seq_len; hoff[i] = f.seq_off;
+        }
+        memcpy(hp + o_goff, h_genome_off, ((size_t)nc + 1) * 8);
+        memcpy(hp + o_rank, h_contig_rank, (size_t)nc * 4);
+        if (seq_total) memcpy(hp + o_seqs, flank_seqs, (size_t)seq_total);
+    }
+    HIPCHK(hipMemcpyAsync(d_up, hp, up_bytes, hipMemcpyHostToDevice, st));   // pinned bytes stay untouched until the final read-back, which is ordered behind this copy
+    int32_t *d_tab = (int32_t *)(d_up + o_tab); int64_t *d_soff = (int64_t *)(d_up + o_soff); char *d_seqs = d_up + o_seqs;
+    int32_t *d_rank = (int32_t *)(d_up + o_rank); int64_t *d_goff = (int64_t *)(d_up + o_goff);
     HIPCHK(hipEventRecord(ctx->ev0, st));
     FlankDev F; F.n = nF; F.contig = d_tab; F.pos = d_tab + nF; F.orient = d_tab + 2 * (size_t)nF; F.ccount = d_tab + 3 * (size_t)nF;
     F.total = d_tab + 4 * (size_t)nF; F.seq_len = d_tab + 5 * (size_t)nF; F.seq_off = d_soff; F.seqs = d_seqs;
@@ -537,72 +534,58 @@ extern "C" int mfk_pairflanks(mfk_ctx *ctx, const mfk_reads *reads, const mfk_pa
     ctx->pstats[0] = nP;
     uint32_t nK = 0, nFin = 0;
     uint32_t h_ps[MFK_N_STATS]; memset(h_ps, 0, sizeof h_ps);
-    bool got_stats = false;
     std::vector<uint32_t> h_fin, h_span, h_c5, h_c3; std::vector<int32_t> h_ir, h_meta; std::vector<char> h_dr; uint32_t stride = 0;
     if (nP > 0) {
+        // everything downstream is sized by the candidate count; the kept / final counts stay on the device
         uint32_t *c5 = aalloc<uint32_t>(ctx, nP), *c3 = aalloc<uint32_t>(ctx, nP);
         int32_t *ir = aalloc<int32_t>(ctx, 6 * (size_t)nP);
-        uint64_t *keys = aalloc<uint64_t>(ctx, nP), *keys2 = aalloc<uint64_t>(ctx, nP);
+        uint64_t *keys = aalloc<uint64_t>(ctx, nP), *keys2 = aalloc<uint64_t>(ctx, nP), *kk2 = aalloc<uint64_t>(ctx, nP), *kk = nullptr;
         uint32_t *vals = aalloc<uint32_t>(ctx, nP), *order = aalloc<uint32_t>(ctx, nP);
         uint32_t *best5 = aalloc<uint32_t>(ctx, nF), *best3 = aalloc<uint32_t>(ctx, nF);
         uint8_t *used5 = aalloc<uint8_t>(ctx, nF), *used3 = aalloc<uint8_t>(ctx, nF), *state = aalloc<uint8_t>(ctx, nP);
-        uint32_t *kflag = aalloc<uint32_t>(ctx, nP), *kscan = aalloc<uint32_t>(ctx, (size_t)nP + 1);
-        if (!c5 || !c3 || !ir || !keys || !keys2 || !vals || !order || !best5 || !best3 || !used5 || !used3 || !state || !kflag || !kscan) return 1;
+        uint32_t *kflag = aalloc<uint32_t>(ctx, nP), *kscan = aalloc<uint32_t>(ctx, (size_t)nP + 1), *jscan = aalloc<uint32_t>(ctx, (size_t)nP + 1);
+        uint32_t *kept = aalloc<uint32_t>(ctx, nP), *spanning = aalloc<uint32_t>(ctx, nP);
+        uint32_t *fin = aalloc<uint32_t>(ctx, nP), *fin_span = aalloc<uint32_t>(ctx, nP);
+        int32_t *meta = aalloc<int32_t>(ctx, 3 * (size_t)nP);
+        stride = 2 * (((uint32_t)P.maxdr + 1 + 15) & ~15u);
+        uint32_t *d_pstats = nullptr, *kv = nullptr, *jflag = nullptr; char *dr = nullptr;
+        FillGroup z(ctx, 0), f(ctx, 0xFF);
+        z.want(&d_pstats, MFK_N_STATS); z.want(&kv, nP); z.want(&jflag, nP); z.want(&dr, (size_t)nP * stride);
+        f.want(&kk, nP);   // unused sort keys stay ~0 and sort behind the kept pairs
+        if (!c5 || !c3 || !ir || !keys || !keys2 || !kk2 || !vals || !order || !best5 || !best3 || !used5 || !used3 || !state || !kflag || !kscan || !jscan ||
+            !kept || !spanning || !fin || !fin_span || !meta || z.commit() || f.commit()) return 1;
         const unsigned pb = nblocks(nP, 256);
         PROF_LAUNCH(k_pair_window<true>, dim3(fb), dim3(256), 0, st, F, P.maxdr, sorted, (uint32_t *)nullptr, (const uint32_t *)coff, c5, c3);
         KCHK();
-        PROF_LAUNCH(k_inverted_repeat, dim3(nP), dim3(64), 0, st, F, (const uint32_t *)c5, (const uint32_t *)c3, nP, ir);
-        KCHK();
-        PROF_LAUNCH(k_assign_keys, dim3(pb), dim3(256), 0, st, F, (const uint32_t *)c5, (const uint32_t *)c3, (const int32_t *)ir, nP, keys, vals);
+        PROF_LAUNCH(k_inverted_repeat, dim3(nP), dim3(64), 0, st, F, (const uint32_t *)c5, (const uint32_t *)c3, nP, ir, keys, vals);
         KCHK();
         if (int rc = dev_sort_pairs64(ctx, keys, keys2, vals, order, nP, 0, 56)) return rc;
-        PROF_LAUNCH(k_assign, dim3(1), dim3(1024), 0, st, (const uint32_t *)order, (const uint32_t *)c5, (const uint32_t *)c3, nP, nF, best5, best3, used5, used3, state);
-        KCHK();
-        PROF_LAUNCH(k_kept_flags, dim3(pb), dim3(256), 0, st, (const uint8_t *)state, nP, kflag);
+        PROF_LAUNCH(k_assign, dim3(1), dim3(1024), 0, st, (const uint32_t *)order, (const uint32_t *)c5, (const uint32_t *)c3, nP, nF, best5, best3, used5, used3, state, kflag);
         KCHK();
         if (int rc = dev_excl_scan32(ctx, kflag, kscan, nP)) return rc;
-        if (int rc = read_back(ctx, kscan + nP, &nK, 4)) return rc;
-        ctx->pstats[1] = nK;
-        if (nK > 0) {
-            uint64_t *kk = aalloc<uint64_t>(ctx, nK), *kk2 = aalloc<uint64_t>(ctx, nK);
-            uint32_t *kv = aalloc<uint32_t>(ctx, nK), *kept = aalloc<uint32_t>(ctx, nK), *spanning = aalloc<uint32_t>(ctx, nK);
-            uint32_t *jflag = aalloc<uint32_t>(ctx, nK), *jscan = aalloc<uint32_t>(ctx, (size_t)nK + 1);
-            if (!kk || !kk2 || !kv || !kept || !spanning || !jflag || !jscan) return 1;
-            const unsigned kb = nblocks(nK, 256);
-            PROF_LAUNCH(k_kept_keys, dim3(pb), dim3(256), 0, st, F, (const uint32_t *)order, (const uint32_t *)c5, (const uint32_t *)c3, (const uint8_t *)state, (const uint32_t *)kscan, nP, (const int32_t *)d_rank, kk, kv);
-            KCHK();
-            if (int rc = dev_sort_pairs64(ctx, kk, kk2, kv, kept, nK, 0, 64)) return rc;
-            PROF_LAUNCH(k_spanning, dim3(nK), dim3(256), 0, st, R, P, F, (const uint32_t *)kept, (const uint32_t *)c5, (const uint32_t *)c3, nK, spanning);
-            KCHK();
-            PROF_LAUNCH(k_junction_filter, dim3(kb), dim3(256), 0, st, F, (const uint32_t *)kept, (const uint32_t *)c5, (const uint32_t *)c3, (const uint32_t *)spanning, (const int32_t *)ir, nK, P.maxjsp, jflag, d_pstats);
-            KCHK();
-            if (int rc = dev_excl_scan32(ctx, jflag, jscan, nK)) return rc;
-            if (int rc = read_back(ctx, jscan + nK, &nFin, 4)) return rc;
-            if (nFin > 0) {
-                uint32_t *fin = aalloc<uint32_t>(ctx, nFin), *fin_span = aalloc<uint32_t>(ctx, nFin);
-                stride = 2 * (((uint32_t)P.maxdr + 1 + 15) & ~15u);
-                char *dr = aalloc<char>(ctx, (size_t)nFin * stride); int32_t *meta = aalloc<int32_t>(ctx, 3 * (size_t)nFin);
-                if (!fin || !fin_span || !dr || !meta) return 1;
-                HIPCHK(hipMemsetAsync(dr, 0, (size_t)nFin * stride, st));
-                PROF_LAUNCH(k_final_list, dim3(kb), dim3(256), 0, st, (const uint32_t *)kept, (const uint32_t *)jflag, (const uint32_t *)jscan, (const uint32_t *)spanning, nK, fin, fin_span);
-                KCHK();
-                PROF_LAUNCH(k_direct_repeats, dim3(nFin), dim3(1024), 0, st, R, F, (const uint32_t *)fin, (const uint32_t *)c5, (const uint32_t *)c3, nFin, genome, (const int64_t *)d_goff, dr, stride, meta);
-                KCHK();
-                HIPCHK(hipEventRecord(ctx->ev1, st));
-                h_fin.resize(nFin); h_span.resize(nFin); h_meta.resize(3 * (size_t)nFin); h_dr.resize((size_t)nFin * stride);
-                h_c5.resize(nP); h_c3.resize(nP); h_ir.resize(6 * (size_t)nP);
-                ReadBatch rb(ctx);
-                rb.add(fin, h_fin.data(), nFin * 4); rb.add(fin_span, h_span.data(), nFin * 4);
-                rb.add(meta, h_meta.data(), 3 * (size_t)nFin * 4); rb.add(dr, h_dr.data(), (size_t)nFin * stride);
-                rb.add(c5, h_c5.data(), nP * 4); rb.add(c3, h_c3.data(), nP * 4); rb.add(ir, h_ir.data(), 6 * (size_t)nP * 4);
-                rb.add(d_pstats, h_ps, sizeof h_ps);
-                if (int rc = rb.flush()) return rc;
-                got_stats = true;
-            }
-        }
-    }
-    if (nFin == 0) HIPCHK(hipEventRecord(ctx->ev1, st));
-    if (!got_stats) if (int rc = read_back(ctx, d_pstats, h_ps, sizeof h_ps)) return rc;
+        const uint32_t *nK_p = kscan + nP;
+        PROF_LAUNCH(k_kept_keys, dim3(pb), dim3(256), 0, st, F, (const uint32_t *)order, (const uint32_t *)c5, (const uint32_t *)c3, (const uint8_t *)state, (const uint32_t *)kscan, nP, (const int32_t *)d_rank, kk, kv);
+        KCHK();
+        if (int rc = dev_sort_pairs64(ctx, kk, kk2, kv, kept, nP, 0, 64)) return rc;
+        PROF_LAUNCH(k_spanning, dim3(nP), dim3(256), 0, st, R, P, F, (const uint32_t *)kept, (const uint32_t *)c5, (const uint32_t *)c3, nK_p, (const int32_t *)ir, spanning, jflag, d_pstats);
+        KCHK();
+        if (int rc = dev_excl_scan32(ctx, jflag, jscan, nP)) return rc;
+        PROF_LAUNCH(k_direct_repeats, dim3(nP), dim3(1024), 0, st, R, F, (const uint32_t *)kept, nK_p, (const uint32_t *)jflag, (const uint32_t *)jscan, (const uint32_t *)spanning,
+                    (const uint32_t *)c5, (const uint32_t *)c3, fin, fin_span, genome, (const int64_t *)d_goff, dr, stride, meta);
+        KCHK();
+        HIPCHK(hipEventRecord(ctx->ev1, st));
+        h_fin.resize(nP); h_span.resize(nP); h_meta.resize(3 * (size_t)nP); h_dr.resize((size_t)nP * stride);
+        h_c5.resize(nP); h_c3.resize(nP); h_ir.resize(6 * (size_t)nP);
+        ReadBatch rb(ctx);
+        rb.add(nK_p, &nK, 4); rb.add(jscan + nP, &nFin, 4);
+        rb.add(fin, h_fin.data(), nP * 4); rb.add(fin_span, h_span.data(), nP * 4);
+        rb.add(meta, h_meta.data(), 3 * (size_t)nP * 4); rb.add(dr, h_dr.data(), (size_t)nP * stride);
+        rb.add(c5, h_c5.data(), nP * 4); rb.add(c3, h_c3.data(), nP * 4); rb.add(ir, h_ir.data(), 6 * (size_t)nP * 4);
+        rb.add(d_pstats, h_ps, sizeof h_ps);
+        if (int rc = rb.flush()) return rc;
+    } else
+        HIPCHK(hipEventRecord(ctx->ev1, st));
+    ctx->pstats[1] = nK;
     ctx->pstats[2] = h_ps[2]; ctx->pstats[3] = h_ps[3]; ctx->pstats[4] = nFin;
     prof_collect(ctx);
     float ms = 0.f;
