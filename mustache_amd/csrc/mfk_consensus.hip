@@ -350,8 +350,10 @@ __device__ __forceinline__ int d_myers(const uint64_t (&plane)[4][NL], const uin
     int score = m;
     const int tl = (m - 1) >> 6;
     const uint64_t tb = 1ull << ((m - 1) & 63);
+    uint64_t next = *reinterpret_cast<const uint64_t *>(text);
     for (int o = 0; o < m; o += 8) {
-        uint64_t chunk = *reinterpret_cast<const uint64_t *>(text + o);
+        const uint64_t chunk = next;
+        if (o + 8 < m) next = *reinterpret_cast<const uint64_t *>(text + o + 8);   // in flight while this chunk is processed
         int lim = m - o < 8 ? m - o : 8;
         for (int s = 0; s < lim; s++) {
             uint32_t c = (uint32_t)(chunk >> (8 * s)) & 0xFF;

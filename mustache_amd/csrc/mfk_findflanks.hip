@@ -22,20 +22,16 @@
 
 // ---- K1: clip events -------------------------------------------------------------------------------------------
 // parse_softclips (findflanks.py:100-121) in one pass over tiles of 4096 reads.  Phase 1: each lane loads the flags of 16
-// consecutive reads (one dwordx4) and pushes the lenient-clipped ones (~1.5 %) to a list in LDS.  Phase 2: one thread
-// per listed read gathers the rest of its record (all column loads issued together), runs passes_read_filters and
-// emits one 64-bit key (gpos | side | read) per clip.  Clipped reads pile up at the insertion sites (a 1000x site puts
-// ~500 of them into one tile); the list spreads them over the whole workgroup instead of leaving one lane with eight
-// dependent gathers in a row.  Keys are staged in LDS and flushed with ONE global reservation per workgroup; their
-// order is arbitrary, which is fine because keys are unique and the radix sort that follows fixes the order.
+// consecutive reads (one dwordx4; the next tile's load is issued before this tile is processed) and pushes the
+// lenient-clipped ones (~1.5 %) to a list in LDS.  Phase 2: one thread per listed read gathers the rest of its record
+// (all column loads issued together), runs passes_read_filters and emits one 64-bit key (gpos | side | read) per clip.
+// Clipped reads pile up at the insertion sites (a 1000x site puts ~500 of them into one tile); the list spreads them
+// over the whole workgroup instead of leaving one lane with eight dependent gathers in a row.  Keys are staged in LDS
+// and flushed with one global reservation; their order is arbitrary, which is fine because keys are unique and the
+// sort that follows fixes the order.
 #define EV_STAGE 2048
+#define CL_CAP 1024
 #define SCAN_TILE (SCAN_THREADS * 16)
-
-// Site bitmaps over the gpos axis.  `all`: a site exists (its first setter counts it: "sites after parse").  `strong`:
-// some clip at the site meets min_softclip_length on its side, i.e. the site survives filter_softclips_minlength
-// (findflanks.py:124-145).  Only the events of strong sites go on to the sort and the site table: at 1000x they are
-// ~8 % of all events, the rest are single mismatches at read ends scattered over the genome.
-struct SiteMaps { uint32_t *all, *strong; };
 
 __device__ __forceinline__ void d_stage_event(uint64_t key, uint64_t *stage, uint32_t *s_n, uint64_t *ev, uint32_t *ev_count, uint32_t cap) {
     uint32_t slot = atomicAdd(s_n, 1u);
@@ -43,68 +39,69 @@ __device__ __forceinline__ void d_stage_event(uint64_t key, uint64_t *stage, uin
     else { uint32_t g = atomicAdd(ev_count, 1u); if (g < cap) ev[g] = key; }   // deeper than the stage: rare slow path
 }
 
-__device__ __forceinline__ void d_mark_site(const SiteMaps &M, uint32_t gpos, bool strong, uint32_t *s_new) {
-    const uint32_t bit = 1u << (gpos & 31);
-    if (!(atomicOr(&M.all[gpos >> 5], bit) & bit)) atomicAdd(s_new, 1u);
-    if (strong && M.strong) atomicOr(&M.strong[gpos >> 5], bit);
+// one lenient-clipped read: read filters + its one or two events
+__device__ __forceinline__ void d_clip_events(const DevReads &R, const DevParams &P, int64_t r, uint8_t f, uint64_t *stage, uint32_t *s_n, uint64_t *ev, uint32_t *ev_count, uint32_t cap) {
+    // Only the columns this read's clip kinds need (every column touched costs a whole cache line of HBM traffic for
+    // one sparse read), all issued together: none of these loads depends on another
+    const int lk = d_lkind(f), rk = d_rkind(f);
+    const bool both = lk && rk;
+    const int mq = R.mapq[r];
+    const int ql = both ? R.qlen[r] : 0, fo = both ? R.first_op_len[r] : 0, lo = both ? R.last_op_len[r] : 0;
+    const int32_t rs = lk ? R.ref_start[r] : 0, re = rk ? R.ref_end[r] : 0;
+    const uint32_t base = R.contig_base[R.contig_id[r]];
+    const int llen = lk == 1 ? fo : (lk == 2 ? 1 : 0), rlen = rk == 1 ? lo : (rk == 2 ? 1 : 0);   // d_llen / d_rlen
+    if (mq < P.minq) return;                                                                    // d_passes
+    if (lk && rk && ql - rlen - llen < P.minial) return;
+    if (rk) {   // right clip -> 5p site (findflanks.py:117-118, 594-597); d_rsite
+        const int32_t site = rk == 1 ? re : re - 1;
+        d_stage_event(((uint64_t)(base + (uint32_t)(site + 1)) << 32) | (uint64_t)(uint32_t)r, stage, s_n, ev, ev_count, cap);
+    }
+    if (lk) {   // left clip -> 3p site (findflanks.py:120-121, 599-602); d_lsite
+        const int32_t site = lk == 1 ? rs - 1 : rs;
+        d_stage_event(((uint64_t)(base + (uint32_t)(site + 1)) << 32) | (1ull << 31) | (uint64_t)(uint32_t)r, stage, s_n, ev, ev_count, cap);
+    }
 }
 
-__global__ __launch_bounds__(SCAN_THREADS) void k_scan_clips(DevReads R, DevParams P, uint64_t *ev, uint32_t *ev_count, uint32_t cap, SiteMaps M, uint32_t *n_sites_all) {
+__device__ __forceinline__ uint4 d_load_flags16(const DevReads &R, int64_t g, int64_t ngroups) {
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (g < ngroups) {
+        const int64_t r0 = g << 4;
+        if (r0 + 16 <= R.n) v = *reinterpret_cast<const uint4 *>(R.flags + r0);
+        else {
+            uint32_t w[4] = {0, 0, 0, 0};
+            for (int k = 0; k < (int)(R.n - r0); k++) w[k >> 2] |= (uint32_t)R.flags[r0 + k] << ((k & 3) * 8);   // reads past the end stay 0 = unclipped
+            v = make_uint4(w[0], w[1], w[2], w[3]);
+        }
+    }
+    return v;
+}
+
+__global__ __launch_bounds__(SCAN_THREADS) void k_scan_clips(DevReads R, DevParams P, uint64_t *ev, uint32_t *ev_count, uint32_t cap) {
     __shared__ uint64_t stage[EV_STAGE];
-    __shared__ uint32_t cl_r[SCAN_TILE];
-    __shared__ uint8_t cl_f[SCAN_TILE];
-    __shared__ uint32_t s_n, s_base, s_ncl, s_new;
-    if (threadIdx.x == 0) { s_n = 0; s_ncl = 0; s_new = 0; }
+    __shared__ uint32_t cl_r[CL_CAP];
+    __shared__ uint8_t cl_f[CL_CAP];
+    __shared__ uint32_t s_n, s_base, s_ncl;
+    if (threadIdx.x == 0) { s_n = 0; s_ncl = 0; }
     __syncthreads();
     const int64_t ngroups = (R.n + 15) >> 4;
     const int64_t ntiles = (ngroups + SCAN_THREADS - 1) / SCAN_THREADS;
+    uint4 nxt = d_load_flags16(R, (int64_t)blockIdx.x * SCAN_THREADS + threadIdx.x, ngroups);
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const int64_t g = tile * SCAN_THREADS + threadIdx.x;
-        if (g < ngroups) {
-            uint32_t w[4] = {0, 0, 0, 0};
-            int nvalid = 16;
-            const int64_t r0 = g << 4;
-            if (r0 + 16 <= R.n) {
-                uint4 v = *reinterpret_cast<const uint4 *>(R.flags + r0);
-                w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
-            } else {
-                nvalid = (int)(R.n - r0);
-                for (int k = 0; k < nvalid; k++) w[k >> 2] |= (uint32_t)R.flags[r0 + k] << ((k & 3) * 8);
+        const uint4 v = nxt;
+        const int64_t r0 = (tile * SCAN_THREADS + threadIdx.x) << 4;
+        if (tile + gridDim.x < ntiles) nxt = d_load_flags16(R, (tile + gridDim.x) * SCAN_THREADS + threadIdx.x, ngroups);
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+        if ((w[0] | w[1] | w[2] | w[3]) & 0x0F0F0F0Fu)
+            for (int k = 0; k < 16; k++) {
+                const uint8_t f = (uint8_t)(w[k >> 2] >> ((k & 3) * 8));
+                if (!(f & 15)) continue;
+                const uint32_t slot = atomicAdd(&s_ncl, 1u);
+                if (slot < CL_CAP) { cl_r[slot] = (uint32_t)(r0 + k); cl_f[slot] = f; }
+                else d_clip_events(R, P, r0 + k, f, stage, &s_n, ev, ev_count, cap);   // list full (a tile of mostly clipped reads): do it here
             }
-            if ((w[0] | w[1] | w[2] | w[3]) & 0x0F0F0F0Fu)
-                for (int k = 0; k < nvalid; k++) {
-                    const uint8_t f = (uint8_t)(w[k >> 2] >> ((k & 3) * 8));
-                    if (!(f & 15)) continue;
-                    const uint32_t slot = atomicAdd(&s_ncl, 1u);
-                    cl_r[slot] = (uint32_t)(r0 + k); cl_f[slot] = f;
-                }
-        }
         __syncthreads();
-        const uint32_t ncl = s_ncl;
-        for (uint32_t i = threadIdx.x; i < ncl; i += SCAN_THREADS) {
-            const int64_t r = cl_r[i];
-            const uint8_t f = cl_f[i];
-            // the whole record at once: these loads do not depend on each other
-            const int mq = R.mapq[r], ql = R.qlen[r], fo = R.first_op_len[r], lo = R.last_op_len[r];
-            const int32_t rs = R.ref_start[r], re = R.ref_end[r];
-            const uint32_t base = R.contig_base[R.contig_id[r]];
-            const int lk = d_lkind(f), rk = d_rkind(f);
-            const int llen = lk == 1 ? fo : (lk == 2 ? 1 : 0), rlen = rk == 1 ? lo : (rk == 2 ? 1 : 0);   // d_llen / d_rlen
-            if (mq < P.minq) continue;                                                                  // d_passes
-            if (lk && rk && ql - rlen - llen < P.minial) continue;
-            if (rk) {   // right clip -> 5p site (findflanks.py:117-118, 594-597); d_rsite
-                const int32_t site = rk == 1 ? re : re - 1;
-                const uint32_t gpos = base + (uint32_t)(site + 1);
-                d_mark_site(M, gpos, lo >= P.minlen, &s_new);   // meets_minlength_right: raw length of the last CIGAR op (quirk Q1)
-                d_stage_event(((uint64_t)gpos << 32) | (uint64_t)(uint32_t)r, stage, &s_n, ev, ev_count, cap);
-            }
-            if (lk) {   // left clip -> 3p site (findflanks.py:120-121, 599-602); d_lsite
-                const int32_t site = lk == 1 ? rs - 1 : rs;
-                const uint32_t gpos = base + (uint32_t)(site + 1);
-                d_mark_site(M, gpos, fo >= P.minlen, &s_new);   // meets_minlength_left: raw length of the first CIGAR op
-                d_stage_event(((uint64_t)gpos << 32) | (1ull << 31) | (uint64_t)(uint32_t)r, stage, &s_n, ev, ev_count, cap);
-            }
-        }
+        const uint32_t ncl = s_ncl < CL_CAP ? s_ncl : CL_CAP;
+        for (uint32_t i = threadIdx.x; i < ncl; i += SCAN_THREADS) d_clip_events(R, P, (int64_t)cl_r[i], cl_f[i], stage, &s_n, ev, ev_count, cap);
         __syncthreads();
         if (threadIdx.x == 0) s_ncl = 0;
         // the stage fills up at deep sites: flush it between tiles once it is half full
@@ -120,40 +117,8 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_clips(DevReads R, DevPara
     }
     const uint32_t n = s_n < EV_STAGE ? s_n : EV_STAGE;
     if (threadIdx.x == 0 && n) s_base = atomicAdd(ev_count, n);
-    if (threadIdx.x == 0 && s_new) atomicAdd(n_sites_all, s_new);
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < n; i += SCAN_THREADS) if (s_base + i < cap) ev[s_base + i] = stage[i];
-}
-
-// events of strong sites -> ev2 (order arbitrary, the sort follows)
-__global__ __launch_bounds__(256) void k_keep_strong(const uint64_t *ev, const uint32_t *ev_count, uint32_t cap, const uint32_t *strong, uint64_t *ev2, uint32_t *ev2_count) {
-    __shared__ uint64_t stage[EV_STAGE];
-    __shared__ uint32_t s_n, s_base;
-    const uint32_t E = *ev_count < cap ? *ev_count : cap;
-    if (threadIdx.x == 0) s_n = 0;
-    __syncthreads();
-    for (uint32_t base = blockIdx.x * 256; base < E; base += gridDim.x * 256) {
-        const uint32_t i = base + threadIdx.x;
-        if (i < E) {
-            const uint64_t key = ev[i];
-            const uint32_t g = (uint32_t)(key >> 32);
-            if ((strong[g >> 5] >> (g & 31)) & 1) stage[atomicAdd(&s_n, 1u)] = key;   // at most 256 per round: the stage has room
-        }
-        __syncthreads();
-        if (s_n > EV_STAGE - 256) {
-            const uint32_t n = s_n;
-            if (threadIdx.x == 0) s_base = atomicAdd(ev2_count, n);
-            __syncthreads();
-            for (uint32_t k = threadIdx.x; k < n; k += 256) ev2[s_base + k] = stage[k];
-            __syncthreads();
-            if (threadIdx.x == 0) s_n = 0;
-        }
-        __syncthreads();
-    }
-    const uint32_t n = s_n;
-    if (threadIdx.x == 0 && n) s_base = atomicAdd(ev2_count, n);
-    __syncthreads();
-    for (uint32_t k = threadIdx.x; k < n; k += 256) ev2[s_base + k] = stage[k];
 }
 
 // ---- K2: per-event information ---------------------------------------------------------------------------------
@@ -188,32 +153,49 @@ struct SiteTab {
     uint32_t *st;                                      // bit0 keep_5p, bit1 keep_3p, bit2 alive
 };
 
-__global__ void k_site_accumulate(DevReads R, const uint64_t *keys, const uint8_t *info, const uint32_t *head_scan, uint32_t E, SiteTab T) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= E) return;
-    uint8_t in = info[i];
-    uint32_t s = head_scan[i] + (in & 1) - 1;   // exclusive scan of heads + own head - 1
-    uint64_t key = keys[i];
-    int side = (in >> 3) & 1;
-    if (in & 1) {
-        T.gpos[s] = (uint32_t)(key >> 32);
-        T.contig[s] = (int32_t)R.contig_id[key & 0x7fffffffu];
-        T.ev_begin[s] = i;
-        if (s > 0) T.ev_end[s - 1] = i;
+// Events are sorted, so the events of one (site, side) are neighbours: a segmented scan inside each wave adds them up
+// and only the last lane of a run touches the site's counters (a 1000x site would otherwise put ~500 atomics on one word).
+__global__ __launch_bounds__(256) void k_site_accumulate(DevReads R, const uint64_t *keys, const uint8_t *info, const uint32_t *head_scan, uint32_t E, SiteTab T) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const bool valid = i < E;
+    uint32_t seg = 0xFFFFFFFFu, add = 0, orb = 0, s = 0;
+    int side = 0;
+    if (valid) {
+        const uint8_t in = info[i];
+        s = head_scan[i] + (in & 1) - 1;   // exclusive scan of heads + own head - 1
+        const uint64_t key = keys[i];
+        side = (in >> 3) & 1;
+        if (in & 1) {
+            T.gpos[s] = (uint32_t)(key >> 32);
+            T.contig[s] = (int32_t)R.contig_id[key & 0x7fffffffu];
+            T.ev_begin[s] = i;
+            if (s > 0) T.ev_end[s - 1] = i;
+        }
+        if (i == E - 1) T.ev_end[s] = E;
+        if (side == 1 && ((in & 1) || !((info[i - 1] >> 3) & 1))) T.ev_mid[s] = i;
+        seg = 2 * s + (uint32_t)side;
+        add = (in & 2) ? 1u : 0u;
+        orb = (in & 4) ? 1u : 0u;
     }
-    if (i == E - 1) T.ev_end[s] = E;
-    if (side == 1 && ((in & 1) || !((info[i - 1] >> 3) & 1))) T.ev_mid[s] = i;
-    if (in & 2) atomicAdd(&T.cnt2[2 * s + side], 1u);
-    if (in & 4) atomicOr(&T.sflags[s], 1u << side);
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t k2 = __shfl_up(seg, d, 64), a2 = __shfl_up(add, d, 64), o2 = __shfl_up(orb, d, 64);
+        if (lane >= d && k2 == seg) { add += a2; orb |= o2; }
+    }
+    const uint32_t nxt = __shfl_down(seg, 1, 64);
+    if (valid && (lane == 63 || nxt != seg)) {
+        if (add) atomicAdd(&T.cnt2[seg], add);
+        if (orb) atomicOr(&T.sflags[s], 1u << side);
+    }
 }
 
 // site state + filter_softclips_minlength (findflanks.py:124-145) + filter_softclips_mincount (148-169) in one pass;
 // `upto`: 0 = state only, 1 = + minlength, 2 = + mincount
-__global__ void k_site_filters(SiteTab T, const uint32_t *n_sites_p, int mincount, int upto, uint32_t *stats) {
-    uint32_t n = *n_sites_p;
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    int alive1 = 0, alive2 = 0;
-    if (i < n) {
+__global__ __launch_bounds__(256) void k_site_filters(SiteTab T, const uint32_t *n_sites_p, int mincount, int upto, uint32_t *stats) {
+    const uint32_t n = *n_sites_p;
+    uint32_t c1 = 0, c2 = 0;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         if (T.ev_mid[i] == 0xFFFFFFFFu) T.ev_mid[i] = T.ev_end[i];
         uint32_t s = 7;
         if (upto >= 1) {
@@ -221,20 +203,28 @@ __global__ void k_site_filters(SiteTab T, const uint32_t *n_sites_p, int mincoun
             if (!(m & 1)) s &= ~1u;
             if (!(m & 2)) s &= ~2u;
             if (!(s & 3)) s &= ~4u;
-            alive1 = (s >> 2) & 1;
+            c1 += (s >> 2) & 1;
         }
         if (upto >= 2 && (s & 4)) {
             if ((int64_t)T.cnt2[2 * i] < (int64_t)mincount) s &= ~1u;
             if ((int64_t)T.cnt2[2 * i + 1] < (int64_t)mincount) s &= ~2u;
             if (!(s & 3)) s &= ~4u;
-            alive2 = (s >> 2) & 1;
+            c2 += (s >> 2) & 1;
         }
         T.st[i] = s;
     }
-    int c1 = __syncthreads_count(alive1);
-    int c2 = __syncthreads_count(alive2);
-    if (threadIdx.x == 0 && c1) atomicAdd(&stats[1], (uint32_t)c1);
-    if (threadIdx.x == 0 && c2) atomicAdd(&stats[2], (uint32_t)c2);
+    // one pair of atomics per workgroup (the grid is capped, see the launch)
+    __shared__ uint32_t sh[2];
+    if (threadIdx.x < 2) sh[threadIdx.x] = 0;
+    __syncthreads();
+    for (int o = 32; o > 0; o >>= 1) { c1 += __shfl_xor(c1, o, 64); c2 += __shfl_xor(c2, o, 64); }
+    if ((threadIdx.x & 63) == 0) { if (c1) atomicAdd(&sh[0], c1); if (c2) atomicAdd(&sh[1], c2); }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (blockIdx.x == 0) stats[0] = n;
+        if (sh[0]) atomicAdd(&stats[1], sh[0]);
+        if (sh[1]) atomicAdd(&stats[2], sh[1]);
+    }
 }
 
 // filter_softclips_mindistance findflanks.py:171-200.  A site with 5p clips needs a surviving site with 3p clips at a
@@ -416,37 +406,25 @@ extern "C" int mfk_findflanks(mfk_ctx *ctx, const mfk_reads *reads, const mfk_pa
     unsigned nblk = (unsigned)((ngroups + SCAN_THREADS - 1) / SCAN_THREADS);
     if (nblk > SCAN_MAX_BLOCKS) nblk = SCAN_MAX_BLOCKS;
     if (nblk < 1) nblk = 1;
-    // from the minlength filter on only strong sites matter: their events alone are sorted (k_keep_strong)
-    const bool prefilter = stop_after >= MFK_STAGE_MINLENGTH;
-    const size_t bm_words = ((size_t)R.gpos_span >> 5) + 2;
     uint32_t *d_stats = nullptr, *ev_count = nullptr;
-    SiteMaps M; M.all = nullptr; M.strong = nullptr;
-    uint32_t E_all = 0, E = 0;
+    uint32_t E = 0;
     uint64_t *ev = nullptr;
     uint64_t cap64 = (uint64_t)R.n / 8 + 65536;            // clips are a few percent of the reads; grown on overflow
     for (int attempt = 0; attempt < 2; attempt++) {
         if (cap64 > 2 * (uint64_t)R.n + 16) cap64 = 2 * (uint64_t)R.n + 16;
         if (cap64 > 0xFFFFFFF0ull) { snprintf(ctx->err, sizeof ctx->err, "more than 2^32 soft-clip events in one call"); return 1; }
-        uint64_t *ev_all = aalloc<uint64_t>(ctx, (size_t)cap64);
-        ev = prefilter ? aalloc<uint64_t>(ctx, (size_t)cap64) : ev_all;
-        if (!ev_all || !ev) return 1;
+        ev = aalloc<uint64_t>(ctx, (size_t)cap64);
+        if (!ev) return 1;
         FillGroup z(ctx, 0);
-        z.want(&d_stats, MFK_N_STATS); z.want(&ev_count, 4); z.want(&M.all, bm_words);
-        if (prefilter) z.want(&M.strong, bm_words);
+        z.want(&d_stats, MFK_N_STATS); z.want(&ev_count, 4);
         if (z.commit()) return 1;
-        PROF_LAUNCH(k_scan_clips, dim3(nblk), dim3(SCAN_THREADS), 0, st, R, P, ev_all, ev_count, (uint32_t)cap64, M, d_stats);
+        PROF_LAUNCH(k_scan_clips, dim3(nblk), dim3(SCAN_THREADS), 0, st, R, P, ev, ev_count, (uint32_t)cap64);
         KCHK();
-        if (prefilter) {
-            PROF_LAUNCH(k_keep_strong, dim3(256), dim3(256), 0, st, (const uint64_t *)ev_all, (const uint32_t *)ev_count, (uint32_t)cap64, (const uint32_t *)M.strong, ev, ev_count + 1);
-            KCHK();
-        }
-        uint32_t h_cnt[2] = {0, 0};
-        if (int rc = read_back(ctx, ev_count, h_cnt, 8)) return rc;
-        E_all = h_cnt[0]; E = prefilter ? h_cnt[1] : h_cnt[0];
-        if ((uint64_t)E_all <= cap64) break;
-        cap64 = (uint64_t)E_all + 16;                        // every event was counted: exact size for the second try
+        if (int rc = read_back(ctx, ev_count, &E, 4)) return rc;
+        if ((uint64_t)E <= cap64) break;
+        cap64 = (uint64_t)E + 16;                            // every event was counted: exact size for the second try
     }
-    ctx->stats[10] = E_all;
+    ctx->stats[10] = E;
 
     uint32_t n_act = 0;
     ActTab A; memset(&A, 0, sizeof A);
@@ -475,7 +453,7 @@ extern "C" int mfk_findflanks(mfk_ctx *ctx, const mfk_reads *reads, const mfk_pa
         PROF_LAUNCH(k_site_accumulate, dim3(eb), dim3(256), 0, st, R, (const uint64_t *)ev_sorted, (const uint8_t *)ev_info, (const uint32_t *)head_scan, E, T);
         KCHK();
         const int upto = stop_after >= MFK_STAGE_MINCOUNT ? 2 : (stop_after >= MFK_STAGE_MINLENGTH ? 1 : 0);
-        PROF_LAUNCH(k_site_filters, dim3(eb), dim3(256), 0, st, T, n_sites_p, P.mincount, upto, d_stats);
+        PROF_LAUNCH(k_site_filters, dim3(eb < 256 ? eb : 256), dim3(256), 0, st, T, n_sites_p, P.mincount, upto, d_stats);
         KCHK();
         if (stop_after >= MFK_STAGE_MINDIST1) {
             PROF_LAUNCH(k_mindistance, dim3(eb), dim3(256), 0, st, (const uint32_t *)T.gpos, (const uint32_t *)T.cnt2, (const uint32_t *)T.st, st2, n_sites_p, 0u, P.mindist, d_stats + 3, alive);

@@ -68,32 +68,33 @@ __device__ void d_ir_detect(const uint8_t *code, int L, int16_t *S, uint8_t *mas
     __syncthreads();
     int nrep = 0;
     // Anti-diagonal wavefront held in registers: lane owns rows iA = lane and iB = lane + 64 (L <= 100) and keeps its
-    // cells of the last two diagonals; the cells of row i+1 come from the next lane by a shuffle.  S is still written to
-    // LDS, but only the traceback reads it, so a diagonal costs a few shuffles instead of three LDS round trips + a barrier.
+    // cells of the last two diagonals packed in one register (scores fit 16 bits); the cells of row i+1 come from the
+    // next lane through a DPP wave shift, row 64 (lane 0's second slot) reaches lane 63 through a scalar broadcast.  S is
+    // still written to LDS, but only the traceback reads it; the column characters are fetched one diagonal ahead, so a
+    // diagonal is a short chain of VALU instructions instead of three LDS round trips and a barrier.
     const int iA = lane, iB = lane + 64;
+    uint8_t *cm = mask + IR_MAXLEN + 4;   // code | masked << 3, rebuilt every pass (the caller's mask array has room for it)
     while (nrep < IR_MAXREP) {
-        for (int i = lane; i < L; i += 64) S[i * L + i] = 0;
-        const int cA = iA < L ? code[iA] : 4, cB = iB < L ? code[iB] : 4;
-        const bool mA = iA < L ? mask[iA] != 0 : true, mB = iB < L ? mask[iB] != 0 : true;
-        int p1A = 0, p2A = 0, p1B = 0, p2B = 0;   // S(i, i+d-1) and S(i, i+d-2)
-        int cjA = iA + 1 < L ? code[iA + 1] : 4, cjB = iB + 1 < L ? code[iB + 1] : 4;
-        bool mjA = iA + 1 < L ? mask[iA + 1] != 0 : true, mjB = iB + 1 < L ? mask[iB + 1] != 0 : true;
+        for (int i = lane; i < L; i += 64) { S[i * L + i] = 0; cm[i] = (uint8_t)(code[i] | (mask[i] ? 8 : 0)); }
+        __syncthreads();
+        const int cA = iA < L ? cm[iA] : 12, cB = iB < L ? cm[iB] : 12;
+        int cjA = iA + 1 < L ? cm[iA + 1] : 12, cjB = iB + 1 < L ? cm[iB + 1] : 12;
+        unsigned pA = 0, pB = 0;               // S(i, i+d-1) | S(i, i+d-2) << 16
         unsigned bestkey = 0;   // score << 16 | (255 - j) << 8 | i : highest score, then smallest j, then largest i
+        const int nB = L - 64;  // row B has cells only on diagonals d < L - 64
         for (int d = 1; d < L; d++) {
-            int n1A = __shfl_down(p1A, 1, 64), n2A = __shfl_down(p2A, 1, 64);
-            const int n1B = __shfl_down(p1B, 1, 64), n2B = __shfl_down(p2B, 1, 64);
-            const int b1 = __shfl(p1B, 0, 64), b2 = __shfl(p2B, 0, 64);
-            if (lane == 63) { n1A = b1; n2A = b2; }   // row 64 lives in lane 0's second slot
+            unsigned nA = (unsigned)__builtin_amdgcn_update_dpp(0, (int)pA, 0x130 /* wave_shl:1: lane i <- lane i+1 */, 0xF, 0xF, false);
+            const unsigned fromB = (unsigned)__builtin_amdgcn_readfirstlane((int)pB);
+            if (lane == 63) nA = fromB;
             // next diagonal's column characters: issued now, used in the next iteration
-            const int ncjA = iA + d + 1 < L ? code[iA + d + 1] : 4, ncjB = iB + d + 1 < L ? code[iB + d + 1] : 4;
-            const bool nmjA = iA + d + 1 < L ? mask[iA + d + 1] != 0 : true, nmjB = iB + d + 1 < L ? mask[iB + d + 1] != 0 : true;
-            int vA = 0, vB = 0;
-            const int jA = iA + d, jB = iB + d;
+            const int ncjA = iA + d + 1 < L ? cm[iA + d + 1] : 12;
+            int vA = 0;
+            const int jA = iA + d;
             if (jA < L) {
-                if (!mA && !mjA) {
+                if (!((cA | cjA) & 8)) {
                     const int m = (cA < 4 && cjA < 4 && cA + cjA == 3) ? MATCH : MISMATCH;
-                    vA = (d >= 2 ? n2A : 0) + m;
-                    const int up = n1A - GAP, left = p1A - GAP;
+                    vA = (d >= 2 ? (int)(nA >> 16) : 0) + m;
+                    const int up = (int)(nA & 0xFFFF) - GAP, left = (int)(pA & 0xFFFF) - GAP;
                     if (up > vA) vA = up;
                     if (left > vA) vA = left;
                     if (vA < 0) vA = 0;
@@ -102,21 +103,29 @@ __device__ void d_ir_detect(const uint8_t *code, int L, int16_t *S, uint8_t *mas
                 const unsigned key = ((unsigned)vA << 16) | ((unsigned)(255 - jA) << 8) | (unsigned)iA;
                 if (vA > 0 && key > bestkey) bestkey = key;
             }
-            if (jB < L) {
-                if (!mB && !mjB) {
-                    const int m = (cB < 4 && cjB < 4 && cB + cjB == 3) ? MATCH : MISMATCH;
-                    vB = (d >= 2 ? n2B : 0) + m;
-                    const int up = n1B - GAP, left = p1B - GAP;
-                    if (up > vB) vB = up;
-                    if (left > vB) vB = left;
-                    if (vB < 0) vB = 0;
+            pA = (pA << 16) | (unsigned)vA;
+            cjA = ncjA;
+            if (d < nB) {   // wave-uniform
+                const unsigned nBv = (unsigned)__builtin_amdgcn_update_dpp(0, (int)pB, 0x130, 0xF, 0xF, false);
+                const int ncjB = iB + d + 1 < L ? cm[iB + d + 1] : 12;
+                int vB = 0;
+                const int jB = iB + d;
+                if (jB < L) {
+                    if (!((cB | cjB) & 8)) {
+                        const int m = (cB < 4 && cjB < 4 && cB + cjB == 3) ? MATCH : MISMATCH;
+                        vB = (d >= 2 ? (int)(nBv >> 16) : 0) + m;
+                        const int up = (int)(nBv & 0xFFFF) - GAP, left = (int)(pB & 0xFFFF) - GAP;
+                        if (up > vB) vB = up;
+                        if (left > vB) vB = left;
+                        if (vB < 0) vB = 0;
+                    }
+                    S[iB * L + jB] = (int16_t)vB;
+                    const unsigned key = ((unsigned)vB << 16) | ((unsigned)(255 - jB) << 8) | (unsigned)iB;
+                    if (vB > 0 && key > bestkey) bestkey = key;
                 }
-                S[iB * L + jB] = (int16_t)vB;
-                const unsigned key = ((unsigned)vB << 16) | ((unsigned)(255 - jB) << 8) | (unsigned)iB;
-                if (vB > 0 && key > bestkey) bestkey = key;
+                pB = (pB << 16) | (unsigned)vB;
+                cjB = ncjB;
             }
-            p2A = p1A; p1A = vA; p2B = p1B; p1B = vB;
-            cjA = ncjA; cjB = ncjB; mjA = nmjA; mjB = nmjB;
         }
         __syncthreads();
         for (int o = 32; o > 0; o >>= 1) { unsigned other = __shfl_xor(bestkey, o, 64); if (other > bestkey) bestkey = other; }
@@ -165,7 +174,7 @@ __device__ void d_ir_detect(const uint8_t *code, int L, int16_t *S, uint8_t *mas
 // generic entry: sequences given explicitly (mfk_ir_detect)
 __global__ __launch_bounds__(64) void k_ir_seqs(const char *seqs, const int64_t *off, uint32_t n, int32_t *out) {
     __shared__ int16_t S[IR_MAXLEN * IR_MAXLEN];
-    __shared__ uint8_t code[IR_MAXLEN + 4], mask[IR_MAXLEN + 4];
+    __shared__ uint8_t code[IR_MAXLEN + 4], mask[2 * (IR_MAXLEN + 4)];   // mask | cm (d_ir_detect)
     __shared__ int32_t rep[4 * IR_MAXREP + 8];
     uint32_t k = blockIdx.x;
     if (k >= n) return;
@@ -188,7 +197,7 @@ __device__ __forceinline__ uint64_t d_assign_key(const FlankDev &F, uint32_t a, 
 // also writes the candidate's sort key for assign_pairs (stable order by IR_length desc, diffcount asc, difflength asc)
 __global__ __launch_bounds__(64) void k_inverted_repeat(FlankDev F, const uint32_t *c5, const uint32_t *c3, uint32_t n, int32_t *out, uint64_t *keys, uint32_t *vals) {
     __shared__ int16_t S[IR_MAXLEN * IR_MAXLEN];
-    __shared__ uint8_t code[IR_MAXLEN + 4], mask[IR_MAXLEN + 4];
+    __shared__ uint8_t code[IR_MAXLEN + 4], mask[2 * (IR_MAXLEN + 4)];   // mask | cm (d_ir_detect)
     __shared__ int32_t rep[4 * IR_MAXREP + 8];
     uint32_t k = blockIdx.x;
     if (k >= n) return;
