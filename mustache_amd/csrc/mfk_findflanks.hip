@@ -2,9 +2,10 @@
 // _findflanks, findflanks.py:24-51).  Kernels, in call order:
 //
 //   k_scan_clips              parse_softclips (findflanks.py:100-121): streams the flags column (1 B/read, 16 reads per
-//                             lane per load), evaluates the read filters only for lenient-clipped reads and emits one
-//                             64-bit event key (gpos | side | read) per clip, staged in LDS, one global reservation per
-//                             workgroup; the sort that follows makes the order deterministic (keys are unique).
+//                             lane per load) and lists the lenient-clipped reads
+//   k_clip_events             read filters for the listed reads and one 64-bit event key (gpos | side | read) per clip,
+//                             staged in LDS, one global reservation per workgroup; the sort that follows makes the
+//                             order deterministic (keys are unique)
 //   rocPRIM radix sort        events -> (site, side, BAM order)
 //   k_event_info              per event: site head, first-of-its-query-name (link-chain walk, quirk Q3), meets_minlength
 //   k_site_accumulate         per-site distinct-name counts and flags (SoftclipSite, findflanks.py:727-745, 797-801)
@@ -16,51 +17,24 @@
 //   run_consensus             mfk_consensus.hip
 //   k_consensus_filters       filter_consensus_sequences_minlength/_mincount/filter_multiple (findflanks.py:241-342)
 #include "mfk_host.h"
+#include <stdlib.h>
 
 #define SCAN_THREADS 256
 #define SCAN_MAX_BLOCKS 2048
 
 // ---- K1: clip events -------------------------------------------------------------------------------------------
-// parse_softclips (findflanks.py:100-121) in one pass over tiles of 4096 reads.  Phase 1: each lane loads the flags of 16
-// consecutive reads (one dwordx4; the next tile's load is issued before this tile is processed) and pushes the
-// lenient-clipped ones (~1.5 %) to a list in LDS.  Phase 2: one thread per listed read gathers the rest of its record
-// (all column loads issued together), runs passes_read_filters and emits one 64-bit key (gpos | side | read) per clip.
-// Clipped reads pile up at the insertion sites (a 1000x site puts ~500 of them into one tile); the list spreads them
-// over the whole workgroup instead of leaving one lane with eight dependent gathers in a row.  Keys are staged in LDS
-// and flushed with one global reservation; their order is arbitrary, which is fine because keys are unique and the
-// sort that follows fixes the order.
+// parse_softclips (findflanks.py:100-121) in two kernels.
+//   k_scan_clips   streams the flags column (1 B/read; each lane loads 16 reads as one dwordx4, the next tile's load is
+//                  issued before this tile is processed) and appends the lenient-clipped reads (~1.5 %) to a list,
+//                  one reservation per workgroup and tile (block-wide prefix sum of the per-lane counts).
+//   k_clip_events  one thread per listed read: gathers the columns its clip kinds need (all loads issued together),
+//                  runs passes_read_filters and emits one 64-bit key (gpos | side | read) per clip, staged in LDS and
+//                  flushed with one reservation per workgroup.
+// Clipped reads pile up at the insertion sites (a 1000x site puts ~1000 of them into one 4096-read tile); with the list
+// in between, those gathers are spread over the whole GPU instead of serialising inside one workgroup.  The order of
+// list and keys is arbitrary: keys are unique and the sort that follows fixes the order.
 #define EV_STAGE 2048
-#define CL_CAP 1024
 #define SCAN_TILE (SCAN_THREADS * 16)
-
-__device__ __forceinline__ void d_stage_event(uint64_t key, uint64_t *stage, uint32_t *s_n, uint64_t *ev, uint32_t *ev_count, uint32_t cap) {
-    uint32_t slot = atomicAdd(s_n, 1u);
-    if (slot < EV_STAGE) stage[slot] = key;
-    else { uint32_t g = atomicAdd(ev_count, 1u); if (g < cap) ev[g] = key; }   // deeper than the stage: rare slow path
-}
-
-// one lenient-clipped read: read filters + its one or two events
-__device__ __forceinline__ void d_clip_events(const DevReads &R, const DevParams &P, int64_t r, uint8_t f, uint64_t *stage, uint32_t *s_n, uint64_t *ev, uint32_t *ev_count, uint32_t cap) {
-    // Only the columns this read's clip kinds need (every column touched costs a whole cache line of HBM traffic for
-    // one sparse read), all issued together: none of these loads depends on another
-    const int lk = d_lkind(f), rk = d_rkind(f);
-    const bool both = lk && rk;
-    const int mq = R.mapq[r];
-    const int ql = both ? R.qlen[r] : 0, fo = both ? R.first_op_len[r] : 0, lo = both ? R.last_op_len[r] : 0;
-    const int32_t rs = lk ? R.ref_start[r] : 0, re = rk ? R.ref_end[r] : 0;
-    const uint32_t base = R.contig_base[R.contig_id[r]];
-    const int llen = lk == 1 ? fo : (lk == 2 ? 1 : 0), rlen = rk == 1 ? lo : (rk == 2 ? 1 : 0);   // d_llen / d_rlen
-    if (mq < P.minq) return;                                                                    // d_passes
-    if (lk && rk && ql - rlen - llen < P.minial) return;
-    if (rk) {   // right clip -> 5p site (findflanks.py:117-118, 594-597); d_rsite
-        const int32_t site = rk == 1 ? re : re - 1;
-        d_stage_event(((uint64_t)(base + (uint32_t)(site + 1)) << 32) | (uint64_t)(uint32_t)r, stage, s_n, ev, ev_count, cap);
-    }
-    if (lk) {   // left clip -> 3p site (findflanks.py:120-121, 599-602); d_lsite
-        const int32_t site = lk == 1 ? rs - 1 : rs;
-        d_stage_event(((uint64_t)(base + (uint32_t)(site + 1)) << 32) | (1ull << 31) | (uint64_t)(uint32_t)r, stage, s_n, ev, ev_count, cap);
-    }
-}
 
 __device__ __forceinline__ uint4 d_load_flags16(const DevReads &R, int64_t g, int64_t ngroups) {
     uint4 v = make_uint4(0, 0, 0, 0);
@@ -76,13 +50,16 @@ __device__ __forceinline__ uint4 d_load_flags16(const DevReads &R, int64_t g, in
     return v;
 }
 
-__global__ __launch_bounds__(SCAN_THREADS) void k_scan_clips(DevReads R, DevParams P, uint64_t *ev, uint32_t *ev_count, uint32_t cap) {
-    __shared__ uint64_t stage[EV_STAGE];
-    __shared__ uint32_t cl_r[CL_CAP];
-    __shared__ uint8_t cl_f[CL_CAP];
-    __shared__ uint32_t s_n, s_base, s_ncl;
-    if (threadIdx.x == 0) { s_n = 0; s_ncl = 0; }
-    __syncthreads();
+// list entry: read index | flags << 32.  The list has LIST_SEGS segments of seg_cap entries, each with its own counter
+// (a cache line apart): a workgroup reserves room with one atomic per tile, and thousands of those on ONE address would
+// serialise in the L2 and cost more than the whole stream.
+#define LIST_SEGS 64
+#define SEG_PAD 32     // counters 128 bytes apart
+__global__ __launch_bounds__(SCAN_THREADS) void k_scan_clips(DevReads R, uint64_t *list, uint32_t *seg_count, uint32_t seg_cap) {
+    __shared__ uint32_t sh[8];
+    __shared__ uint32_t s_base;
+    const uint32_t seg = blockIdx.x % LIST_SEGS;
+    list += (size_t)seg * seg_cap;
     const int64_t ngroups = (R.n + 15) >> 4;
     const int64_t ntiles = (ngroups + SCAN_THREADS - 1) / SCAN_THREADS;
     uint4 nxt = d_load_flags16(R, (int64_t)blockIdx.x * SCAN_THREADS + threadIdx.x, ngroups);
@@ -90,35 +67,87 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_clips(DevReads R, DevPara
         const uint4 v = nxt;
         const int64_t r0 = (tile * SCAN_THREADS + threadIdx.x) << 4;
         if (tile + gridDim.x < ntiles) nxt = d_load_flags16(R, (tile + gridDim.x) * SCAN_THREADS + threadIdx.x, ngroups);
-        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-        if ((w[0] | w[1] | w[2] | w[3]) & 0x0F0F0F0Fu)
-            for (int k = 0; k < 16; k++) {
-                const uint8_t f = (uint8_t)(w[k >> 2] >> ((k & 3) * 8));
-                if (!(f & 15)) continue;
-                const uint32_t slot = atomicAdd(&s_ncl, 1u);
-                if (slot < CL_CAP) { cl_r[slot] = (uint32_t)(r0 + k); cl_f[slot] = f; }
-                else d_clip_events(R, P, r0 + k, f, stage, &s_n, ev, ev_count, cap);   // list full (a tile of mostly clipped reads): do it here
+        // 16-bit map of this lane's lenient-clipped reads
+        uint32_t cmap = 0;
+        {
+            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                uint32_t t = w[j];
+                t = (t | (t >> 1) | (t >> 2) | (t >> 3)) & 0x01010101u;
+                cmap |= ((t & 1u) | ((t >> 7) & 2u) | ((t >> 14) & 4u) | ((t >> 21) & 8u)) << (4 * j);
             }
-        __syncthreads();
-        const uint32_t ncl = s_ncl < CL_CAP ? s_ncl : CL_CAP;
-        for (uint32_t i = threadIdx.x; i < ncl; i += SCAN_THREADS) d_clip_events(R, P, (int64_t)cl_r[i], cl_f[i], stage, &s_n, ev, ev_count, cap);
-        __syncthreads();
-        if (threadIdx.x == 0) s_ncl = 0;
-        // the stage fills up at deep sites: flush it between tiles once it is half full
-        if (s_n >= EV_STAGE / 2) {
-            const uint32_t n = s_n < EV_STAGE ? s_n : EV_STAGE;
-            if (threadIdx.x == 0) s_base = atomicAdd(ev_count, n);
+        }
+        uint32_t total;
+        uint32_t slot = block_excl_scan(__popc(cmap), sh, &total);
+        if (total) {   // block-uniform
+            if (threadIdx.x == 0) s_base = atomicAdd(&seg_count[seg * SEG_PAD], total);
             __syncthreads();
-            for (uint32_t i = threadIdx.x; i < n; i += SCAN_THREADS) if (s_base + i < cap) ev[s_base + i] = stage[i];
+            slot += s_base;
+            const uint64_t lo = (uint64_t)v.x | ((uint64_t)v.y << 32), hi = (uint64_t)v.z | ((uint64_t)v.w << 32);
+            while (cmap) {
+                const int k = __builtin_ctz(cmap);
+                cmap &= cmap - 1;
+                const uint64_t f = ((k < 8 ? lo : hi) >> ((k & 7) * 8)) & 0xFF;
+                if (slot < seg_cap) list[slot] = (uint64_t)(r0 + k) | (f << 32);
+                slot++;
+            }
+        }
+        __syncthreads();   // s_base / sh are reused by the next tile
+    }
+}
+
+// grid (x, LIST_SEGS): workgroup (x, seg) takes every gridDim.x-th 256-entry slice of list segment seg
+__global__ __launch_bounds__(256) void k_clip_events(DevReads R, DevParams P, const uint64_t *list, const uint32_t *seg_count, uint32_t seg_cap,
+                                                     uint64_t *ev, uint32_t *ev_count, uint32_t cap) {
+    __shared__ uint64_t stage[EV_STAGE];
+    __shared__ uint32_t s_n, s_base;
+    const uint32_t cnt = seg_count[blockIdx.y * SEG_PAD];
+    const uint32_t n = cnt < seg_cap ? cnt : seg_cap;
+    list += (size_t)blockIdx.y * seg_cap;
+    if (threadIdx.x == 0) s_n = 0;
+    __syncthreads();
+    for (uint32_t b0 = blockIdx.x * 256; b0 < n; b0 += gridDim.x * 256) {   // block-uniform trip count
+        const uint32_t i = b0 + threadIdx.x;
+        if (i < n) {
+            const uint64_t e = list[i];
+            const int64_t r = (int64_t)(e & 0x7fffffffu);
+            const uint8_t f = (uint8_t)(e >> 32);
+            // Only the columns this read's clip kinds need (every column touched costs a whole cache line of HBM traffic
+            // for one sparse read), all issued together: none of these loads depends on another
+            const int lk = d_lkind(f), rk = d_rkind(f);
+            const bool both = lk && rk;
+            const int mq = R.mapq[r];
+            const int ql = both ? R.qlen[r] : 0, fo = both ? R.first_op_len[r] : 0, lo = both ? R.last_op_len[r] : 0;
+            const int32_t rs = lk ? R.ref_start[r] : 0, re = rk ? R.ref_end[r] : 0;
+            const uint32_t base = R.contig_base[R.contig_id[r]];
+            const int llen = lk == 1 ? fo : (lk == 2 ? 1 : 0), rlen = rk == 1 ? lo : (rk == 2 ? 1 : 0);   // d_llen / d_rlen
+            if (mq >= P.minq && !(both && ql - rlen - llen < P.minial)) {                               // d_passes
+                if (rk) {   // right clip -> 5p site (findflanks.py:117-118, 594-597); d_rsite
+                    const int32_t site = rk == 1 ? re : re - 1;
+                    stage[atomicAdd(&s_n, 1u)] = ((uint64_t)(base + (uint32_t)(site + 1)) << 32) | (uint64_t)(uint32_t)r;
+                }
+                if (lk) {   // left clip -> 3p site (findflanks.py:120-121, 599-602); d_lsite
+                    const int32_t site = lk == 1 ? rs - 1 : rs;
+                    stage[atomicAdd(&s_n, 1u)] = ((uint64_t)(base + (uint32_t)(site + 1)) << 32) | (1ull << 31) | (uint64_t)(uint32_t)r;
+                }
+            }
+        }
+        __syncthreads();
+        if (s_n > EV_STAGE - 512) {   // the next round adds at most 512 keys
+            const uint32_t m = s_n;
+            if (threadIdx.x == 0) s_base = atomicAdd(ev_count, m);
+            __syncthreads();
+            for (uint32_t k = threadIdx.x; k < m; k += 256) if (s_base + k < cap) ev[s_base + k] = stage[k];
             __syncthreads();
             if (threadIdx.x == 0) s_n = 0;
         }
         __syncthreads();
     }
-    const uint32_t n = s_n < EV_STAGE ? s_n : EV_STAGE;
-    if (threadIdx.x == 0 && n) s_base = atomicAdd(ev_count, n);
+    const uint32_t m = s_n;
+    if (threadIdx.x == 0 && m) s_base = atomicAdd(ev_count, m);
     __syncthreads();
-    for (uint32_t i = threadIdx.x; i < n; i += SCAN_THREADS) if (s_base + i < cap) ev[s_base + i] = stage[i];
+    for (uint32_t k = threadIdx.x; k < m; k += 256) if (s_base + k < cap) ev[s_base + k] = stage[k];
 }
 
 // ---- K2: per-event information ---------------------------------------------------------------------------------
@@ -296,7 +325,7 @@ __device__ __forceinline__ int d_set_of(const DevReads &R, const DevParams &P, i
     return cat == CAT_DELETION ? 5 + qi : -1;                     // 6 upstream, 7 downstream
 }
 
-__global__ __launch_bounds__(256) void k_classify(DevReads R, DevParams P, ActTab A, uint32_t n_act) {
+__global__ __launch_bounds__(1024) void k_classify(DevReads R, DevParams P, ActTab A, uint32_t n_act) {
     __shared__ uint32_t cnt[8];
     __shared__ int64_t range[2];
     const uint32_t k = blockIdx.x;
@@ -406,23 +435,31 @@ extern "C" int mfk_findflanks(mfk_ctx *ctx, const mfk_reads *reads, const mfk_pa
     unsigned nblk = (unsigned)((ngroups + SCAN_THREADS - 1) / SCAN_THREADS);
     if (nblk > SCAN_MAX_BLOCKS) nblk = SCAN_MAX_BLOCKS;
     if (nblk < 1) nblk = 1;
-    uint32_t *d_stats = nullptr, *ev_count = nullptr;
+    uint32_t *d_stats = nullptr, *ev_count = nullptr;   // ev_count[0] events, [SEG_PAD * (1 + seg)] listed reads of a segment
     uint32_t E = 0;
     uint64_t *ev = nullptr;
-    uint64_t cap64 = (uint64_t)R.n / 8 + 65536;            // clips are a few percent of the reads; grown on overflow
+    uint64_t cap64 = (uint64_t)R.n / 8 + 65536, seg_cap = cap64 / LIST_SEGS + 4096;   // clips are a few percent of the reads; grown on overflow
+    std::vector<uint32_t> h_cnt((size_t)SEG_PAD * (LIST_SEGS + 1));
     for (int attempt = 0; attempt < 2; attempt++) {
         if (cap64 > 2 * (uint64_t)R.n + 16) cap64 = 2 * (uint64_t)R.n + 16;
-        if (cap64 > 0xFFFFFFF0ull) { snprintf(ctx->err, sizeof ctx->err, "more than 2^32 soft-clip events in one call"); return 1; }
+        if (cap64 > 0xFFFFFFF0ull || seg_cap > 0x7FFFFFF0ull) { snprintf(ctx->err, sizeof ctx->err, "more than 2^32 soft-clip events in one call"); return 1; }
         ev = aalloc<uint64_t>(ctx, (size_t)cap64);
-        if (!ev) return 1;
+        uint64_t *list = aalloc<uint64_t>(ctx, (size_t)seg_cap * LIST_SEGS);
+        if (!ev || !list) return 1;
         FillGroup z(ctx, 0);
-        z.want(&d_stats, MFK_N_STATS); z.want(&ev_count, 4);
+        z.want(&d_stats, MFK_N_STATS); z.want(&ev_count, h_cnt.size());
         if (z.commit()) return 1;
-        PROF_LAUNCH(k_scan_clips, dim3(nblk), dim3(SCAN_THREADS), 0, st, R, P, ev, ev_count, (uint32_t)cap64);
+        PROF_LAUNCH(k_scan_clips, dim3(nblk), dim3(SCAN_THREADS), 0, st, R, list, ev_count + SEG_PAD, (uint32_t)seg_cap);
         KCHK();
-        if (int rc = read_back(ctx, ev_count, &E, 4)) return rc;
-        if ((uint64_t)E <= cap64) break;
-        cap64 = (uint64_t)E + 16;                            // every event was counted: exact size for the second try
+        PROF_LAUNCH(k_clip_events, dim3(8, LIST_SEGS), dim3(256), 0, st, R, P, (const uint64_t *)list, (const uint32_t *)(ev_count + SEG_PAD), (uint32_t)seg_cap, ev, ev_count, (uint32_t)cap64);
+        KCHK();
+        if (int rc = read_back(ctx, ev_count, h_cnt.data(), h_cnt.size() * 4)) return rc;
+        E = h_cnt[0];
+        uint64_t seg_max = 0, listed = 0;
+        for (int sgi = 0; sgi < LIST_SEGS; sgi++) { uint64_t c = h_cnt[(size_t)SEG_PAD * (1 + sgi)]; listed += c; if (c > seg_max) seg_max = c; }
+        if (seg_max <= seg_cap && (uint64_t)E <= cap64) break;
+        if (seg_max > seg_cap) { seg_cap = seg_max + 16; if (cap64 < 2 * listed + 16) cap64 = 2 * listed + 16; }   // every read was counted: exact sizes
+        else cap64 = (uint64_t)E + 16;                                                                            // every event was counted
     }
     ctx->stats[10] = E;
 
@@ -483,7 +520,7 @@ extern "C" int mfk_findflanks(mfk_ctx *ctx, const mfk_reads *reads, const mfk_pa
         PROF_LAUNCH(k_compact_sites, dim3(eb), dim3(256), 0, st, T, n_sites_p, (const uint32_t *)ascan, A);
         KCHK();
         if (stop_after >= MFK_STAGE_UNCLIPPED) {
-            PROF_LAUNCH(k_classify, dim3(n_act), dim3(256), 0, st, R, P, A, n_act);
+            PROF_LAUNCH(k_classify, dim3(n_act), dim3(1024), 0, st, R, P, A, n_act);   // few sites, ~1000 reads each: wide workgroups keep the gather chains short
             KCHK();
         }
         if (stop_after >= MFK_STAGE_RATIOS) {

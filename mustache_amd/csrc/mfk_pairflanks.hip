@@ -272,7 +272,7 @@ __device__ __forceinline__ bool d_spans(const DevReads &R, const DevParams &P, i
 }
 
 // + filter_junction_spanning pairflanks.py:421-431 (float64, strict <, quirk P9) by the block's first thread
-__global__ __launch_bounds__(256) void k_spanning(DevReads R, DevParams P, FlankDev F, const uint32_t *kept, const uint32_t *c5, const uint32_t *c3, const uint32_t *n_kept,
+__global__ __launch_bounds__(1024) void k_spanning(DevReads R, DevParams P, FlankDev F, const uint32_t *kept, const uint32_t *c5, const uint32_t *c3, const uint32_t *n_kept,
                                                   const int32_t *ir, uint32_t *spanning, uint32_t *jflag, uint32_t *pstats) {
     __shared__ uint32_t cnt;
     __shared__ int64_t range[2];
@@ -372,7 +372,11 @@ __global__ __launch_bounds__(1024) void k_direct_repeats(DevReads R, FlankDev F,
         if (r < range[1] && d_overlaps(R, r, (int32_t)es) && R.qlen[r] != 0) {
             const uint8_t f = R.flags[r];
             int64_t pi = -1;
-            { int64_t lo = prange[0], hi = prange[1]; while (lo < hi) { int64_t m = (lo + hi) >> 1; if ((int64_t)R.pool_read[m] < r) lo = m + 1; else hi = m; } if (lo < prange[1] && (int64_t)R.pool_read[lo] == r) pi = lo; }
+            {   // the pool usually holds every read of the window: then read r sits at a fixed offset from the range start
+                const int64_t guess = prange[0] + (r - range[0]);
+                if (guess < prange[1] && (int64_t)R.pool_read[guess] == r) pi = guess;
+                else { int64_t lo = prange[0], hi = prange[1]; while (lo < hi) { int64_t m = (lo + hi) >> 1; if ((int64_t)R.pool_read[m] < r) lo = m + 1; else hi = m; } if (lo < prange[1] && (int64_t)R.pool_read[lo] == r) pi = lo; }
+            }
             if (pi < 0) err = 1;
             else {
                 const uint64_t o0 = R.pool_off[pi];
@@ -576,7 +580,7 @@ extern "C" int mfk_pairflanks(mfk_ctx *ctx, const mfk_reads *reads, const mfk_pa
         PROF_LAUNCH(k_kept_keys, dim3(pb), dim3(256), 0, st, F, (const uint32_t *)order, (const uint32_t *)c5, (const uint32_t *)c3, (const uint8_t *)state, (const uint32_t *)kscan, nP, (const int32_t *)d_rank, kk, kv);
         KCHK();
         if (int rc = dev_sort_pairs64(ctx, kk, kk2, kv, kept, nP, 0, 64)) return rc;
-        PROF_LAUNCH(k_spanning, dim3(nP), dim3(256), 0, st, R, P, F, (const uint32_t *)kept, (const uint32_t *)c5, (const uint32_t *)c3, nK_p, (const int32_t *)ir, spanning, jflag, d_pstats);
+        PROF_LAUNCH(k_spanning, dim3(nP), dim3(1024), 0, st, R, P, F, (const uint32_t *)kept, (const uint32_t *)c5, (const uint32_t *)c3, nK_p, (const int32_t *)ir, spanning, jflag, d_pstats);
         KCHK();
         if (int rc = dev_excl_scan32(ctx, jflag, jscan, nP)) return rc;
         PROF_LAUNCH(k_direct_repeats, dim3(nP), dim3(1024), 0, st, R, F, (const uint32_t *)kept, nK_p, (const uint32_t *)jflag, (const uint32_t *)jscan, (const uint32_t *)spanning,
