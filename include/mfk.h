@@ -181,6 +181,9 @@ double mfk_last_device_ms(mfk_ctx *ctx);
  * fetch: names = '\n'-separated kernel names in the order of ms[] / calls[]. */
 int mfk_profile_enable(mfk_ctx *ctx, int on);
 int mfk_profile_fetch(mfk_ctx *ctx, char *names, int64_t names_cap, double *ms, int64_t *calls, int64_t cap, int64_t *n);
+/* restrict the bracketing to the kernels named in `names` ('\n'-separated; NULL or "" = every kernel), so that a timed
+ * region pays for two event records per launch only where a duration is wanted.  Also clears the totals. */
+int mfk_profile_select(mfk_ctx *ctx, const char *names);
 
 #ifdef __cplusplus
 }

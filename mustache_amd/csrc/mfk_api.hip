@@ -16,6 +16,7 @@ mfk_ctx *mfk_create(int device_id) {
     ctx->pinned_cap = 0;
     ctx->err[0] = 0;
     ctx->prof_on = false;
+    ctx->prof_skip = false;
     ctx->prof_used = 0;
     memset(ctx->stats, 0, sizeof ctx->stats);
     memset(ctx->pstats, 0, sizeof ctx->pstats);
@@ -48,6 +49,21 @@ int mfk_profile_enable(mfk_ctx *ctx, int on) {
     return 0;
 }
 
+int mfk_profile_select(mfk_ctx *ctx, const char *names) {
+    if (!ctx) return 1;
+    ctx->prof_filter.clear();
+    ctx->prof_kernel.clear(); ctx->prof_ms.clear(); ctx->prof_calls.clear();
+    if (!names) return 0;
+    const char *p = names;
+    while (*p) {
+        const char *e = strchr(p, '\n');
+        size_t len = e ? (size_t)(e - p) : strlen(p);
+        if (len) ctx->prof_filter.emplace_back(p, len);
+        p += len + (e ? 1 : 0);
+    }
+    return 0;
+}
+
 int mfk_profile_fetch(mfk_ctx *ctx, char *names, int64_t names_cap, double *ms, int64_t *calls, int64_t cap, int64_t *n) {
     if (!ctx || !n) return 1;
     int64_t k = 0, o = 0;
@@ -66,6 +82,12 @@ int mfk_profile_fetch(mfk_ctx *ctx, char *names, int64_t names_cap, double *ms, 
 
 void prof_begin(mfk_ctx *ctx, const char *name) {
     if (!ctx->prof_on) return;
+    ctx->prof_skip = false;
+    if (!ctx->prof_filter.empty()) {
+        bool hit = false;
+        for (auto &f : ctx->prof_filter) if (f == name) { hit = true; break; }
+        if (!hit) { ctx->prof_skip = true; return; }
+    }
     if (ctx->prof_used + 2 > ctx->prof_events.size()) {
         hipEvent_t a, b;
         if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { ctx->prof_on = false; return; }
@@ -76,6 +98,7 @@ void prof_begin(mfk_ctx *ctx, const char *name) {
 }
 
 void prof_end(mfk_ctx *ctx) {
+    if (ctx->prof_skip) { ctx->prof_skip = false; return; }
     if (!ctx->prof_on || ctx->prof_names.size() * 2 != ctx->prof_used + 2) return;
     (void)hipEventRecord(ctx->prof_events[ctx->prof_used + 1], ctx->stream);
     ctx->prof_used += 2;

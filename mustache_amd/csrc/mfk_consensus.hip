@@ -320,7 +320,7 @@ __global__ __launch_bounds__(64) void k_leaf_first(Words W, Jobs J, uint16_t *lc
         int l = d_lcp(a, la, W.ch + W.off[v], lv);
         mrow[j] = (uint16_t)l;
         if (l > 0) atomicMin(&tmin[l - 1], j);
-        if (l == lv) atomicMin(&W.cover[v], k);   // word v is a prefix of this leaf
+        if (l == lv) atomicMin(&W.cover[v], k);   // word v is a prefix of this leaf; fire-and-forget (a read-before-write check costs a load round trip)
     }
     __syncthreads();
     // suffix minimum over depth: lane owns `per` consecutive depths, then a wave-wide suffix scan of the lane minima
@@ -393,28 +393,32 @@ __device__ __forceinline__ int d_myers(const uint64_t (&plane)[4][NL], const uin
 // DFS order of the leaves (traverse_seqs, flanktrie.py:157-170): at the first differing depth the branch whose first word
 // came earlier is visited first.  One block per leaf slot a, threads over the later leaves b; rank = #leaves before.
 __global__ __launch_bounds__(256) void k_leaf_rank(Words W, Jobs J) {
+    __shared__ uint32_t s_rank;
     const uint32_t n_leaf = W.n_list[0];
     for (uint32_t it = blockIdx.x; it < n_leaf; it += gridDim.x) {
-    uint32_t slot = W.leaf_list[it];
-    uint32_t job = W.job[slot], w0 = J.w0[job], nl = J.nl[job];
-    uint32_t ka = slot - w0;
-    if (ka + 1 >= nl) continue;
-    uint32_t wa = w0 + W.leaf_word[slot];
-    const uint8_t *a = W.ch + W.off[wa];
-    const int la = (int)W.len[wa];
-    const uint32_t *ta = W.npos + W.off[wa];
-    uint32_t rank_a = 0;
-    for (uint32_t kb = ka + 1 + threadIdx.x; kb < nl; kb += blockDim.x) {
-        uint32_t wb = w0 + W.leaf_word[w0 + kb];
-        const int lb = (int)W.len[wb];
-        const int m = la < lb ? la : lb;
-        int k = d_lcp(a, la, W.ch + W.off[wb], lb);
-        if (k < m) {
-            uint32_t tav = ta[k], tbv = W.npos[W.off[wb] + k];   // same depth: positions order like first-word indices
-            if (tav < tbv) atomicAdd(&W.leaf_rank[w0 + kb], 1u); else rank_a++;
+        __syncthreads();
+        if (threadIdx.x == 0) s_rank = 0;
+        __syncthreads();
+        const uint32_t slot = W.leaf_list[it];
+        const uint32_t job = W.job[slot], w0 = J.w0[job], nl = J.nl[job];
+        const uint32_t ka = slot - w0;
+        const uint32_t wa = w0 + W.leaf_word[slot];
+        const uint8_t *a = W.ch + W.off[wa];
+        const int la = (int)W.len[wa];
+        const uint32_t *ta = W.npos + W.off[wa];
+        uint32_t before = 0;   // leaves visited before a: every leaf counts its own predecessors, nobody writes to another leaf
+        for (uint32_t kb = threadIdx.x; kb < nl; kb += blockDim.x) {
+            if (kb == ka) continue;
+            const uint32_t wb = w0 + W.leaf_word[w0 + kb];
+            const int lb = (int)W.len[wb];
+            const int m = la < lb ? la : lb;
+            const int k = d_lcp(a, la, W.ch + W.off[wb], lb);
+            if (k < m && W.npos[W.off[wb] + k] < ta[k]) before++;   // same depth: positions order like first-word indices
         }
-    }
-    if (rank_a) atomicAdd(&W.leaf_rank[slot], rank_a);
+        for (int o = 32; o > 0; o >>= 1) before += __shfl_xor(before, o, 64);
+        if ((threadIdx.x & 63) == 0 && before) atomicAdd(&s_rank, before);
+        __syncthreads();
+        if (threadIdx.x == 0) W.leaf_rank[slot] = s_rank;
     }
 }
 
@@ -534,9 +538,20 @@ __global__ __launch_bounds__(256) void k_components(Words W, Jobs J, int final_p
         for (uint32_t p = 1; p < np; p++) if (pc[p] > pc[best]) best = p;
         J.giant[job] = label[best];
     }
-    if (final_pass)   // list of the cluster representatives for k_reach_init / k_cluster_vote
-        for (uint32_t a = threadIdx.x; a < nl; a += blockDim.x)
-            if (label[a] == a) W.rep_list[atomicAdd(&W.n_list[1], 1u)] = w0 + a;
+    if (final_pass) {   // list of the cluster representatives for k_cluster_vote: one global reservation per job
+        __shared__ uint32_t s_nrep, s_rbase;
+        __syncthreads();
+        if (threadIdx.x == 0) s_nrep = 0;
+        __syncthreads();
+        uint32_t mine = 0;
+        for (uint32_t a = threadIdx.x; a < nl; a += blockDim.x) if (label[a] == a) mine++;
+        uint32_t at = mine ? atomicAdd(&s_nrep, mine) : 0;
+        __syncthreads();
+        if (threadIdx.x == 0 && s_nrep) s_rbase = atomicAdd(&W.n_list[1], s_nrep);
+        __syncthreads();
+        at += s_rbase;
+        for (uint32_t a = threadIdx.x; a < nl; a += blockDim.x) if (label[a] == a) W.rep_list[at++] = w0 + a;
+    }
 }
 
 // ---- trie node sums ---------------------------------------------------------------------------------------------------

@@ -344,6 +344,7 @@ __global__ __launch_bounds__(1024) void k_classify(DevReads R, DevParams P, ActT
     }
     __syncthreads();
     const int64_t lo = range[0], hi = range[1];
+    uint32_t mine[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // per-thread tallies: one LDS atomic per set and wave at the end
     for (int64_t r = lo + threadIdx.x; r < hi; r += blockDim.x) {
         if (!d_overlaps(R, r, start)) continue;
         const uint8_t f = R.flags[r];
@@ -363,8 +364,17 @@ __global__ __launch_bounds__(1024) void k_classify(DevReads R, DevParams P, ActT
                 if (!d_passes(R, P, p, fp)) continue;
                 if (d_set_of(R, P, p, fp, q, qi) == set) { dup = true; break; }
             }
-            if (!dup) atomicAdd(&cnt[set], 1u);
+            if (!dup) {
+#pragma unroll
+                for (int c = 0; c < 8; c++) if (c == set) mine[c]++;
+            }
         }
+    }
+#pragma unroll
+    for (int c = 0; c < 8; c++) {
+        uint32_t v = mine[c];
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        if ((threadIdx.x & 63) == 0 && v) atomicAdd(&cnt[c], v);
     }
     __syncthreads();
     if (threadIdx.x < 8) A.counts[8 * k + threadIdx.x] = cnt[threadIdx.x];

@@ -24,6 +24,8 @@ struct mfk_ctx {
     char err[1024];
     // optional per-kernel timing (mfk_profile_enable): HIP events around every launch on the ctx stream
     bool prof_on;
+    std::vector<std::string> prof_filter;      // empty = every kernel
+    bool prof_skip;                            // the launch between prof_begin / prof_end is not bracketed
     std::vector<hipEvent_t> prof_events;       // pool, two per launch
     std::vector<const char *> prof_names;      // launches of the current call
     size_t prof_used;

@@ -290,6 +290,7 @@ __global__ __launch_bounds__(1024) void k_spanning(DevReads R, DevParams P, Flan
         if (threadIdx.x == 0) { cnt = 0; range[0] = a; range[1] = b; }
     }
     __syncthreads();
+    uint32_t mine = 0;
     for (int64_t r = range[0] + threadIdx.x; r < range[1]; r += blockDim.x) {
         if (!d_overlaps(R, r, start)) continue;
         uint8_t f = R.flags[r];
@@ -302,8 +303,10 @@ __global__ __launch_bounds__(1024) void k_spanning(DevReads R, DevParams P, Flan
             uint8_t fp = R.flags[p];
             if (d_passes(R, P, p, fp) && d_spans(R, P, p, fp, pos3, pos5)) { dup = true; break; }
         }
-        if (!dup) atomicAdd(&cnt, 1u);
+        if (!dup) mine++;
     }
+    for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o, 64);
+    if ((threadIdx.x & 63) == 0 && mine) atomicAdd(&cnt, mine);
     __syncthreads();
     if (threadIdx.x == 0) {
         spanning[k] = cnt;

@@ -112,6 +112,7 @@ class Binding:
         if hasattr(self.so, prefix + "profile_enable"):
             f("profile_enable", C.c_int, [_p, C.c_int])
             f("profile_fetch", C.c_int, [_p, _p, C.c_int64, _p, _p, C.c_int64, C.POINTER(C.c_int64)])
+            f("profile_select", C.c_int, [_p, C.c_char_p])
         self.ctx = self.create(device_id)
         if not self.ctx:
             raise MfkError("%screate(%d) failed: no usable HIP device for %s" % (prefix, device_id, path))
@@ -199,6 +200,10 @@ class Binding:
     def profile(self, on=True):
         """Start (and clear) or stop per-kernel HIP-event timing of the compute calls."""
         self._check(self.profile_enable(self.ctx, 1 if on else 0))
+
+    def profile_only(self, names):
+        """Time only the named kernels (empty / None = all); clears the totals."""
+        self._check(self.profile_select(self.ctx, "\n".join(names or []).encode()))
 
     def profile_totals(self):
         """dict kernel name -> (total ms, launches) since profile(True)."""
