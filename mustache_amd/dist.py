@@ -70,35 +70,58 @@ def owned(rows, own, contig=None):
     return rows[m]
 
 
-def allgather_flanks(flanks, seqs, device=None):
+GATHER_CAP = 64 * 1024     # bytes per rank that travel in the first (normally only) collective
+
+
+def _all_gather_bytes(mine, ws):
+    """all-gather of equally sized uint8 tensors -> (ws, n) tensor."""
+    import torch
+    import torch.distributed as dist
+    if dist.get_backend() == "nccl":
+        out = torch.empty((ws, mine.numel()), dtype=torch.uint8, device=mine.device)
+        dist.all_gather_into_tensor(out, mine)
+        return out
+    parts = [torch.zeros_like(mine) for _ in range(ws)]
+    dist.all_gather(parts, mine)
+    return torch.stack(parts)
+
+
+def allgather_flanks(flanks, seqs, device=None, cap=GATHER_CAP):
     """Merge per-rank flank tables (FLANK_DTYPE rows + their sequence bytes).  Returns (rows, seqs) with seq_off
-    rebased, ranks concatenated in rank order.  Works without torch.distributed initialised (single process)."""
+    rebased, ranks concatenated in rank order.  Works without torch.distributed initialised (single process).
+
+    One collective in the common case: every rank sends a 16-byte header (row count, sequence bytes) followed by its
+    rows and sequences, padded to `cap` bytes.  Only if some rank's table is larger than `cap` does a second all-gather
+    with the true maximum follow (all ranks see the same headers, so they agree on that without talking)."""
     import torch
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return flanks, seqs
     ws = dist.get_world_size()
     dev = device if device is not None else ("cuda" if dist.get_backend() == "nccl" else "cpu")
-    counts = torch.tensor([flanks.shape[0], len(seqs)], dtype=torch.int64, device=dev)
-    all_counts = [torch.zeros(2, dtype=torch.int64, device=dev) for _ in range(ws)]
-    dist.all_gather(all_counts, counts)
-    all_counts = torch.stack(all_counts).cpu().numpy()
-    max_rows, max_bytes = int(all_counts[:, 0].max()), int(all_counts[:, 1].max())
     rec = _lib.FLANK_DTYPE.itemsize
-    buf = np.zeros(max_rows * rec + max_bytes, dtype=np.uint8)
-    buf[:flanks.shape[0] * rec] = np.frombuffer(np.ascontiguousarray(flanks).tobytes(), dtype=np.uint8)
-    buf[max_rows * rec:max_rows * rec + len(seqs)] = np.frombuffer(seqs, dtype=np.uint8)
-    mine = torch.from_numpy(buf).to(dev)
-    gathered = [torch.zeros_like(mine) for _ in range(ws)]
-    if mine.numel():
-        dist.all_gather(gathered, mine)
+    body = np.ascontiguousarray(flanks).tobytes() + bytes(seqs)
+    head = np.array([flanks.shape[0], len(seqs)], dtype=np.int64).tobytes()
+
+    def exchange(size):
+        buf = np.zeros(16 + size, dtype=np.uint8)
+        buf[:16] = np.frombuffer(head, dtype=np.uint8)
+        n = min(len(body), size)
+        buf[16:16 + n] = np.frombuffer(body[:n], dtype=np.uint8)
+        return _all_gather_bytes(torch.from_numpy(buf).to(dev), ws).cpu().numpy()
+
+    got = exchange(cap)
+    counts = got[:, :16].copy().view(np.int64).reshape(ws, 2)
+    need = int((counts[:, 0] * rec + counts[:, 1]).max())
+    if need > cap:
+        got = exchange(need)
     rows, blobs, off = [], [], 0
     for r in range(ws):
-        nr, nb = int(all_counts[r, 0]), int(all_counts[r, 1])
-        g = gathered[r].cpu().numpy()
+        nr, nb = int(counts[r, 0]), int(counts[r, 1])
+        g = got[r, 16:]
         part = np.frombuffer(g[:nr * rec].tobytes(), dtype=_lib.FLANK_DTYPE).copy()
         part["seq_off"] += off
         rows.append(part)
-        blobs.append(g[max_rows * rec:max_rows * rec + nb].tobytes())
+        blobs.append(g[nr * rec:nr * rec + nb].tobytes())
         off += nb
     return np.concatenate(rows) if rows else flanks, b"".join(blobs)

@@ -23,7 +23,7 @@ def _free_port():
     return port
 
 
-def _worker(rank, world, port, out_dir):
+def _worker(rank, world, port, out_dir, cap):
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from oracle.oracle import Oracle
@@ -45,7 +45,7 @@ def _worker(rank, world, port, out_dir):
         row["seq_off"] = off
         off += len(s)
         seqs.append(s)
-    rows, blob = mdist.allgather_flanks(mine, b"".join(seqs), device="cpu")
+    rows, blob = mdist.allgather_flanks(mine, b"".join(seqs), device="cpu", cap=cap)
     if rank == 0:
         np.save(os.path.join(out_dir, "rows.npy"), rows)
         with open(os.path.join(out_dir, "seqs.bin"), "wb") as fh:
@@ -53,9 +53,10 @@ def _worker(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
-def test_coordinate_shards_merge_to_the_unsharded_table(tmp_path, oracle):
+@pytest.mark.parametrize("cap", [mdist.GATHER_CAP, 64])   # 64 bytes: the table does not fit, the second all-gather runs
+def test_coordinate_shards_merge_to_the_unsharded_table(tmp_path, oracle, cap):
     world = 2
-    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), cap), nprocs=world, join=True)
     rows = np.load(os.path.join(tmp_path, "rows.npy"))
     blob = open(os.path.join(tmp_path, "seqs.bin"), "rb").read()
     case = util.load_json("sim_b")
