@@ -173,6 +173,15 @@ int mfk_pairflanks_fetch(mfk_ctx *ctx, mfk_pair *pairs, char *strs, int64_t *sta
  * has_ir, arm1_start, arm1_end, arm2_start, arm2_end (1-based inclusive, einverted convention), n_reported. */
 int mfk_ir_detect(mfk_ctx *ctx, const char *seqs, const int64_t *off, int64_t n, int32_t *out);
 
+/* recall: per-site read tallies at GIVEN positions (replaces Recaller.parse_clipped_and_unclipped_read_info,
+ * recall.py:50-112, with get_reads_at_site / get_unclipped_read_info_at_site of findflanks.py:399-452).  Sites are host
+ * arrays (contig id, 0-based position, -1 .. contig length); counts_out: n_sites x 10 int32 in the order softclip_5p,
+ * softclip_3p, runthrough, small_insertion_5p, small_insertion_3p, large_insertion_5p, large_insertion_3p, deletion,
+ * upstream_deletion, downstream_deletion (distinct query names each).  Uses min_alignment_quality,
+ * min_alignment_inner_length and large_insertion_cutoff of params. */
+int mfk_recall(mfk_ctx *ctx, const mfk_reads *reads, const mfk_params *params, const int32_t *h_contig_id, const int32_t *h_pos,
+               int64_t n_sites, int32_t *h_counts_out);
+
 /* time spent in device work of the last compute call, milliseconds (HIP events on the ctx stream) */
 double mfk_last_device_ms(mfk_ctx *ctx);
 

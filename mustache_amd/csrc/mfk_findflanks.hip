@@ -318,25 +318,25 @@ __global__ void k_compact_sites(SiteTab T, const uint32_t *n_p, const uint32_t *
 // One workgroup per active site.  Reads overlapping [pos-1, pos+2) (clamped, get_reads_at_site 399-415) that pass the
 // read filters are classified at pos (six categories) and, deletions only, at pos-1 and pos+1 (380-396).  A read counts
 // for a set only if no earlier read of the same query name (link chain) falls in the same set: that is len(set(names)).
+// sets: 0 runthrough, 1-2 small insertion 5p/3p, 3-4 large insertion 5p/3p, 5 deletion (qi 0, at pos); 6 / 7 deletion at
+// pos-1 / pos+1 (qi 1 / 2); recall only: 8 / 9 lenient right / left clip at pos (qi 3 / 4, recall.py:96-112)
 __device__ __forceinline__ int d_set_of(const DevReads &R, const DevParams &P, int64_t r, uint8_t f, int32_t q, int qi) {
+    if (qi == 3) return (d_rkind(f) && d_rsite(R, r, f) == q) ? 8 : -1;   // is_right_softclipped_lenient_at_site -> 5p
+    if (qi == 4) return (d_lkind(f) && d_lsite(R, r, f) == q) ? 9 : -1;   // is_left_softclipped_lenient_at_site -> 3p
     if (d_clipped_at(R, r, f, q)) return -1;                      // findflanks.py:429-430
     int cat = d_classify(R, P, r, f, q, qi != 0);
     if (qi == 0) return cat - 1;                                  // CAT_NONE -> -1
     return cat == CAT_DELETION ? 5 + qi : -1;                     // 6 upstream, 7 downstream
 }
 
-__global__ __launch_bounds__(1024) void k_classify(DevReads R, DevParams P, ActTab A, uint32_t n_act) {
-    __shared__ uint32_t cnt[8];
-    __shared__ int64_t range[2];
-    const uint32_t k = blockIdx.x;
-    if (k >= n_act) return;
-    const int32_t contig = A.contig[k];
-    const int32_t pos = (int32_t)(A.gpos[k] - R.contig_base[contig]) - 1;
+// the whole workgroup tallies one site into cnt[NSETS] (LDS); range = 2 x int64 of LDS
+template <int NSETS>
+__device__ __forceinline__ void d_site_tally(const DevReads &R, const DevParams &P, int32_t contig, int32_t pos, uint32_t *cnt, int64_t *range) {
     const int32_t clen = R.contig_len[contig];
     int32_t start = pos - 1, end = pos + 2;
     if (start < 0) start = 0;
     if (end > clen) end = clen;
-    if (threadIdx.x < 8) cnt[threadIdx.x] = 0;
+    if (threadIdx.x < NSETS) cnt[threadIdx.x] = 0;
     if (threadIdx.x < 64) {   // first wave: cooperative search of the read range
         int64_t a = 0, b = 0;
         if (start < end) d_fetch_range_wave(R, contig, start, end, &a, &b);
@@ -344,13 +344,16 @@ __global__ __launch_bounds__(1024) void k_classify(DevReads R, DevParams P, ActT
     }
     __syncthreads();
     const int64_t lo = range[0], hi = range[1];
-    uint32_t mine[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // per-thread tallies: one LDS atomic per set and wave at the end
+    uint32_t mine[NSETS];   // per-thread tallies: one LDS atomic per set and wave at the end
+#pragma unroll
+    for (int c = 0; c < NSETS; c++) mine[c] = 0;
+    constexpr int NQ = NSETS > 8 ? 5 : 3;
     for (int64_t r = lo + threadIdx.x; r < hi; r += blockDim.x) {
         if (!d_overlaps(R, r, start)) continue;
         const uint8_t f = R.flags[r];
         if (!d_passes(R, P, r, f)) continue;
-        for (int qi = 0; qi < 3; qi++) {
-            int32_t q = qi == 0 ? pos : (qi == 1 ? pos - 1 : pos + 1);
+        for (int qi = 0; qi < NQ; qi++) {
+            int32_t q = qi == 1 ? pos - 1 : (qi == 2 ? pos + 1 : pos);
             if (qi == 1 && pos - 1 < 0) continue;                 // findflanks.py:382
             if (qi == 2 && pos + 1 >= clen) continue;             // findflanks.py:387
             int set = d_set_of(R, P, r, f, q, qi);
@@ -366,18 +369,40 @@ __global__ __launch_bounds__(1024) void k_classify(DevReads R, DevParams P, ActT
             }
             if (!dup) {
 #pragma unroll
-                for (int c = 0; c < 8; c++) if (c == set) mine[c]++;
+                for (int c = 0; c < NSETS; c++) if (c == set) mine[c]++;
             }
         }
     }
 #pragma unroll
-    for (int c = 0; c < 8; c++) {
+    for (int c = 0; c < NSETS; c++) {
         uint32_t v = mine[c];
         for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
         if ((threadIdx.x & 63) == 0 && v) atomicAdd(&cnt[c], v);
     }
     __syncthreads();
+}
+
+__global__ __launch_bounds__(1024) void k_classify(DevReads R, DevParams P, ActTab A, uint32_t n_act) {
+    __shared__ uint32_t cnt[8];
+    __shared__ int64_t range[2];
+    const uint32_t k = blockIdx.x;
+    if (k >= n_act) return;
+    const int32_t contig = A.contig[k];
+    const int32_t pos = (int32_t)(A.gpos[k] - R.contig_base[contig]) - 1;
+    d_site_tally<8>(R, P, contig, pos, cnt, range);
     if (threadIdx.x < 8) A.counts[8 * k + threadIdx.x] = cnt[threadIdx.x];
+}
+
+// recall (Recaller.parse_clipped_and_unclipped_read_info, recall.py:50-112): the same tallies at GIVEN sites, plus the
+// distinct names of the reads lenient-clipped at the site.  sites: contig, pos pairs; counts: 10 per site in the order
+// softclip 5p, softclip 3p, runthrough, small ins 5p/3p, large ins 5p/3p, deletion, upstream / downstream deletion
+__global__ __launch_bounds__(1024) void k_recall(DevReads R, DevParams P, const int32_t *sites, uint32_t n, int32_t *counts) {
+    __shared__ uint32_t cnt[10];
+    __shared__ int64_t range[2];
+    const uint32_t k = blockIdx.x;
+    if (k >= n) return;
+    d_site_tally<10>(R, P, sites[2 * k], sites[2 * k + 1], cnt, range);
+    if (threadIdx.x < 10) counts[10 * k + threadIdx.x] = (int32_t)cnt[threadIdx.x < 2 ? 8 + threadIdx.x : threadIdx.x - 2];
 }
 
 // ---- K7: filter_softclips_count_ratios findflanks.py:203-239; ratios 827-845 (float64, quirk Q8) -------------------
@@ -633,5 +658,39 @@ extern "C" int mfk_findflanks_fetch(mfk_ctx *ctx, mfk_site *sites, mfk_flank *fl
     if (flanks && !ctx->flanks.empty()) memcpy(flanks, ctx->flanks.data(), ctx->flanks.size() * sizeof(mfk_flank));
     if (seqs && !ctx->seqs.empty()) memcpy(seqs, ctx->seqs.data(), ctx->seqs.size());
     if (stats) memcpy(stats, ctx->stats, sizeof ctx->stats);
+    return 0;
+}
+
+// ---- recall ---------------------------------------------------------------------------------------------------------
+extern "C" int mfk_recall(mfk_ctx *ctx, const mfk_reads *reads, const mfk_params *params, const int32_t *h_contig_id, const int32_t *h_pos,
+                          int64_t n_sites, int32_t *h_counts) {
+    if (!ctx || !reads || !params || n_sites < 0 || (n_sites > 0 && (!h_contig_id || !h_pos || !h_counts))) return 1;
+    HIPCHK(hipSetDevice(ctx->device));
+    ctx->err[0] = 0;
+    if (n_sites == 0) return 0;
+    if (n_sites > 0x7FFFFFFF / 10) { snprintf(ctx->err, sizeof ctx->err, "too many sites in one call"); return 1; }
+    for (int64_t i = 0; i < n_sites; i++) {
+        if (h_contig_id[i] < 0 || h_contig_id[i] >= reads->n_contigs) { snprintf(ctx->err, sizeof ctx->err, "site %lld: contig id %d out of range", (long long)i, h_contig_id[i]); return 1; }
+        if (h_pos[i] < -1 || h_pos[i] > reads->h_contig_len[h_contig_id[i]]) { snprintf(ctx->err, sizeof ctx->err, "site %lld: position %d outside contig", (long long)i, h_pos[i]); return 1; }
+    }
+    arena_reset(ctx);
+    DevReads R; DevParams P;
+    if (int rc = upload_reads(ctx, reads, params, &R, &P)) return rc;
+    hipStream_t st = ctx->stream;
+    const size_t pin_off = upload_reads_pinned_bytes(reads->n_contigs), bytes = (size_t)n_sites * 8;
+    char *hp = (char *)pinned_buf(ctx, pin_off + bytes);
+    int32_t *d_sites = aalloc<int32_t>(ctx, 2 * (size_t)n_sites), *d_counts = aalloc<int32_t>(ctx, 10 * (size_t)n_sites);
+    if (!hp || !d_sites || !d_counts) return 1;
+    int32_t *hs = (int32_t *)(hp + pin_off);
+    for (int64_t i = 0; i < n_sites; i++) { hs[2 * i] = h_contig_id[i]; hs[2 * i + 1] = h_pos[i]; }
+    HIPCHK(hipMemcpyAsync(d_sites, hs, bytes, hipMemcpyHostToDevice, st));
+    HIPCHK(hipEventRecord(ctx->ev0, st));
+    PROF_LAUNCH(k_recall, dim3((unsigned)n_sites), dim3(1024), 0, st, R, P, (const int32_t *)d_sites, (uint32_t)n_sites, d_counts);
+    KCHK();
+    HIPCHK(hipEventRecord(ctx->ev1, st));
+    if (int rc = read_back(ctx, d_counts, h_counts, 10 * (size_t)n_sites * 4)) return rc;
+    prof_collect(ctx);
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1) == hipSuccess) ctx->last_ms = ms;
     return 0;
 }

@@ -59,6 +59,10 @@ PAIR_DTYPE = np.dtype([(n, np.int32) for n in (
 assert SITE_DTYPE.itemsize == 56 and FLANK_DTYPE.itemsize == 72 and PAIR_DTYPE.itemsize == 96
 
 # CLI defaults are authoritative (reference main.py:68-78, 102-107), not the class defaults
+RECALL_COUNTS = ("softclip_count_5p", "softclip_count_3p", "runthrough_count", "small_insertion_count_5p",
+                 "small_insertion_count_3p", "large_insertion_count_5p", "large_insertion_count_3p", "deletion_count",
+                 "upstream_deletion_count", "downstream_deletion_count")
+
 DEFAULT_PARAMS = dict(min_softclip_length=8, min_softclip_count=2, min_alignment_quality=20,
                       min_alignment_inner_length=21, min_distance_to_mate=22, large_insertion_cutoff=30,
                       min_count_consensus=2, max_direct_repeat_length=20, min_softclip_ratio=0.10,
@@ -109,6 +113,7 @@ class Binding:
                                   C.POINTER(C.c_int64), C.POINTER(C.c_int64)])
         f("pairflanks_fetch", C.c_int, [_p, _p, _p, _p])
         f("ir_detect", C.c_int, [_p, _p, _p, C.c_int64, _p])
+        f("recall", C.c_int, [_p, C.POINTER(MfkReads), C.POINTER(MfkParams), _p, _p, C.c_int64, _p])
         if hasattr(self.so, prefix + "profile_enable"):
             f("profile_enable", C.c_int, [_p, C.c_int])
             f("profile_fetch", C.c_int, [_p, _p, C.c_int64, _p, _p, C.c_int64, C.POINTER(C.c_int64)])
@@ -195,6 +200,15 @@ class Binding:
         out = np.zeros((len(seqs), 6), dtype=np.int32)
         buf = np.frombuffer(blob, dtype=np.uint8)
         self._check(self.ir_detect(self.ctx, buf.ctypes.data, off.ctypes.data, len(seqs), out.ctypes.data))
+        return out
+
+    def run_recall(self, reads, params, contig_ids, positions):
+        """Per-site tallies at given (contig id, position) pairs -> int32 array [n, 10] in RECALL_COUNTS order."""
+        cid = np.ascontiguousarray(contig_ids, dtype=np.int32)
+        pos = np.ascontiguousarray(positions, dtype=np.int32)
+        out = np.zeros((cid.shape[0], 10), dtype=np.int32)
+        self._check(self.recall(self.ctx, C.byref(reads), C.byref(params), cid.ctypes.data, pos.ctypes.data, cid.shape[0],
+                                out.ctypes.data))
         return out
 
     def profile(self, on=True):

@@ -1,4 +1,4 @@
-"""Command line: ``mustache findflanks`` / ``mustache pairflanks`` with the reference's flags, short flags and defaults
+"""Command line: ``mustache findflanks`` / ``mustache pairflanks`` / ``mustache recall`` with the reference's flags, short flags and defaults
 (reference mustache/main.py:66-117; the CLI defaults are authoritative, not the class defaults or the help texts).
 
     python -m mustache_amd.main findflanks BAM -o out.findflanks.tsv
@@ -77,6 +77,24 @@ def pairflanks(flanksfile, bamfile, genome, max_direct_repeat_length, min_alignm
     _pairflanks(flanksfile, bamfile, genome, max_direct_repeat_length, min_alignment_quality,
                 min_alignment_inner_length, max_junction_spanning_prop, large_insertion_cutoff, output_file,
                 device=device)
+
+
+@cli.command(short_help="Recall softclip counts and runthrough counts from BAM file at specified pairflank insertions.")
+@click.argument("pairsfile", type=click.Path(exists=True))
+@click.argument("bamfile", type=click.Path(exists=True))
+@click.option("--min_alignment_quality", "-minq", default=20)
+@click.option("--min_alignment_inner_length", "-minial", default=21)
+@click.option("--large_insertion_cutoff", "-lins", default=30)
+@click.option("--output_file", "-o", default="mustache.recall.tsv")
+@click.option("--device", default="cuda:0", help="GPU to run on (not in the reference).")
+def recall(pairsfile, bamfile, min_alignment_quality, min_alignment_inner_length, large_insertion_cutoff, output_file, device):
+    """reference main.py:272-284"""
+    from .recall import _recall
+    log_params(command="recall", pairsfile=pairsfile, bamfile=bamfile, min_alignment_quality=min_alignment_quality,
+               min_alignment_inner_length=min_alignment_inner_length, large_insertion_cutoff=large_insertion_cutoff,
+               output_file=output_file)
+    _recall(pairsfile, bamfile, min_alignment_quality, min_alignment_inner_length, large_insertion_cutoff, output_file,
+            device=device)
 
 
 if __name__ == "__main__":

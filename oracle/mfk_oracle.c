@@ -211,6 +211,40 @@ static void fetch_reads(const mfk_reads *R, int32_t contig, int32_t start, int32
     }
 }
 
+/* one site: the reads of get_reads_at_site, sorted into the sets of get_unclipped_read_info_at_site (findflanks.py:418-452)
+ * at pos, the deletion sets at pos-1 / pos+1 (380-396) and, as recall.py:96-112 does, the reads lenient-clipped at pos.
+ * c10: softclip_5p softclip_3p runthrough si5 si3 li5 li3 del updel downdel (distinct query names) */
+static void tally_site(const octx *C, const mfk_reads *R, const mfk_params *P, int32_t contig, int32_t pos, int32_t *c10) {
+    int32_t clen = R->h_contig_len[contig];
+    int32_t start = pos - 1, end = pos + 2;
+    if (start < 0) start = 0;
+    if (end > clen) end = clen;
+    ivec fetched = {0}, reads = {0};
+    if (start < end) fetch_reads(R, contig, start, end, &fetched);
+    for (int64_t k = 0; k < fetched.n; k++) if (passes_read_filters(R, P, fetched.v[k])) iv_push(&reads, fetched.v[k]);
+    ivec sets[10]; memset(sets, 0, sizeof sets);  /* sc5 sc3 runthrough si5 si3 li5 li3 del up down */
+    for (int64_t k = 0; k < reads.n; k++) {
+        int64_t r = reads.v[k];
+        if (rkind(R, r) && rsite(R, r) == pos) iv_push(&sets[0], (int32_t)r);   /* is_right_softclipped_lenient_at_site -> 5p */
+        if (lkind(R, r) && lsite(R, r) == pos) iv_push(&sets[1], (int32_t)r);   /* is_left_softclipped_lenient_at_site -> 3p */
+        if (clipped_at_site(R, r, pos)) continue;
+        int cat = classify_read(R, P, r, pos, 0);
+        if (cat != CAT_NONE) iv_push(&sets[2 + cat - 1], (int32_t)r);
+    }
+    if (pos - 1 >= 0) for (int64_t k = 0; k < reads.n; k++) {
+        int64_t r = reads.v[k];
+        if (clipped_at_site(R, r, pos - 1)) continue;
+        if (classify_read(R, P, r, pos - 1, 1) == CAT_DELETION) iv_push(&sets[8], (int32_t)r);
+    }
+    if (pos + 1 < clen) for (int64_t k = 0; k < reads.n; k++) {
+        int64_t r = reads.v[k];
+        if (clipped_at_site(R, r, pos + 1)) continue;
+        if (classify_read(R, P, r, pos + 1, 1) == CAT_DELETION) iv_push(&sets[9], (int32_t)r);
+    }
+    for (int k = 0; k < 10; k++) { c10[k] = distinct_names(C, &sets[k]); iv_free(&sets[k]); }
+    iv_free(&fetched); iv_free(&reads);
+}
+
 /* ---- trie (flanktrie.py) ------------------------------------------------------------------------------------ */
 typedef struct { int32_t child[16]; int32_t first_child, last_child, next_sib, parent; int32_t ch; int32_t counter, word_count; int64_t qual; } tnode;
 typedef struct { tnode *n; int32_t cnt, cap; } trie_t;
@@ -479,32 +513,9 @@ int mfko_findflanks(void *c, const mfk_reads *R, const mfk_params *P, int stop_a
     for (int64_t i = 0; i < ns; i++) {
         site_t *s = &C->sites[i];
         if (!s->alive) continue;
-        int32_t clen = R->h_contig_len[s->contig];
-        int32_t start = s->pos - 1, end = s->pos + 2;
-        if (start < 0) start = 0;
-        if (end > clen) end = clen;
-        ivec fetched = {0}, reads = {0};
-        fetch_reads(R, s->contig, start, end, &fetched);
-        for (int64_t k = 0; k < fetched.n; k++) if (passes_read_filters(R, P, fetched.v[k])) iv_push(&reads, fetched.v[k]);
-        ivec sets[8]; memset(sets, 0, sizeof sets);  /* runthrough si5 si3 li5 li3 del up down */
-        for (int64_t k = 0; k < reads.n; k++) {
-            int64_t r = reads.v[k];
-            if (clipped_at_site(R, r, s->pos)) continue;
-            int cat = classify_read(R, P, r, s->pos, 0);
-            if (cat != CAT_NONE) iv_push(&sets[cat - 1], (int32_t)r);
-        }
-        if (s->pos - 1 >= 0) for (int64_t k = 0; k < reads.n; k++) {
-            int64_t r = reads.v[k];
-            if (clipped_at_site(R, r, s->pos - 1)) continue;
-            if (classify_read(R, P, r, s->pos - 1, 1) == CAT_DELETION) iv_push(&sets[6], (int32_t)r);
-        }
-        if (s->pos + 1 < clen) for (int64_t k = 0; k < reads.n; k++) {
-            int64_t r = reads.v[k];
-            if (clipped_at_site(R, r, s->pos + 1)) continue;
-            if (classify_read(R, P, r, s->pos + 1, 1) == CAT_DELETION) iv_push(&sets[7], (int32_t)r);
-        }
-        for (int k = 0; k < 8; k++) { s->c[2 + k] = distinct_names(C, &sets[k]); iv_free(&sets[k]); }
-        iv_free(&fetched); iv_free(&reads);
+        int32_t c10[10];
+        tally_site(C, R, P, s->contig, s->pos, c10);
+        for (int k = 0; k < 8; k++) s->c[2 + k] = c10[2 + k];
     }
     if (stop_after <= MFK_STAGE_UNCLIPPED) goto done;
     /* ---- filter_softclips_count_ratios findflanks.py:203-239; ratios findflanks.py:827-845 ---- */
@@ -874,4 +885,18 @@ int mfko_ir_report(const char *s, int L, int32_t *out) {
     ir_t rep[IR_MAXREP]; int n = ir_detect(s, L, rep);
     for (int k = 0; k < n; k++) { out[4 * k] = rep[k].a1s + 1; out[4 * k + 1] = rep[k].a1e + 1; out[4 * k + 2] = rep[k].a2s + 1; out[4 * k + 3] = rep[k].a2e + 1; }
     return n;
+}
+
+/* ---- recall (recall.py:50-112) -------------------------------------------------------------------------------------- */
+int mfko_recall(void *c, const mfk_reads *R, const mfk_params *P, const int32_t *contig_id, const int32_t *pos, int64_t n_sites, int32_t *counts) {
+    octx *C = (octx *)c;
+    if (!C || !R || !P || n_sites < 0) return 1;
+    C->err[0] = 0;
+    for (int64_t i = 0; i < n_sites; i++) {
+        if (contig_id[i] < 0 || contig_id[i] >= R->n_contigs) { snprintf(C->err, sizeof C->err, "site %lld: contig id %d out of range", (long long)i, contig_id[i]); return 1; }
+        if (pos[i] < -1 || pos[i] > R->h_contig_len[contig_id[i]]) { snprintf(C->err, sizeof C->err, "site %lld: position %d outside contig", (long long)i, pos[i]); return 1; }
+    }
+    build_name_ids(C, R);
+    for (int64_t i = 0; i < n_sites; i++) tally_site(C, R, P, contig_id[i], pos[i], counts + 10 * i);
+    return 0;
 }

@@ -173,6 +173,22 @@ def run_pairflanks(flanks_tsv_path, readset, genome, ir_finder, output_file, **p
     return df, open(output_file).read()
 
 
+def run_recall(pairs_tsv_path, readset, output_file, min_alignment_quality=20, min_alignment_inner_length=21,
+               large_insertion_cutoff=30):
+    """Run the reference's _recall (recall.py:15-28) on a ReadSet.  Returns (DataFrame, TSV text)."""
+    install_stubs()
+    from mustache.recall import _recall
+    key = "__readset_%d.bam" % id(readset)
+    _registry["bam"][key] = readset
+    del _log[:]
+    try:
+        df = _recall(pairs_tsv_path, key, min_alignment_quality, min_alignment_inner_length, large_insertion_cutoff,
+                     output_file)
+    finally:
+        del _registry["bam"][key]
+    return df, open(output_file).read()
+
+
 def reference_modules():
     install_stubs()
     from mustache import sctools, misc, flanktrie, pysamtools

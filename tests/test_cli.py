@@ -5,7 +5,7 @@ import pytest
 from click.testing import CliRunner
 
 from mustache_amd import bamio
-from mustache_amd.main import cli, findflanks, pairflanks
+from mustache_amd.main import cli, findflanks, pairflanks, recall
 from tests import util
 
 FINDFLANKS_FLAGS = {  # long, short, default   (reference main.py:68-78)
@@ -20,7 +20,12 @@ PAIRFLANKS_FLAGS = {  # reference main.py:102-107
     "large_insertion_cutoff": ("-lins", 30), "output_file": ("-o", "mustache.pairflanks.tsv")}
 
 
-@pytest.mark.parametrize("cmd,flags", [(findflanks, FINDFLANKS_FLAGS), (pairflanks, PAIRFLANKS_FLAGS)])
+RECALL_FLAGS = {  # reference main.py:272-279
+    "min_alignment_quality": ("-minq", 20), "min_alignment_inner_length": ("-minial", 21),
+    "large_insertion_cutoff": ("-lins", 30), "output_file": ("-o", "mustache.recall.tsv")}
+
+
+@pytest.mark.parametrize("cmd,flags", [(findflanks, FINDFLANKS_FLAGS), (pairflanks, PAIRFLANKS_FLAGS), (recall, RECALL_FLAGS)])
 def test_flags_and_defaults(cmd, flags):
     opts = {p.name: p for p in cmd.params if hasattr(p, "opts") and p.opts and p.opts[0].startswith("--")}
     for name, (short, default) in flags.items():
@@ -31,7 +36,7 @@ def test_flags_and_defaults(cmd, flags):
 
 def test_help_runs():
     r = CliRunner().invoke(cli, ["--help"])
-    assert r.exit_code == 0 and "findflanks" in r.output and "pairflanks" in r.output
+    assert r.exit_code == 0 and "findflanks" in r.output and "pairflanks" in r.output and "recall" in r.output
 
 
 @pytest.mark.gpu
@@ -56,3 +61,9 @@ def test_cli_end_to_end_from_bam(tmp_path, name):
     r = CliRunner().invoke(cli, args, catch_exceptions=False)
     assert r.exit_code == 0, r.output
     assert open(pf).read() == case["pairflanks_tsv"]
+    # recall on the pairs just written (reference main.py:272-284, recall.py)
+    rc = os.path.join(tmp_path, "s.recall.tsv")
+    r = CliRunner().invoke(cli, ["recall", pf, bam, "-o", rc], catch_exceptions=False)
+    assert r.exit_code == 0, r.output
+    own = [e for e in util.load_json("recall_vectors")[name] if e["label"] == "own_pairs"][0]
+    assert open(rc).read() == own["recall_tsv"]

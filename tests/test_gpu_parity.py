@@ -103,3 +103,31 @@ def test_empty_and_tiny_inputs(hip, oracle):
     packed = pack_reads(rs.contigs, rs, pool="all")
     res = hip.run_findflanks(_device_reads(hip, packed), lib.make_params())
     assert len(res["flanks"]) == 0 and len(res["sites"]) == 0
+
+
+@pytest.mark.parametrize("name", util.CASES)
+def test_recall_golden_bit_exact(hip, name):
+    """mfk_recall through the C-ABI equals what the reference's recall.py wrote."""
+    case = util.load_json(name)
+    rs = util.case_readset(case)
+    packed = pack_reads(rs.contigs, rs, pool="none")
+    rsd = _device_reads(hip, packed)
+    for e in util.load_json("recall_vectors")[name]:
+        assert util.recall_text(hip, rsd, packed, e) == e["recall_tsv"], e["label"]
+
+
+@pytest.mark.parametrize("seed", (41, 42, 43))
+def test_recall_random_sites_match_oracle(hip, oracle, seed):
+    rng = np.random.default_rng(seed)
+    genome, rs, _ = simulate_readset(seed=seed, contig_lens=(6000, 3000), n_insertions=3, coverage=int(rng.integers(20, 200)),
+                                     read_len=100, sub_rate=0.01, wildtype_frac=0.2)
+    packed = pack_reads(rs.contigs, rs, pool="none")
+    cid = rng.integers(0, 2, 400).astype(np.int32)
+    pos = np.array([int(rng.integers(-1, packed.contig_len[c] + 1)) for c in cid], dtype=np.int32)
+    params = lib.make_params(min_alignment_quality=int(rng.choice([0, 20, 40])), large_insertion_cutoff=int(rng.choice([3, 30])))
+    got = hip.run_recall(_device_reads(hip, packed), params, cid, pos)
+    want = oracle.run_recall(oracle.reads(packed), params, cid, pos)
+    assert np.array_equal(got, want)
+    assert want.sum() > 0
+    with pytest.raises(lib.MfkError):
+        hip.run_recall(_device_reads(hip, packed), params, [0], [int(packed.contig_len[0]) + 1])

@@ -47,3 +47,17 @@ def test_levenshtein_matches_textbook(oracle):
         a = bytes(rng.integers(65, 69, rng.integers(0, 40)).astype(np.uint8))
         b = bytes(rng.integers(65, 69, rng.integers(0, 40)).astype(np.uint8))
         assert oracle.levenshtein(a, b) == _levenshtein(a, b)
+
+
+@pytest.mark.parametrize("name", util.CASES)
+def test_oracle_reproduces_reference_recall(oracle, name):
+    """recall: the oracle's tallies at given sites equal the TSV the reference's recall.py wrote
+    (tests/golden/make_golden_recall.py), including contig ends, empty positions and stricter read filters."""
+    case = util.load_json(name)
+    rs = util.case_readset(case)
+    packed = pack_reads(rs.contigs, rs, pool="none")
+    R = oracle.reads(packed)
+    entries = util.load_json("recall_vectors")[name]
+    assert entries
+    for e in entries:
+        assert util.recall_text(oracle, R, packed, e) == e["recall_tsv"], e["label"]

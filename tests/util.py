@@ -53,3 +53,12 @@ def assert_same_sites(a, b):
     assert a.shape == b.shape, (a.shape, b.shape)
     for name in a.dtype.names:
         assert np.array_equal(a[name], b[name]), (name, a[name][:20], b[name][:20])
+
+
+def recall_text(binding, reads_struct, packed, entry):
+    """TSV text of ``mustache recall`` through ``binding`` for one entry of recall_vectors.json.gz."""
+    from mustache_amd.recall import recall_packed
+    pairs = pd.read_csv(io.StringIO(entry["pairs_tsv"]), sep="\t")
+    params = lib.make_params(**entry["params"])
+    df = recall_packed(binding, reads_struct, packed.contig_names, params, pairs, None, verbose=False)
+    return df.to_csv(sep="\t", index=False)
