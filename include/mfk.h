@@ -182,6 +182,13 @@ int mfk_ir_detect(mfk_ctx *ctx, const char *seqs, const int64_t *off, int64_t n,
 int mfk_recall(mfk_ctx *ctx, const mfk_reads *reads, const mfk_params *params, const int32_t *h_contig_id, const int32_t *h_pos,
                int64_t n_sites, int32_t *h_counts_out);
 
+/* inferseq-overlap: best ungapped sliding overlap of the end of the 5p flank with the start of the 3p flank (replaces
+ * get_best_sliding_alignment, inferseqoverlap.py:94-164, called from find_overlap 73-91).  seqs5 / seqs3: HOST
+ * concatenated sequences with n+1 offsets each (bytes are compared as they are).  out: n x 6 int32 = best_score,
+ * best_score_mismatches, best_r_start, best_r_end, best_q_start, best_q_end (q = 5p flank, r = 3p flank; half-open).
+ * An empty sequence is the reference's IndexError: return code 7. */
+int mfk_overlap(mfk_ctx *ctx, const char *seqs5, const int64_t *off5, const char *seqs3, const int64_t *off3, int64_t n, int32_t *out);
+
 /* time spent in device work of the last compute call, milliseconds (HIP events on the ctx stream) */
 double mfk_last_device_ms(mfk_ctx *ctx);
 

@@ -114,6 +114,7 @@ class Binding:
         f("pairflanks_fetch", C.c_int, [_p, _p, _p, _p])
         f("ir_detect", C.c_int, [_p, _p, _p, C.c_int64, _p])
         f("recall", C.c_int, [_p, C.POINTER(MfkReads), C.POINTER(MfkParams), _p, _p, C.c_int64, _p])
+        f("overlap", C.c_int, [_p, _p, _p, _p, _p, C.c_int64, _p])
         if hasattr(self.so, prefix + "profile_enable"):
             f("profile_enable", C.c_int, [_p, C.c_int])
             f("profile_fetch", C.c_int, [_p, _p, C.c_int64, _p, _p, C.c_int64, C.POINTER(C.c_int64)])
@@ -209,6 +210,22 @@ class Binding:
         out = np.zeros((cid.shape[0], 10), dtype=np.int32)
         self._check(self.recall(self.ctx, C.byref(reads), C.byref(params), cid.ctypes.data, pos.ctypes.data, cid.shape[0],
                                 out.ctypes.data))
+        return out
+
+    def run_overlap(self, seqs5, seqs3):
+        """Best sliding overlap per pair of strings -> int32 array [n, 6]: best_score, best_score_mismatches, r_start,
+        r_end, q_start, q_end (q = seqs5[i], r = seqs3[i])."""
+        assert len(seqs5) == len(seqs3)
+        def blob(seqs):
+            b = [s.encode() for s in seqs]
+            off = np.zeros(len(b) + 1, dtype=np.int64)
+            off[1:] = np.cumsum([len(x) for x in b])
+            return np.frombuffer(b"".join(b) + b"\0", dtype=np.uint8), off
+        b5, o5 = blob(seqs5)
+        b3, o3 = blob(seqs3)
+        out = np.zeros((len(seqs5), 6), dtype=np.int32)
+        self._check(self.overlap(self.ctx, b5.ctypes.data, o5.ctypes.data, b3.ctypes.data, o3.ctypes.data, len(seqs5),
+                                 out.ctypes.data))
         return out
 
     def profile(self, on=True):

@@ -97,5 +97,21 @@ def recall(pairsfile, bamfile, min_alignment_quality, min_alignment_inner_length
             device=device)
 
 
+@cli.command(name="inferseq-overlap", short_help="Infers the identity of an inserted sequence by checking if the two flanks overlap with one another.")
+@click.argument("pairsfile", type=click.Path(exists=True))
+@click.option("--min_overlap_score", "-minscore", default=10)
+@click.option("--min_overlap_perc_identity", "-minopi", default=0.9)
+@click.option("--min_inferseq_size", "-minsize", default=30)
+@click.option("--output_file", "-o", default="mustache.inferseq_overlap.tsv")
+@click.option("--device", default="cuda:0", help="GPU to run on (not in the reference).")
+def inferseq_overlap(pairsfile, min_overlap_score, min_overlap_perc_identity, min_inferseq_size, output_file, device):
+    """reference main.py:167-182"""
+    from .inferseqoverlap import _inferseq_overlap
+    log_params(command="inferseq_overlap", pairsfile=pairsfile, min_overlap_score=min_overlap_score,
+               min_overlap_perc_identity=min_overlap_perc_identity, min_inferseq_size=min_inferseq_size,
+               output_file=output_file)
+    _inferseq_overlap(pairsfile, min_overlap_score, min_overlap_perc_identity, min_inferseq_size, output_file, device=device)
+
+
 if __name__ == "__main__":
     cli()

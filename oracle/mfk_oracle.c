@@ -900,3 +900,35 @@ int mfko_recall(void *c, const mfk_reads *R, const mfk_params *P, const int32_t 
     for (int64_t i = 0; i < n_sites; i++) tally_site(C, R, P, contig_id[i], pos[i], counts + 10 * i);
     return 0;
 }
+
+/* ---- inferseq-overlap: get_best_sliding_alignment inferseqoverlap.py:94-164, the window state machine as written ---- */
+int mfko_overlap(void *c, const char *seqs5, const int64_t *off5, const char *seqs3, const int64_t *off3, int64_t n, int32_t *out) {
+    octx *C = (octx *)c;
+    if (!C || n < 0) return 1;
+    C->err[0] = 0;
+    for (int64_t k = 0; k < n; k++) {
+        const char *query = seqs5 + off5[k], *ref = seqs3 + off3[k];
+        int64_t lq = off5[k + 1] - off5[k], lr = off3[k + 1] - off3[k];
+        if (lq <= 0 || lr <= 0) { snprintf(C->err, sizeof C->err, "IndexError: pair %lld has an empty flank sequence (inferseqoverlap.py:126)", (long long)k); return 7; }
+        int64_t max_len = lq < lr ? lq : lr;
+        int max_len_query = max_len == lq, max_len_ref = !max_len_query;
+        int64_t best_score = INT64_MIN, best_mm = 0, best_rs = 0, best_re = 0, best_qs = 0, best_qe = 0;
+        int64_t q_start = lq - 1, q_end = lq, r_start = 0, r_end = 1;
+        int reached_max = 0;
+        while (q_start != q_end) {
+            int64_t score = 0, mismatches = 0;
+            for (int64_t i = 0; i < q_end - q_start; i++) {
+                if (query[q_start + i] == ref[r_start + i]) score += 1;
+                else { score -= 1; mismatches += 1; }
+            }
+            if (score > best_score) { best_score = score; best_mm = mismatches; best_rs = r_start; best_re = r_end; best_qs = q_start; best_qe = q_end; }
+            if (q_end - q_start == max_len) reached_max = 1;
+            if (!reached_max) { q_start -= 1; r_end += 1; }
+            else if (max_len_query) { if (r_end == lr) { r_start += 1; q_end -= 1; } else { r_start += 1; r_end += 1; } }
+            else if (max_len_ref) { if (q_start == 0) { r_start += 1; q_end -= 1; } else { q_start -= 1; q_end -= 1; } }
+        }
+        int32_t *o = out + 6 * k;
+        o[0] = (int32_t)best_score; o[1] = (int32_t)best_mm; o[2] = (int32_t)best_rs; o[3] = (int32_t)best_re; o[4] = (int32_t)best_qs; o[5] = (int32_t)best_qe;
+    }
+    return 0;
+}

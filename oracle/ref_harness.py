@@ -82,6 +82,11 @@ def install_stubs():
             setattr(mod, k, v)
         sys.modules["Bio." + sub] = mod
         setattr(bio, sub, mod)
+    pw = types.ModuleType("Bio.pairwise2")            # imported by inferseqoverlap.py:9-10, used only in its verbose branch
+    pw.format_alignment = lambda *a, **k: ""
+    pw.align = types.SimpleNamespace(localms=lambda *a, **k: [])
+    sys.modules["Bio.pairwise2"] = pw
+    bio.pairwise2 = pw
     sys.modules["Bio"] = bio
     sys.modules["Bio.SeqIO"] = seqio
     if REF_ROOT not in sys.path:
@@ -187,6 +192,25 @@ def run_recall(pairs_tsv_path, readset, output_file, min_alignment_quality=20, m
     finally:
         del _registry["bam"][key]
     return df, open(output_file).read()
+
+
+def run_inferseq_overlap(pairs_tsv_path, output_file, min_overlap_score=10, min_overlap_perc_identity=0.9,
+                         min_inferseq_size=30):
+    """Run the reference's _inferseq_overlap (inferseqoverlap.py:21-42).  Returns the TSV text it wrote."""
+    install_stubs()
+    from mustache.inferseqoverlap import _inferseq_overlap
+    del _log[:]
+    try:
+        _inferseq_overlap(pairs_tsv_path, min_overlap_score, min_overlap_perc_identity, min_inferseq_size, output_file)
+    except SystemExit:      # handle_empty_pairsfile writes the header-only table and exits
+        pass
+    return open(output_file).read()
+
+
+def reference_overlap_functions():
+    install_stubs()
+    from mustache import inferseqoverlap as m
+    return m.get_best_sliding_alignment, m.find_overlap
 
 
 def reference_modules():

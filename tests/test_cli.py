@@ -5,7 +5,7 @@ import pytest
 from click.testing import CliRunner
 
 from mustache_amd import bamio
-from mustache_amd.main import cli, findflanks, pairflanks, recall
+from mustache_amd.main import cli, findflanks, inferseq_overlap, pairflanks, recall
 from tests import util
 
 FINDFLANKS_FLAGS = {  # long, short, default   (reference main.py:68-78)
@@ -25,7 +25,13 @@ RECALL_FLAGS = {  # reference main.py:272-279
     "large_insertion_cutoff": ("-lins", 30), "output_file": ("-o", "mustache.recall.tsv")}
 
 
-@pytest.mark.parametrize("cmd,flags", [(findflanks, FINDFLANKS_FLAGS), (pairflanks, PAIRFLANKS_FLAGS), (recall, RECALL_FLAGS)])
+OVERLAP_FLAGS = {  # reference main.py:169-173
+    "min_overlap_score": ("-minscore", 10), "min_overlap_perc_identity": ("-minopi", 0.9),
+    "min_inferseq_size": ("-minsize", 30), "output_file": ("-o", "mustache.inferseq_overlap.tsv")}
+
+
+@pytest.mark.parametrize("cmd,flags", [(findflanks, FINDFLANKS_FLAGS), (pairflanks, PAIRFLANKS_FLAGS), (recall, RECALL_FLAGS),
+                                       (inferseq_overlap, OVERLAP_FLAGS)])
 def test_flags_and_defaults(cmd, flags):
     opts = {p.name: p for p in cmd.params if hasattr(p, "opts") and p.opts and p.opts[0].startswith("--")}
     for name, (short, default) in flags.items():
@@ -67,3 +73,9 @@ def test_cli_end_to_end_from_bam(tmp_path, name):
     assert r.exit_code == 0, r.output
     own = [e for e in util.load_json("recall_vectors")[name] if e["label"] == "own_pairs"][0]
     assert open(rc).read() == own["recall_tsv"]
+    # inferseq-overlap on the same pairs (reference main.py:167-182, inferseqoverlap.py)
+    ov = os.path.join(tmp_path, "s.inferseq_overlap.tsv")
+    r = CliRunner().invoke(cli, ["inferseq-overlap", pf, "-o", ov], catch_exceptions=False)
+    assert r.exit_code == 0, r.output
+    own = [e for e in util.load_json("overlap_vectors")["tables"] if e["label"] == name + "_own_pairs"][0]
+    assert open(ov).read() == own["overlap_tsv"]

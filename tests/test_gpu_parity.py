@@ -131,3 +131,22 @@ def test_recall_random_sites_match_oracle(hip, oracle, seed):
     assert want.sum() > 0
     with pytest.raises(lib.MfkError):
         hip.run_recall(_device_reads(hip, packed), params, [0], [int(packed.contig_len[0]) + 1])
+
+
+def test_overlap_golden_bit_exact(hip, oracle):
+    """mfk_overlap through the C-ABI: the reference's tuples on 160 string pairs and its TSVs on nine pairs tables."""
+    vec = util.load_json("overlap_vectors")
+    got = hip.run_overlap([v[0] for v in vec["sliding"]], [v[1] for v in vec["sliding"]])
+    assert [[int(x) for x in row] for row in got] == [v[2] for v in vec["sliding"]]
+    for e in vec["tables"]:
+        assert util.overlap_text(hip, e) == e["overlap_tsv"], e["label"]
+    # long sequences (past the LDS staging limit) and many pairs, against the oracle
+    rng = np.random.default_rng(7)
+    def rs(n, a="ACGT"):
+        return "".join(a[i] for i in rng.integers(0, len(a), n))
+    s5 = [rs(int(rng.integers(1, 400))) for _ in range(500)] + [rs(30000), rs(20000, "AC"), rs(5)]
+    s3 = [rs(int(rng.integers(1, 400))) for _ in range(500)] + [rs(10000), rs(21000, "AC"), rs(40000)]
+    s3[0] = s5[0][-20:] + s3[0]
+    assert np.array_equal(hip.run_overlap(s5, s3), oracle.run_overlap(s5, s3))
+    with pytest.raises(lib.MfkError):
+        hip.run_overlap(["ACGT"], [""])

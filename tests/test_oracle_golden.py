@@ -61,3 +61,17 @@ def test_oracle_reproduces_reference_recall(oracle, name):
     assert entries
     for e in entries:
         assert util.recall_text(oracle, R, packed, e) == e["recall_tsv"], e["label"]
+
+
+def test_oracle_reproduces_reference_overlap(oracle):
+    """inferseq-overlap: the oracle's window walk equals get_best_sliding_alignment of the reference on
+    160 string pairs, and the host mirror on top of it reproduces the reference's TSVs (tests/golden/make_golden_overlap.py)."""
+    vec = util.load_json("overlap_vectors")
+    got = oracle.run_overlap([v[0] for v in vec["sliding"]], [v[1] for v in vec["sliding"]])
+    for row, v in zip(got, vec["sliding"]):
+        assert [int(x) for x in row] == v[2], v[:2]
+    for e in vec["tables"]:
+        assert util.overlap_text(oracle, e) == e["overlap_tsv"], e["label"]
+    assert sum(len(e["overlap_tsv"].splitlines()) > 1 for e in vec["tables"]) >= 5
+    with pytest.raises(Exception):
+        oracle.run_overlap(["ACGT"], [""])

@@ -62,3 +62,14 @@ def recall_text(binding, reads_struct, packed, entry):
     params = lib.make_params(**entry["params"])
     df = recall_packed(binding, reads_struct, packed.contig_names, params, pairs, None, verbose=False)
     return df.to_csv(sep="\t", index=False)
+
+
+def overlap_text(binding, entry):
+    """TSV text of ``mustache inferseq-overlap`` through ``binding`` for one table of overlap_vectors.json.gz."""
+    from mustache_amd import inferseqoverlap as iso
+    pairs = pd.read_csv(io.StringIO(entry["pairs_tsv"]), sep="\t", keep_default_na=False, na_values=iso._NA_VALUES)
+    if pairs.shape[0] == 0:
+        return pd.DataFrame(columns=iso.OVERLAP_COLUMNS).to_csv(sep="\t", index=False)
+    p = dict(min_overlap_score=10, min_overlap_perc_identity=0.9, min_inferseq_size=30)
+    p.update(entry["params"])
+    return iso.inferseq_overlap_frame(binding, pairs, **p).to_csv(sep="\t", index=False)
