@@ -168,6 +168,13 @@ int mfk_pairflanks_fetch(mfk_ctx *ctx, mfk_pair *pairs, char *strs, int64_t *sta
 /* pairflanks stats[0]: candidate pairs (pair_all_nearby_flanks), [1]: assigned, [2]: with IR, [3]: spanning_count>0,
  * [4]: after filter_junction_spanning. */
 
+/* Inverted-repeat results from an external detector for the NEXT mfk_pairflanks call on this ctx -- the escape hatch
+ * for sites that have EMBOSS einverted, which is what the reference runs (embosstools.py:8-26, pairflanks.py:172-219).
+ * One row per candidate pair (pair_all_nearby_flanks, pairflanks.py:138-169): flank row indices and ir = has_ir,
+ * arm1_start, arm1_end, arm2_start, arm2_end (1-based inclusive, after the acceptance loop of pairflanks.py:196-205;
+ * arm1 = IR_3p, arm2 = IR_5p).  A candidate without a row makes mfk_pairflanks fail with code 8.  n = 0 clears. */
+int mfk_pairflanks_set_ir(mfk_ctx *ctx, int64_t n, const int32_t *index_5p, const int32_t *index_3p, const int32_t *ir);
+
 /* inverted-repeat detection on its own (replaces one einverted run, embosstools.py:8-26 + pairflanks.py:183-213).
  * seqs: HOST concatenated upper-case sequences, off: n+1 offsets.  out: n x 6 int32:
  * has_ir, arm1_start, arm1_end, arm2_start, arm2_end (1-based inclusive, einverted convention), n_reported. */

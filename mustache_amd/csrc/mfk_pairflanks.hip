@@ -17,6 +17,8 @@
 //                              50-bp window in LDS
 #include "mfk_host.h"
 
+#include <algorithm>
+
 #define IR_MAXLEN 100      // 40 + 20 + 40 (truncated_flank_length, pairflanks.py:78, 183-186)
 #define IR_MAXREP 8
 
@@ -213,6 +215,20 @@ __global__ __launch_bounds__(64) void k_inverted_repeat(FlankDev F, const uint32
     __syncthreads();
     d_ir_detect(code, L, S, mask, rep, out + 6 * (size_t)k);
     if (threadIdx.x == 0) { keys[k] = d_assign_key(F, a, b, out + 6 * (size_t)k); vals[k] = k; }
+}
+
+// external inverted-repeat table (mfk_pairflanks_set_ir, e.g. from EMBOSS einverted): rows i5 i3 has a1s a1e a2s a2e
+// sorted by (i5, i3); a candidate without a row raises the error word
+__global__ void k_ir_lookup(FlankDev F, const uint32_t *c5, const uint32_t *c3, uint32_t n, const int32_t *tab, uint32_t n_tab, int32_t *out, uint64_t *keys, uint32_t *vals, uint32_t *err) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const int32_t a = (int32_t)c5[k], b = (int32_t)c3[k];
+    uint32_t lo = 0, hi = n_tab;
+    while (lo < hi) { uint32_t m = (lo + hi) >> 1; const int32_t *r = tab + 7 * (size_t)m; if (r[0] < a || (r[0] == a && r[1] < b)) lo = m + 1; else hi = m; }
+    int32_t *o = out + 6 * (size_t)k;
+    if (lo < n_tab && tab[7 * (size_t)lo] == a && tab[7 * (size_t)lo + 1] == b) { for (int z = 0; z < 5; z++) o[z] = tab[7 * (size_t)lo + 2 + z]; o[5] = -1; }
+    else { for (int z = 0; z < 6; z++) o[z] = 0; atomicOr(err, 1u); }
+    keys[k] = d_assign_key(F, (uint32_t)a, (uint32_t)b, o); vals[k] = k;
 }
 
 // ---- assign_pairs ------------------------------------------------------------------------------------------------------
@@ -491,6 +507,8 @@ extern "C" int mfk_ir_detect(mfk_ctx *ctx, const char *seqs, const int64_t *off,
 extern "C" int mfk_pairflanks(mfk_ctx *ctx, const mfk_reads *reads, const mfk_params *params, const mfk_flank *flanks, const char *flank_seqs, int64_t n_flanks,
                               const int32_t *h_contig_rank, const uint8_t *genome, const int64_t *h_genome_off, int64_t *n_pairs_out, int64_t *str_bytes_out) {
     if (!ctx || !reads || !params || n_flanks < 0) return 1;
+    std::vector<int32_t> ir_tab;
+    ir_tab.swap(ctx->ir_ov);                              // the external table (if any) serves exactly this call
     HIPCHK(hipSetDevice(ctx->device));
     ctx->err[0] = 0;
     ctx->pairs.clear(); ctx->strs.clear();
@@ -573,8 +591,16 @@ extern "C" int mfk_pairflanks(mfk_ctx *ctx, const mfk_reads *reads, const mfk_pa
         const unsigned pb = nblocks(nP, 256);
         PROF_LAUNCH(k_pair_window<true>, dim3(fb), dim3(256), 0, st, F, P.maxdr, sorted, (uint32_t *)nullptr, (const uint32_t *)coff, c5, c3);
         KCHK();
-        PROF_LAUNCH(k_inverted_repeat, dim3(nP), dim3(64), 0, st, F, (const uint32_t *)c5, (const uint32_t *)c3, nP, ir, keys, vals);
-        KCHK();
+        if (ir_tab.empty()) {
+            PROF_LAUNCH(k_inverted_repeat, dim3(nP), dim3(64), 0, st, F, (const uint32_t *)c5, (const uint32_t *)c3, nP, ir, keys, vals);
+            KCHK();
+        } else {
+            int32_t *d_tab_ir = aalloc<int32_t>(ctx, ir_tab.size());
+            if (!d_tab_ir) return 1;
+            HIPCHK(hipMemcpyAsync(d_tab_ir, ir_tab.data(), ir_tab.size() * 4, hipMemcpyHostToDevice, st));   // ir_tab lives until the call returns
+            PROF_LAUNCH(k_ir_lookup, dim3(pb), dim3(256), 0, st, F, (const uint32_t *)c5, (const uint32_t *)c3, nP, (const int32_t *)d_tab_ir, (uint32_t)(ir_tab.size() / 7), ir, keys, vals, d_pstats + 15);
+            KCHK();
+        }
         if (int rc = dev_sort_pairs64(ctx, keys, keys2, vals, order, nP, 0, 56)) return rc;
         PROF_LAUNCH(k_assign, dim3(1), dim3(1024), 0, st, (const uint32_t *)order, (const uint32_t *)c5, (const uint32_t *)c3, nP, nF, best5, best3, used5, used3, state, kflag);
         KCHK();
@@ -602,6 +628,8 @@ extern "C" int mfk_pairflanks(mfk_ctx *ctx, const mfk_reads *reads, const mfk_pa
     } else
         HIPCHK(hipEventRecord(ctx->ev1, st));
     ctx->pstats[1] = nK;
+    const bool had_table = !ir_tab.empty();
+    if (had_table && h_ps[15]) { snprintf(ctx->err, sizeof ctx->err, "a candidate pair has no entry in the inverted-repeat table given to mfk_pairflanks_set_ir"); return 8; }
     ctx->pstats[2] = h_ps[2]; ctx->pstats[3] = h_ps[3]; ctx->pstats[4] = nFin;
     prof_collect(ctx);
     float ms = 0.f;
@@ -643,5 +671,21 @@ extern "C" int mfk_pairflanks_fetch(mfk_ctx *ctx, mfk_pair *pairs, char *strs, i
     if (pairs && !ctx->pairs.empty()) memcpy(pairs, ctx->pairs.data(), ctx->pairs.size() * sizeof(mfk_pair));
     if (strs && !ctx->strs.empty()) memcpy(strs, ctx->strs.data(), ctx->strs.size());
     if (stats) memcpy(stats, ctx->pstats, sizeof ctx->pstats);
+    return 0;
+}
+
+// External inverted-repeat results for the NEXT mfk_pairflanks call on this ctx (e.g. parsed from EMBOSS einverted, which
+// is what the reference runs: embosstools.py:8-26, pairflanks.py:172-219).  One row per candidate pair.
+extern "C" int mfk_pairflanks_set_ir(mfk_ctx *ctx, int64_t n, const int32_t *index_5p, const int32_t *index_3p, const int32_t *ir) {
+    if (!ctx || n < 0 || (n > 0 && (!index_5p || !index_3p || !ir))) return 1;
+    ctx->ir_ov.clear();
+    std::vector<int64_t> order((size_t)n);
+    for (int64_t k = 0; k < n; k++) order[(size_t)k] = k;
+    std::sort(order.begin(), order.end(), [&](int64_t x, int64_t y) { return index_5p[x] != index_5p[y] ? index_5p[x] < index_5p[y] : index_3p[x] < index_3p[y]; });
+    ctx->ir_ov.reserve((size_t)n * 7);
+    for (int64_t q : order) {
+        ctx->ir_ov.push_back(index_5p[q]); ctx->ir_ov.push_back(index_3p[q]);
+        for (int z = 0; z < 5; z++) ctx->ir_ov.push_back(ir[5 * q + z]);
+    }
     return 0;
 }

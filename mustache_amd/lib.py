@@ -115,6 +115,7 @@ class Binding:
         f("ir_detect", C.c_int, [_p, _p, _p, C.c_int64, _p])
         f("recall", C.c_int, [_p, C.POINTER(MfkReads), C.POINTER(MfkParams), _p, _p, C.c_int64, _p])
         f("overlap", C.c_int, [_p, _p, _p, _p, _p, C.c_int64, _p])
+        f("pairflanks_set_ir", C.c_int, [_p, C.c_int64, _p, _p, _p])
         if hasattr(self.so, prefix + "profile_enable"):
             f("profile_enable", C.c_int, [_p, C.c_int])
             f("profile_fetch", C.c_int, [_p, _p, C.c_int64, _p, _p, C.c_int64, C.POINTER(C.c_int64)])
@@ -192,6 +193,14 @@ class Binding:
         stats = np.zeros(N_STATS, dtype=np.int64)
         self._check(self.pairflanks_fetch(self.ctx, pairs.ctypes.data, strs.ctypes.data, stats.ctypes.data))
         return {"pairs": pairs, "strs": strs[:sb.value].tobytes(), "stats": stats}
+
+    def set_pair_ir(self, index_5p, index_3p, ir):
+        """Inverted-repeat results of an external detector for the next run_pairflanks (ir: [n, 5] has, a1s, a1e, a2s, a2e)."""
+        i5 = np.ascontiguousarray(index_5p, dtype=np.int32)
+        i3 = np.ascontiguousarray(index_3p, dtype=np.int32)
+        t = np.ascontiguousarray(ir, dtype=np.int32).reshape(-1, 5)
+        assert i5.shape[0] == i3.shape[0] == t.shape[0]
+        self._check(self.pairflanks_set_ir(self.ctx, i5.shape[0], i5.ctypes.data, i3.ctypes.data, t.ctypes.data))
 
     def run_ir_detect(self, seqs):
         """seqs: list of str -> int32 array [n, 6]: has_ir, arm1 start/end, arm2 start/end (1-based), n_reported."""

@@ -66,8 +66,12 @@ def findflanks(bamfile, min_softclip_length, min_softclip_count, min_alignment_q
 @click.option("--large_insertion_cutoff", "-lins", default=30)
 @click.option("--output_file", "-o", default="mustache.pairflanks.tsv")
 @click.option("--device", default="cuda:0", help="GPU to run on (not in the reference).")
+@click.option("--ir-backend", "ir_backend", type=click.Choice(["builtin", "einverted"]), default="builtin",
+              help="Inverted-repeat detector: the library's own (default) or EMBOSS einverted as the reference runs it "
+                   "(needs the executable on PATH; not in the reference).")
 def pairflanks(flanksfile, bamfile, genome, max_direct_repeat_length, min_alignment_quality,
-               min_alignment_inner_length, max_junction_spanning_prop, large_insertion_cutoff, output_file, device):
+               min_alignment_inner_length, max_junction_spanning_prop, large_insertion_cutoff, output_file, device,
+               ir_backend):
     from .pairflanks import _pairflanks
     log_params(command="pairflanks", flanksfile=flanksfile, bamfile=bamfile, genome=genome,
                max_direct_repeat_length=max_direct_repeat_length, min_alignment_quality=min_alignment_quality,
@@ -76,7 +80,7 @@ def pairflanks(flanksfile, bamfile, genome, max_direct_repeat_length, min_alignm
                output_file=output_file)
     _pairflanks(flanksfile, bamfile, genome, max_direct_repeat_length, min_alignment_quality,
                 min_alignment_inner_length, max_junction_spanning_prop, large_insertion_cutoff, output_file,
-                device=device)
+                device=device, ir_backend=ir_backend)
 
 
 @cli.command(short_help="Recall softclip counts and runthrough counts from BAM file at specified pairflank insertions.")

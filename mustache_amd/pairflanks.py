@@ -110,8 +110,10 @@ def contig_ranks(contig_names):
 
 
 def pairflanks_packed(binding, reads_struct, contig_names, params, flanks: pd.DataFrame, genome_dev, genome_off,
-                      output_file=None, verbose=True):
-    """``_pairflanks`` after the inputs are on the device.  ``flanks`` is the frame read from the findflanks TSV."""
+                      output_file=None, verbose=True, ir_backend="builtin", ir_detector=None):
+    """``_pairflanks`` after the inputs are on the device.  ``flanks`` is the frame read from the findflanks TSV.
+    ``ir_backend``: "builtin" = the library's own inverted-repeat detector, "einverted" = run EMBOSS
+    einverted per candidate pair like the reference does and pass its repeats to the library."""
     if flanks.shape[0] == 0:                                                   # pairflanks.py:32-40 (quirk P12)
         if verbose:
             log("No flanks found in the input file...")
@@ -121,6 +123,11 @@ def pairflanks_packed(binding, reads_struct, contig_names, params, flanks: pd.Da
             flank_pairs.to_csv(output_file, sep="\t", index=False)
         return flank_pairs
     tab, seqs = flanks_to_table(flanks, contig_names)
+    if ir_backend == "einverted":
+        from . import einverted
+        binding.set_pair_ir(*einverted.ir_table(tab, seqs, int(params.max_direct_repeat_length), detector=ir_detector))
+    elif ir_backend != "builtin":
+        raise ValueError("ir_backend must be 'builtin' or 'einverted', not %r" % (ir_backend,))
     res = binding.run_pairflanks(reads_struct, params, tab, seqs, contig_ranks(contig_names), genome_dev, genome_off)
     if verbose:
         st = res["stats"]
@@ -141,8 +148,11 @@ def pairflanks_packed(binding, reads_struct, contig_names, params, flanks: pd.Da
 
 def _pairflanks(flanksfile, bamfile, genome, max_direct_repeat_length, min_alignment_quality,
                 min_alignment_inner_length, max_junction_spanning_prop=0.15, large_insertion_cutoff=30,
-                output_file=None, device="cuda:0", verbose=True):
+                output_file=None, device="cuda:0", verbose=True, ir_backend="builtin"):
     """Drop-in for reference pairflanks.py:18-51 (same positional arguments)."""
+    if ir_backend == "einverted":
+        from . import einverted
+        einverted.find_einverted()          # fail before any work when the executable is missing
     import torch
     from .bamio import BamReader, read_fasta
     binding = _lib.load(int(str(device).split(":")[1]) if ":" in str(device) else 0)
@@ -156,7 +166,7 @@ def _pairflanks(flanksfile, bamfile, genome, max_direct_repeat_length, min_align
     with BamReader(bamfile) as bam:
         contig_names = [n for n, _ in bam.contigs]
         if flanks.shape[0] == 0:
-            return pairflanks_packed(binding, None, contig_names, params, flanks, None, None, output_file, verbose)
+            return pairflanks_packed(binding, None, contig_names, params, flanks, None, None, output_file, verbose, ir_backend)
         tab, _ = flanks_to_table(flanks, contig_names)
         g, goff = genome_arrays(gen, contig_names)
         glen = np.diff(goff)
@@ -182,4 +192,4 @@ def _pairflanks(flanksfile, bamfile, genome, max_direct_repeat_length, min_align
         packed = pack_reads(bam.contigs, reads, pool=in_window)
     rs = device_reads(binding, packed, device)
     gdev = torch.from_numpy(g).to(device)
-    return pairflanks_packed(binding, rs, contig_names, params, flanks, gdev, goff, output_file, verbose)
+    return pairflanks_packed(binding, rs, contig_names, params, flanks, gdev, goff, output_file, verbose, ir_backend)

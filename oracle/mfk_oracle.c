@@ -146,6 +146,7 @@ typedef struct {
     mfk_flank *flanks; int64_t n_flanks; char *seqs; int64_t seq_bytes;
     mfk_pair *pairs; int64_t n_pairs; char *strs; int64_t str_bytes;
     int64_t pstats[MFK_N_STATS];
+    int32_t *ir_ov; int64_t n_ir_ov;   /* external inverted-repeat table for the next pairflanks call: i5 i3 has a1s a1e a2s a2e */
     char err[512];
 } octx;
 
@@ -741,7 +742,14 @@ int mfko_pairflanks(void *c, const mfk_reads *R, const mfk_params *P, const mfk_
         memcpy(comb, fseq + f5->seq_off, n5); L = n5;
         memset(comb + L, 'N', 20); L += 20;
         memcpy(comb + L, fseq + f3->seq_off + (f3->seq_len - n3), n3); L += n3;
-        int32_t res[6]; ir_accept(comb, L, res);
+        int32_t res[6];
+        if (C->n_ir_ov) {   /* table from an external detector (mfk_pairflanks_set_ir) */
+            int64_t q = 0;
+            for (; q < C->n_ir_ov; q++) if (C->ir_ov[7 * q] == cand[k].i5 && C->ir_ov[7 * q + 1] == cand[k].i3) break;
+            if (q == C->n_ir_ov) { snprintf(C->err, sizeof C->err, "candidate pair (%d, %d) has no entry in the inverted-repeat table", cand[k].i5, cand[k].i3); free(cand); free(C->ir_ov); C->ir_ov = NULL; C->n_ir_ov = 0; return 8; }
+            for (int z = 0; z < 5; z++) res[z] = C->ir_ov[7 * q + 2 + z];
+            res[5] = -1;
+        } else ir_accept(comb, L, res);
         cand[k].has_ir = res[0];
         /* IR_3p = ir1.seq, IR_5p = ir2.seq (pairflanks.py:212-213); IR_length = len(IR_5p) (225) */
         cand[k].ir[0] = res[1]; cand[k].ir[1] = res[2]; cand[k].ir[2] = res[3]; cand[k].ir[3] = res[4];
@@ -865,6 +873,7 @@ int mfko_pairflanks(void *c, const mfk_reads *R, const mfk_params *P, const mfk_
         free(cols);
     }
     free(kept); free(spanning);
+    free(C->ir_ov); C->ir_ov = NULL; C->n_ir_ov = 0;   /* the table serves one call */
     C->n_pairs = nfin; C->str_bytes = so;
     if (n_pairs) *n_pairs = nfin;
     if (str_bytes) *str_bytes = so;
@@ -930,5 +939,17 @@ int mfko_overlap(void *c, const char *seqs5, const int64_t *off5, const char *se
         int32_t *o = out + 6 * k;
         o[0] = (int32_t)best_score; o[1] = (int32_t)best_mm; o[2] = (int32_t)best_rs; o[3] = (int32_t)best_re; o[4] = (int32_t)best_qs; o[5] = (int32_t)best_qe;
     }
+    return 0;
+}
+
+/* external inverted-repeat results for the next mfko_pairflanks call (see mfk_pairflanks_set_ir) */
+int mfko_pairflanks_set_ir(void *c, int64_t n, const int32_t *index_5p, const int32_t *index_3p, const int32_t *ir) {
+    octx *C = (octx *)c;
+    if (!C || n < 0) return 1;
+    free(C->ir_ov); C->ir_ov = NULL; C->n_ir_ov = 0;
+    if (n == 0) return 0;
+    C->ir_ov = (int32_t *)malloc((size_t)n * 7 * sizeof(int32_t));
+    for (int64_t k = 0; k < n; k++) { C->ir_ov[7 * k] = index_5p[k]; C->ir_ov[7 * k + 1] = index_3p[k]; memcpy(C->ir_ov + 7 * k + 2, ir + 5 * k, 5 * sizeof(int32_t)); }
+    C->n_ir_ov = n;
     return 0;
 }
