@@ -116,18 +116,55 @@ def _reg2bin(beg, end):
     return 0
 
 
+def encode_record(r, cid, name=None):
+    """One alignment as BAM bytes (block_size included).  ``cid`` = reference id; ``name`` overrides r.query_name."""
+    name = (r.query_name if name is None else name).encode() + b"\0"
+    cig = r.cigartuples or []
+    seq = r.query_sequence or ""
+    codes = [BASE_TO_CODE.get(c, 15) for c in seq]
+    if len(codes) & 1:
+        codes.append(0)
+    seqb = bytes((codes[i] << 4) | codes[i + 1] for i in range(0, len(codes), 2))
+    q = r.query_qualities
+    qual = bytes(bytearray(int(x) for x in q)) if q is not None else b"\xff" * len(seq)
+    tags = b""
+    for k, v in r.tags.items():
+        if isinstance(v, str):
+            tags += k.encode() + b"Z" + v.encode() + b"\0"
+        else:
+            tags += k.encode() + b"i" + struct.pack("<i", int(v))
+    end = r.reference_end if cig else r.reference_start + 1
+    body = struct.pack("<iiBBHHHiiii", cid, r.reference_start, len(name), r.mapping_quality,
+                       _reg2bin(r.reference_start, end), len(cig), r.flag, len(seq), -1, -1, 0)
+    body += name + b"".join(struct.pack("<I", (l << 4) | op) for op, l in cig) + seqb + qual + tags
+    return struct.pack("<i", len(body)) + body
+
+
+def bgzf_block(data, level=6):
+    """One BGZF block (SAM spec 4.1) holding ``data`` (at most 0xFF00 bytes, so that it always fits)."""
+    co = zlib.compressobj(level, zlib.DEFLATED, -15)
+    comp = co.compress(data) + co.flush()
+    return (struct.pack("<BBBBIBBHBBHH", 0x1F, 0x8B, 8, 4, 0, 0, 0xFF, 6, 66, 67, 2, len(comp) + 25) + comp +
+            struct.pack("<II", zlib.crc32(data) & 0xFFFFFFFF, len(data)))
+
+
+def bam_header_bytes(contigs, text=None):
+    if text is None:
+        text = "@HD\tVN:1.6\tSO:coordinate\n" + "".join("@SQ\tSN:%s\tLN:%d\n" % c for c in contigs)
+    t = text.encode()
+    out = [b"BAM\1" + struct.pack("<i", len(t)) + t + struct.pack("<i", len(contigs))]
+    for n, l in contigs:
+        nb = n.encode() + b"\0"
+        out.append(struct.pack("<i", len(nb)) + nb + struct.pack("<i", l))
+    return b"".join(out)
+
+
 class BamWriter:
     def __init__(self, path, contigs, text=None):
         self.fh = open(path, "wb")
         self.buf = bytearray()
         self.contig_index = {n: i for i, (n, _) in enumerate(contigs)}
-        if text is None:
-            text = "@HD\tVN:1.6\tSO:coordinate\n" + "".join("@SQ\tSN:%s\tLN:%d\n" % c for c in contigs)
-        t = text.encode()
-        self._put(b"BAM\1" + struct.pack("<i", len(t)) + t + struct.pack("<i", len(contigs)))
-        for n, l in contigs:
-            nb = n.encode() + b"\0"
-            self._put(struct.pack("<i", len(nb)) + nb + struct.pack("<i", l))
+        self._put(bam_header_bytes(contigs, text))
 
     def _put(self, data):
         self.buf += data
@@ -136,35 +173,11 @@ class BamWriter:
             del self.buf[:0xFF00]
 
     def _flush_block(self, data):
-        co = zlib.compressobj(6, zlib.DEFLATED, -15)
-        comp = co.compress(data) + co.flush()
-        bsize = len(comp) + 25
-        self.fh.write(struct.pack("<BBBBIBBHBBHH", 0x1F, 0x8B, 8, 4, 0, 0, 0xFF, 6, 66, 67, 2, bsize))
-        self.fh.write(comp)
-        self.fh.write(struct.pack("<II", zlib.crc32(data) & 0xFFFFFFFF, len(data)))
+        self.fh.write(bgzf_block(data))
 
     def write(self, r):
         cid = self.contig_index[r.reference_name] if r.reference_name is not None else -1
-        name = r.query_name.encode() + b"\0"
-        cig = r.cigartuples or []
-        seq = r.query_sequence or ""
-        codes = [BASE_TO_CODE.get(c, 15) for c in seq]
-        if len(codes) & 1:
-            codes.append(0)
-        seqb = bytes((codes[i] << 4) | codes[i + 1] for i in range(0, len(codes), 2))
-        q = r.query_qualities
-        qual = bytes(bytearray(int(x) for x in q)) if q is not None else b"\xff" * len(seq)
-        tags = b""
-        for k, v in r.tags.items():
-            if isinstance(v, str):
-                tags += k.encode() + b"Z" + v.encode() + b"\0"
-            else:
-                tags += k.encode() + b"i" + struct.pack("<i", int(v))
-        end = r.reference_end if cig else r.reference_start + 1
-        body = struct.pack("<iiBBHHHiiii", cid, r.reference_start, len(name), r.mapping_quality,
-                           _reg2bin(r.reference_start, end), len(cig), r.flag, len(seq), -1, -1, 0)
-        body += name + b"".join(struct.pack("<I", (l << 4) | op) for op, l in cig) + seqb + qual + tags
-        self._put(struct.pack("<i", len(body)) + body)
+        self._put(encode_record(r, cid))
 
     def close(self):
         if self.buf:

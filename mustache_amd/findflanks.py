@@ -1,8 +1,8 @@
 """Host side of ``mustache findflanks``: same function name, arguments and TSV as the reference's stage driver
 ``_findflanks`` (reference mustache/findflanks.py:18-59); the per-read and per-site work runs in libmfk.so on the GPU.
 
-Flow: BAM decode on the CPU (``bamio``) -> ``pack_reads`` (SoA, 24 B/read) -> device tensors -> ``mfk_findflanks`` ->
-flank rows -> pandas frame with the reference's columns -> ``to_csv(sep='\\t', index=False)``.
+Flow: BAM decode + packing on the CPU (``pack_bam``: libmfkio.so, multi-threaded BGZF inflate; SoA, 22 B/read) ->
+device tensors -> ``mfk_findflanks`` -> flank rows -> pandas frame with the reference's columns -> ``to_csv(sep='\\t', index=False)``.
 """
 from __future__ import annotations
 
@@ -12,7 +12,7 @@ import numpy as np
 import pandas as pd
 
 from . import lib as _lib
-from .pack import PackedReads, pack_reads
+from .pack import PackedReads, pack_bam, pack_reads
 
 FLANK_COLUMNS = ["contig", "pos", "orient", "softclip_count_5p", "softclip_count_3p", "runthrough_count",
                  "small_insertion_count_5p", "small_insertion_count_3p", "large_insertion_count_5p",
@@ -82,9 +82,9 @@ def findflanks_packed(binding, reads_struct, contig_names, params, sample_id, ou
 
 def _findflanks(bamfile, min_softclip_length, min_softclip_count, min_alignment_quality, min_alignment_inner_length,
                 min_distance_to_mate, min_softclip_ratio, max_indel_ratio, large_insertion_cutoff,
-                min_count_consensus, sample_id, output_file=None, device="cuda:0", verbose=True):
-    """Drop-in for reference findflanks.py:18-59 (same positional arguments)."""
-    from .bamio import BamReader
+                min_count_consensus, sample_id, output_file=None, device="cuda:0", verbose=True, decoder="native"):
+    """Drop-in for reference findflanks.py:18-59 (same positional arguments).  ``decoder``: "native" (libmfkio.so) or
+    "python" (bamio.BamReader + pack_reads, the readable statement of the same packing rules)."""
     binding = _lib.load(int(str(device).split(":")[1]) if ":" in str(device) else 0)
     params = _lib.make_params(min_softclip_length=min_softclip_length, min_softclip_count=min_softclip_count,
                               min_alignment_quality=min_alignment_quality,
@@ -94,9 +94,20 @@ def _findflanks(bamfile, min_softclip_length, min_softclip_count, min_alignment_
                               min_count_consensus=min_count_consensus)
     if verbose:
         log("Parsing softclipped sites from provided BAM file...")
-    with BamReader(bamfile) as bam:
-        packed = pack_reads(bam.contigs, bam, pool="clipped")
+    if decoder == "native":
+        packed = pack_bam(bamfile, pool="clipped")
+    elif decoder == "python":
+        from .bamio import BamReader
+        with BamReader(bamfile) as bam:
+            packed = pack_reads(bam.contigs, bam, pool="clipped")
+    else:
+        raise ValueError("decoder must be 'native' or 'python', not %r" % (decoder,))
     if verbose:
         log("Packed %d mapped reads (%.1f MB of records)" % (packed.n_reads, packed.nbytes_hot() / 1e6))
+        st = getattr(packed, "io_stats", None)
+        if st:
+            log("BAM decode: %.2f s on %d threads (inflate %.2f s, parse %.2f s, names %.2f s), %.1f M records/s" % (
+                st["seconds_total"], st["n_threads"], st["seconds_inflate"], st["seconds_parse"], st["seconds_link"],
+                st["n_records"] / max(st["seconds_total"], 1e-9) / 1e6))
     rs = device_reads(binding, packed, device)
     return findflanks_packed(binding, rs, packed.contig_names, params, sample_id, output_file, verbose)

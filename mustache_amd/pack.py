@@ -283,3 +283,126 @@ def pack_nibbles(codes):
     if codes.size & 1:
         codes = np.concatenate([codes, np.zeros(1, np.uint8)])
     return ((codes[0::2] << 4) | codes[1::2]).astype(np.uint8)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# native ingestion: libmfkio.so (include/mfk_bamio.h) does BGZF inflate + the rules above in C++ threads
+# ---------------------------------------------------------------------------------------------------------------------
+import ctypes as _C
+import os as _os
+
+IO_LIB_PATH = _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "csrc", "libmfkio.so")
+POOL_MODES = {"none": 0, "clipped": 1, "all": 2, "regions": 3}
+
+
+class _IoRegion(_C.Structure):
+    _fields_ = [("contig_id", _C.c_int32), ("lo", _C.c_int32), ("hi", _C.c_int32), ("es", _C.c_int32),
+                ("ee", _C.c_int32)]
+
+
+_vp = _C.c_void_p
+
+
+class _IoArrays(_C.Structure):
+    _fields_ = ([("n_reads", _C.c_int64), ("n_contigs", _C.c_int32), ("max_span", _C.c_int32), ("n_cx", _C.c_int64),
+                 ("n_blk", _C.c_int64), ("n_pool", _C.c_int64), ("pool_bases_bytes", _C.c_int64),
+                 ("pool_quals_bytes", _C.c_int64)] +
+                [(k, _vp) for k in ("ref_start", "ref_end", "link", "contig_id", "qlen", "first_op_len", "last_op_len",
+                                    "mapq", "flags", "contig_len", "contig_read_start", "cx_read", "cx_off",
+                                    "blk_start", "blk_end", "blk_ins", "pool_read", "pool_off", "pool_bases",
+                                    "pool_quals", "contig_names")] +
+                [("contig_names_bytes", _C.c_int64), ("n_records", _C.c_int64), ("compressed_bytes", _C.c_int64),
+                 ("uncompressed_bytes", _C.c_int64), ("n_threads", _C.c_int32), ("inflate_backend", _C.c_int32),
+                 ("seconds_inflate", _C.c_double), ("seconds_parse", _C.c_double), ("seconds_link", _C.c_double),
+                 ("seconds_total", _C.c_double), ("n_redone_passes", _C.c_int64)])
+
+
+_io_lib = None
+
+
+def io_lib():
+    global _io_lib
+    if _io_lib is None:
+        if not _os.path.exists(IO_LIB_PATH):
+            raise PackError("shared library %s is missing: build it first (python -c 'import __graft_entry__ as g; "
+                            "g.build()')" % IO_LIB_PATH)
+        so = _C.CDLL(IO_LIB_PATH)
+        so.mfkio_pack_bam.restype = _C.c_int
+        so.mfkio_pack_bam.argtypes = [_C.c_char_p, _C.c_int, _vp, _C.c_int64, _C.c_int, _C.c_int64, _C.POINTER(_vp)]
+        so.mfkio_pack_arrays.restype = _C.POINTER(_IoArrays)
+        so.mfkio_pack_arrays.argtypes = [_vp]
+        so.mfkio_pack_error.restype = _C.c_char_p
+        so.mfkio_pack_error.argtypes = [_vp]
+        so.mfkio_pack_free.restype = None
+        so.mfkio_pack_free.argtypes = [_vp]
+        so.mfkio_version.restype = _C.c_int
+        _io_lib = so
+    return _io_lib
+
+
+class _IoOwner:
+    """Keeps a mfkio_pack alive for as long as any array that views its memory."""
+
+    def __init__(self, so, handle):
+        self.so, self.handle = so, handle
+
+    def __del__(self):
+        if self.handle:
+            self.so.mfkio_pack_free(self.handle)
+            self.handle = None
+
+
+def pack_bam(path, pool="clipped", regions=None, threads=0, chunk_bytes=0):
+    """Native counterpart of ``pack_reads(BamReader(path))``: same arrays, bit for bit.
+
+    pool:    'clipped' | 'all' | 'none' | 'regions'.
+    regions: for pool='regions' (pairflanks), rows (contig_id, lo, hi, es, ee) as ``candidate_regions`` returns them:
+             only reads over [lo, hi) are packed, those over [es, ee) carry their bases.
+    The returned PackedReads views the library's memory (no copy); ``.io_stats`` says what the run did.
+    """
+    so = io_lib()
+    mode = POOL_MODES[pool]
+    reg_arr, n_reg = None, 0
+    if mode == 3:
+        regs = list(regions or ())
+        n_reg = len(regs)
+        reg_arr = (_IoRegion * max(n_reg, 1))()
+        for k, r in enumerate(regs):
+            reg_arr[k] = _IoRegion(*[int(x) for x in r])
+    handle = _vp()
+    rc = so.mfkio_pack_bam(_os.fsencode(path), mode, _C.cast(reg_arr, _vp) if reg_arr is not None else None, n_reg,
+                           int(threads), int(chunk_bytes), _C.byref(handle))
+    owner = _IoOwner(so, handle.value)
+    if rc != 0:
+        msg = so.mfkio_pack_error(handle).decode("utf-8", "replace") if handle.value else "out of memory"
+        if rc == 3:
+            raise PackError(msg)
+        if rc == 1:
+            raise OSError(msg)
+        raise ValueError(msg)
+    a = so.mfkio_pack_arrays(handle).contents
+
+    def view(ptr, n, dtype):
+        dt = np.dtype(dtype)
+        if n == 0 or not ptr:
+            return np.zeros(0, dtype=dt)
+        buf = (_C.c_ubyte * (n * dt.itemsize)).from_address(ptr)
+        buf._owner = owner
+        arr = np.frombuffer(buf, dtype=dt)
+        arr.flags.writeable = False
+        return arr
+    n = int(a.n_reads)
+    sizes = {"contig_len": a.n_contigs, "contig_read_start": a.n_contigs + 1, "cx_read": a.n_cx, "cx_off": a.n_cx + 1,
+             "blk_start": a.n_blk, "blk_end": a.n_blk, "blk_ins": a.n_blk, "pool_read": a.n_pool,
+             "pool_off": a.n_pool + 1, "pool_bases": a.pool_bases_bytes, "pool_quals": a.pool_quals_bytes}
+    arrays = {}
+    for k, t in ALL_FIELDS:
+        arrays[k] = view(getattr(a, k), int(sizes.get(k, n)), t)
+    names_blob = _C.string_at(a.contig_names, a.contig_names_bytes) if a.contig_names_bytes else b""
+    contig_names = [s.decode() for s in names_blob.split(b"\0")[:a.n_contigs]]
+    p = PackedReads(contig_names, arrays, int(a.max_span))
+    p.io_stats = {k: getattr(a, k) for k in ("n_records", "compressed_bytes", "uncompressed_bytes", "n_threads",
+                                             "inflate_backend", "seconds_inflate", "seconds_parse", "seconds_link",
+                                             "seconds_total", "n_redone_passes")}
+    p._owner = owner
+    return p

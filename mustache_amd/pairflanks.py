@@ -9,7 +9,7 @@ import pandas as pd
 
 from . import lib as _lib
 from .findflanks import device_reads, log
-from .pack import pack_reads
+from .pack import pack_bam, pack_reads
 
 PAIR_COLUMNS = ["pair_id", "contig", "pos_5p", "pos_3p", "softclip_count_5p", "softclip_count_3p", "total_count_5p",
                 "total_count_3p", "spanning_count", "has_IR", "IR_length", "IR_5p", "IR_3p", "seq_5p", "seq_3p",
@@ -146,10 +146,32 @@ def pairflanks_packed(binding, reads_struct, contig_names, params, flanks: pd.Da
     return flank_pairs
 
 
+def _pack_regions_python(bam, contig_names, regions):
+    """The region filter + pool rule of pack_bam(pool='regions') spelled out on ``AlignedRead`` objects."""
+    by_contig = {}
+    for cid, lo, hi, es, ee in regions:
+        by_contig.setdefault(cid, []).append((lo, hi, es, ee))
+
+    def near(read, cid):
+        for lo, hi, _, _ in by_contig.get(cid, ()):
+            if read.reference_start < hi and read.reference_end > lo:
+                return True
+        return False
+
+    def in_window(read, cid):
+        for _, _, es, ee in by_contig.get(cid, ()):
+            if read.reference_start < ee and read.reference_end > es:
+                return True
+        return False
+    index = {n: i for i, n in enumerate(contig_names)}
+    reads = (r for r in bam if r.cigartuples is not None and near(r, index[r.reference_name]))
+    return pack_reads(bam.contigs, reads, pool=in_window)
+
+
 def _pairflanks(flanksfile, bamfile, genome, max_direct_repeat_length, min_alignment_quality,
                 min_alignment_inner_length, max_junction_spanning_prop=0.15, large_insertion_cutoff=30,
-                output_file=None, device="cuda:0", verbose=True, ir_backend="builtin"):
-    """Drop-in for reference pairflanks.py:18-51 (same positional arguments)."""
+                output_file=None, device="cuda:0", verbose=True, ir_backend="builtin", decoder="native"):
+    """Drop-in for reference pairflanks.py:18-51 (same positional arguments).  ``decoder`` as in ``_findflanks``."""
     if ir_backend == "einverted":
         from . import einverted
         einverted.find_einverted()          # fail before any work when the executable is missing
@@ -172,24 +194,12 @@ def _pairflanks(flanksfile, bamfile, genome, max_direct_repeat_length, min_align
         glen = np.diff(goff)
         regions = candidate_regions(tab, max_direct_repeat_length, glen)
         # only reads that can overlap a candidate region are packed; reads over a direct-repeat window carry bases
-        by_contig = {}
-        for cid, lo, hi, es, ee in regions:
-            by_contig.setdefault(cid, []).append((lo, hi, es, ee))
-
-        def near(read, cid):
-            for lo, hi, _, _ in by_contig.get(cid, ()):
-                if read.reference_start < hi and read.reference_end > lo:
-                    return True
-            return False
-
-        def in_window(read, cid):
-            for _, _, es, ee in by_contig.get(cid, ()):
-                if read.reference_start < ee and read.reference_end > es:
-                    return True
-            return False
-        index = {n: i for i, n in enumerate(contig_names)}
-        reads = (r for r in bam if r.cigartuples is not None and near(r, index[r.reference_name]))
-        packed = pack_reads(bam.contigs, reads, pool=in_window)
+        if decoder == "native":
+            packed = pack_bam(bamfile, pool="regions", regions=regions)
+        elif decoder == "python":
+            packed = _pack_regions_python(bam, contig_names, regions)
+        else:
+            raise ValueError("decoder must be 'native' or 'python', not %r" % (decoder,))
     rs = device_reads(binding, packed, device)
     gdev = torch.from_numpy(g).to(device)
     return pairflanks_packed(binding, rs, contig_names, params, flanks, gdev, goff, output_file, verbose, ir_backend)

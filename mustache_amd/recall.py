@@ -10,7 +10,7 @@ import pandas as pd
 
 from . import lib as _lib
 from .findflanks import device_reads, log
-from .pack import pack_reads
+from .pack import pack_bam
 
 RECALL_COLUMNS = ["contig", "pos", "orient", "softclip_count_5p", "softclip_count_3p", "runthrough_count",
                   "small_insertion_count_5p", "small_insertion_count_3p", "large_insertion_count_5p",
@@ -60,13 +60,11 @@ def recall_packed(binding, reads_struct, contig_names, params, pairs, output_fil
 def _recall(pairsfile, bamfile, min_alignment_quality, min_alignment_inner_length, large_insertion_cutoff, output_file,
             device="cuda:0", verbose=True):
     """Drop-in for reference recall.py:15-28 (same positional arguments)."""
-    from .bamio import BamReader
     pairs = pd.read_csv(pairsfile, sep="\t")
     binding = _lib.load(int(str(device).split(":")[1]) if ":" in str(device) else 0)
     params = _lib.make_params(min_alignment_quality=min_alignment_quality,
                               min_alignment_inner_length=min_alignment_inner_length,
                               large_insertion_cutoff=large_insertion_cutoff)
-    with BamReader(bamfile) as bam:
-        packed = pack_reads(bam.contigs, bam, pool="none")
+    packed = pack_bam(bamfile, pool="none")        # libmfkio.so: multi-threaded BGZF inflate + packing
     rs = device_reads(binding, packed, device)
     return recall_packed(binding, rs, packed.contig_names, params, pairs, output_file, verbose)
