@@ -388,9 +388,7 @@ def pack_bam(path, pool="clipped", regions=None, threads=0, chunk_bytes=0):
             return np.zeros(0, dtype=dt)
         buf = (_C.c_ubyte * (n * dt.itemsize)).from_address(ptr)
         buf._owner = owner
-        arr = np.frombuffer(buf, dtype=dt)
-        arr.flags.writeable = False
-        return arr
+        return np.frombuffer(buf, dtype=dt)
     n = int(a.n_reads)
     sizes = {"contig_len": a.n_contigs, "contig_read_start": a.n_contigs + 1, "cx_read": a.n_cx, "cx_off": a.n_cx + 1,
              "blk_start": a.n_blk, "blk_end": a.n_blk, "blk_ins": a.n_blk, "pool_read": a.n_pool,
