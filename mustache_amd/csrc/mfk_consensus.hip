@@ -30,8 +30,14 @@ struct CMeta {          // small device struct the host reads back once
 
 struct NodeSum { uint32_t q, c, e; };   // quality sum, #words through the node, #words ending on it
 
+struct WordSrc {        // where a word's characters come from: pool offsets and clip lengths of its one or two reads
+    uint64_t o1, o2;
+    uint16_t l1, l2, q1len, q2len;
+};
+
 struct Words {
     uint32_t n;                       // number of words (active jobs only)
+    WordSrc *src;
     int32_t *first, *second;          // reads
     uint32_t *nextra;                 // reads beyond the first with that name
     uint32_t *job;                    // job = 2*k + side
@@ -52,7 +58,8 @@ struct Words {
     uint32_t *cl_key;                 // (is_component << 31) | min DFS rank
     // device-side work lists (order arbitrary): the kernels that work per leaf / per cluster run a fixed grid over them
     uint32_t *leaf_list, *rep_list;   // slots of the leaves / of the cluster representatives
-    uint32_t *n_list;                 // [0] = number of leaves, [1] = number of representatives
+    uint32_t *out_list;               // slots of the leaves outside their job's giant component after the pivot pass
+    uint32_t *n_list;                 // [0] = number of leaves, [1] = number of representatives, [2] = number of outsiders
 };
 
 struct Jobs {
@@ -158,6 +165,8 @@ __global__ __launch_bounds__(256) void k_word_reads(DevReads R, DevParams P, Con
     }
 }
 
+// one thread per word: length, and where its characters are (a binary search of the pool per read: thousands of
+// independent searches in flight instead of one latency chain per wave in k_word_fill)
 __global__ void k_word_len(DevReads R, Words W, const uint32_t *n_words, CMeta *meta) {
     uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
     if (w >= *n_words) return;
@@ -165,9 +174,26 @@ __global__ void k_word_len(DevReads R, Words W, const uint32_t *n_words, CMeta *
     int64_t r1 = W.first[w], r2 = W.second[w];
     if (W.nextra[w] > 1) atomicOr(&meta->err, ERR_READ_NUMBER);      // findflanks.py:976-978 / 1025-1027
     uint8_t f1 = R.flags[r1];
-    int len = side == 0 ? d_rlen(R, r1, f1) : d_llen(R, r1, f1);
-    if (r2 >= 0) { uint8_t f2 = R.flags[r2]; int l2 = side == 0 ? d_rlen(R, r2, f2) : d_llen(R, r2, f2); if (l2 > len) len = l2; }
+    int l1 = side == 0 ? d_rlen(R, r1, f1) : d_llen(R, r1, f1), l2 = 0;
+    const int64_t p1 = d_pool_index(R, r1);
+    int64_t p2 = -1;
+    WordSrc src;
+    src.o1 = p1 >= 0 ? R.pool_off[p1] : 0; src.o2 = 0;
+    src.q1len = R.qlen[r1]; src.q2len = 0;
+    if (r2 >= 0) {
+        uint8_t f2 = R.flags[r2];
+        l2 = side == 0 ? d_rlen(R, r2, f2) : d_llen(R, r2, f2);
+        p2 = d_pool_index(R, r2);
+        src.o2 = p2 >= 0 ? R.pool_off[p2] : 0;
+        src.q2len = R.qlen[r2];
+    }
+    int len = l1 > l2 ? l1 : l2;
     if (len > MAX_WORD_LEN) { atomicOr(&meta->err, ERR_WORD_TOO_LONG); len = MAX_WORD_LEN; }
+    if (l1 > MAX_WORD_LEN) l1 = MAX_WORD_LEN;
+    if (l2 > MAX_WORD_LEN) l2 = MAX_WORD_LEN;
+    if (p1 < 0 || (r2 >= 0 && p2 < 0) || l1 > (int)src.q1len || l2 > (int)src.q2len) { atomicOr(&meta->err, ERR_NO_SEQUENCE); l1 = 0; l2 = 0; }
+    src.l1 = (uint16_t)l1; src.l2 = (uint16_t)l2;
+    W.src[w] = src;
     W.len[w] = (uint32_t)len;
     W.plen[w] = (uint32_t)((len + 15) & ~15);
     atomicMax(&meta->max_len, (uint32_t)len);
@@ -180,39 +206,25 @@ __device__ __forceinline__ void d_clip_char(const DevReads &R, uint64_t pool_off
     *q = R.pool_quals[k];
 }
 
-// one wave per word
-__global__ __launch_bounds__(256) void k_word_fill(DevReads R, Words W, CMeta *meta) {
+// one wave per word: mate merge by quality (combine_softclip_seq_quals_*, findflanks.py:932-1027)
+__global__ __launch_bounds__(256) void k_word_fill(DevReads R, Words W) {
     uint32_t w = blockIdx.x * 4 + (threadIdx.x >> 6);
     int lane = threadIdx.x & 63;
     if (w >= W.n) return;
-    int side = (int)(W.job[w] & 1);
-    int64_t r1 = W.first[w], r2 = W.second[w];
-    uint8_t f1 = R.flags[r1];
-    int l1 = side == 0 ? d_rlen(R, r1, f1) : d_llen(R, r1, f1), l2 = 0;
-    int64_t p1 = d_pool_index_wave(R, r1), p2 = -1;
-    uint64_t o1 = p1 >= 0 ? R.pool_off[p1] : 0, o2 = 0;
-    int q1len = R.qlen[r1], q2len = 0;
-    if (r2 >= 0) {
-        uint8_t f2 = R.flags[r2];
-        l2 = side == 0 ? d_rlen(R, r2, f2) : d_llen(R, r2, f2);
-        p2 = d_pool_index_wave(R, r2);
-        o2 = p2 >= 0 ? R.pool_off[p2] : 0;
-        q2len = R.qlen[r2];
-    }
-    if (p1 < 0 || (r2 >= 0 && p2 < 0) || l1 > q1len || l2 > q2len) { if (lane == 0) atomicOr(&meta->err, ERR_NO_SEQUENCE); return; }
-    if (l1 > MAX_WORD_LEN) l1 = MAX_WORD_LEN;
-    if (l2 > MAX_WORD_LEN) l2 = MAX_WORD_LEN;
+    const int side = (int)(W.job[w] & 1);
+    const WordSrc src = W.src[w];
+    const int l1 = src.l1, l2 = src.l2;
     uint8_t *ch = W.ch + W.off[w], *qq = W.q + W.off[w];
-    int len = (int)W.len[w], plen = (int)W.plen[w];
+    const int len = (int)W.len[w], plen = (int)W.plen[w];
     for (int p = lane; p < plen; p += 64) {
         uint8_t c = 0xFF, q = 0;
         if (p < len) {
             uint8_t c1 = 0, qa = 0, c2 = 0, qb = 0;
-            if (p < l1) d_clip_char(R, o1, q1len, l1, side, p, &c1, &qa);
-            if (p < l2) d_clip_char(R, o2, q2len, l2, side, p, &c2, &qb);
+            if (p < l1) d_clip_char(R, src.o1, src.q1len, l1, side, p, &c1, &qa);
+            if (p < l2) d_clip_char(R, src.o2, src.q2len, l2, side, p, &c2, &qb);
             if (p < l1 && p < l2) { if (qa >= qb) { c = c1; q = qa; } else { c = c2; q = qb; } }   // read1 = first in BAM order (Q4)
             else if (p < l1) { c = c1; q = qa; }
-            else { c = c2; q = qb; }
+            else if (p < l2) { c = c2; q = qb; }
         }
         ch[p] = c; qq[p] = q;
     }
@@ -248,33 +260,52 @@ __global__ __launch_bounds__(256) void k_job_longest(Words W, Jobs J) {
     }
 }
 
-// one wave per word i: is some other word an extension of it (or an earlier copy)?
-__global__ __launch_bounds__(256) void k_leaf_flags(Words W, Jobs J) {
-    uint32_t w = blockIdx.x * 4 + (threadIdx.x >> 6);
-    int lane = threadIdx.x & 63;
-    if (w >= W.n) return;
-    uint32_t job = W.job[w], w0 = J.w0[job], R = J.R[job];
-    const uint8_t *a = W.ch + W.off[w];
-    int la = (int)W.len[w];
+// is some other word an extension of a word (or an earlier copy)?  One wave per LF_WORDS consecutive words.  First
+// every word is tested against the N_LONGEST longest words of its job, all LF_WORDS x N_LONGEST tests at once (one lane
+// each, so the dependent loads job -> word range -> longest -> characters are paid once per wave, not once per word);
+// the words that settles (error-free reads) are done.  The others are scanned against every word of their job by the
+// whole wave.
+// lf = words per wave (1..LF_WORDS): the host takes fewer when there are too few words to fill the GPU with waves.
+#define LF_WORDS 8
+__global__ __launch_bounds__(256) void k_leaf_flags(Words W, Jobs J, int lf) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t wbase = (blockIdx.x * 4 + (threadIdx.x >> 6)) * (uint32_t)lf;
+    if (wbase >= W.n) return;
+    uint32_t m_w0 = 0, m_R = 0, m_off = 0;
+    int m_la = 0;
     bool covered = false;
-    if (lane < N_LONGEST) {
-        uint32_t j = J.longest[job * N_LONGEST + lane];
-        if (j != 0xFFFFFFFFu) {
-            uint32_t v = w0 + j;
-            int lb = (int)W.len[v];
-            if (v != w && lb >= la && d_lcp(a, la, W.ch + W.off[v], lb) >= la && (lb > la || v < w)) covered = true;
+    {
+        const uint32_t w = wbase + (uint32_t)lane / N_LONGEST;
+        if (lane < lf * N_LONGEST && w < W.n) {
+            const uint32_t job = W.job[w];
+            m_w0 = J.w0[job]; m_R = J.R[job]; m_off = (uint32_t)W.off[w]; m_la = (int)W.len[w];
+            const uint32_t j = J.longest[job * N_LONGEST + (lane % N_LONGEST)];
+            if (j != 0xFFFFFFFFu) {
+                const uint32_t v = m_w0 + j;
+                const int lb = (int)W.len[v];
+                if (v != w && lb >= m_la && d_lcp(W.ch + m_off, m_la, W.ch + W.off[v], lb) >= m_la && (lb > m_la || v < w)) covered = true;
+            }
         }
     }
-    if (__ballot(covered)) { if (lane == 0) W.is_leaf[w] = 0; return; }
-    for (uint32_t j = lane; j < R && !covered; j += 64) {
-        uint32_t v = w0 + j;
-        if (v == w) continue;
-        int lb = (int)W.len[v];
-        if (lb < la) continue;
-        if (d_lcp(a, la, W.ch + W.off[v], lb) >= la && (lb > la || v < w)) covered = true;
+    const unsigned long long cov = __ballot(covered);
+    for (int i = 0; i < lf; i++) {   // wave-uniform
+        const uint32_t w = wbase + (uint32_t)i;
+        if (w >= W.n) break;
+        if ((cov >> (i * N_LONGEST)) & ((1ull << N_LONGEST) - 1)) { if (lane == 0) W.is_leaf[w] = 0; continue; }
+        const uint32_t w0 = __shfl(m_w0, i * N_LONGEST, 64), R = __shfl(m_R, i * N_LONGEST, 64);
+        const int la = __shfl(m_la, i * N_LONGEST, 64);
+        const uint8_t *a = W.ch + __shfl(m_off, i * N_LONGEST, 64);
+        bool c2 = false;
+        for (uint32_t j = lane; j < R && !c2; j += 64) {
+            const uint32_t v = w0 + j;
+            if (v == w) continue;
+            const int lb = (int)W.len[v];
+            if (lb < la) continue;
+            if (d_lcp(a, la, W.ch + W.off[v], lb) >= la && (lb > la || v < w)) c2 = true;
+        }
+        const unsigned long long any = __ballot(c2);
+        if (lane == 0) W.is_leaf[w] = any ? 0 : 1;
     }
-    unsigned long long any = __ballot(covered);
-    if (lane == 0) W.is_leaf[w] = any ? 0 : 1;
 }
 
 // one block per job: ordered list of its leaves
@@ -298,22 +329,38 @@ __global__ __launch_bounds__(256) void k_leaf_compact(Words W, Jobs J) {
     for (uint32_t i = threadIdx.x; i < running; i += blockDim.x) W.leaf_list[s_base + i] = w0 + i;
 }
 
-// one wave per leaf slot: t(a[:d+1]) = first word sharing d+1 characters with the leaf, for every depth d
+// one wave per leaf slot: t(a[:d+1]) = first word sharing d+1 characters with the leaf, for every depth d.
+// A wave walks a strided sequence of leaves; what it needs to know about a leaf (slot -> job -> word range, leaf word ->
+// offset, length) is a chain of dependent loads, so lane k resolves the chain of the wave's k-th next leaf and the
+// results are broadcast leaf by leaf: 64 chains in flight instead of one.
 __global__ __launch_bounds__(64) void k_leaf_first(Words W, Jobs J, uint16_t *lcpm) {
     __shared__ uint32_t tmin[MAX_WORD_LEN];
     const int lane = threadIdx.x;
     const uint32_t n_leaf = W.n_list[0];
-    for (uint32_t it = blockIdx.x; it < n_leaf; it += gridDim.x) {
+    for (uint64_t it0 = blockIdx.x; it0 < n_leaf; it0 += (uint64_t)gridDim.x * 64) {
+    uint32_t m_slot = 0, m_w0 = 0, m_R = 0, m_off = 0, m_la = 0;
+    unsigned long long m_adj = 0;
+    {
+        const uint64_t it = it0 + (uint64_t)lane * gridDim.x;
+        if (it < n_leaf) {
+            m_slot = W.leaf_list[it];
+            const uint32_t job = W.job[m_slot];
+            m_w0 = J.w0[job]; m_R = J.R[job]; m_adj = J.adj_off[job];
+            const uint32_t wa = m_w0 + W.leaf_word[m_slot];
+            m_off = (uint32_t)W.off[wa]; m_la = W.len[wa];
+        }
+    }
+    for (int kk = 0; kk < 64 && it0 + (uint64_t)kk * gridDim.x < n_leaf; kk++) {   // wave-uniform
     __syncthreads();
-    uint32_t slot = W.leaf_list[it];
-    uint32_t job = W.job[slot], w0 = J.w0[job], R = J.R[job];
-    uint32_t k = slot - w0;
-    uint32_t wa = w0 + W.leaf_word[slot];
-    const uint8_t *a = W.ch + W.off[wa];
-    int la = (int)W.len[wa];
+    const uint32_t slot = __shfl(m_slot, kk, 64), w0 = __shfl(m_w0, kk, 64), R = __shfl(m_R, kk, 64);
+    const uint32_t off_a = __shfl(m_off, kk, 64);
+    const int la = (int)__shfl(m_la, kk, 64);
+    const unsigned long long adj_off = __shfl(m_adj, kk, 64);
+    const uint32_t k = slot - w0;
+    const uint8_t *a = W.ch + off_a;
     for (int d = lane; d < la; d += 64) tmin[d] = 0xFFFFFFFFu;
     __syncthreads();
-    uint16_t *mrow = lcpm + J.adj_off[job] * 32 + (size_t)k * ((R + 31) >> 5) * 32;   // LCP(leaf, word j), reused by k_reach
+    uint16_t *mrow = lcpm + adj_off * 32 + (size_t)k * ((R + 31) >> 5) * 32;   // LCP(leaf, word j), reused by k_leaf_share
     for (uint32_t j = lane; j < R; j += 64) {
         uint32_t v = w0 + j;
         const int lv = (int)W.len[v];
@@ -331,11 +378,12 @@ __global__ __launch_bounds__(64) void k_leaf_first(Words W, Jobs J, uint16_t *lc
     for (int o = 1; o < 64; o <<= 1) { uint32_t other = __shfl_down(suf, o, 64); if (lane + o < 64 && other < suf) suf = other; }
     uint32_t after = __shfl_down(suf, 1, 64);   // minimum over the lanes behind
     if (lane == 63) after = 0xFFFFFFFFu;
-    uint32_t *np = W.npos + W.off[wa];
+    uint32_t *np = W.npos + off_a;
     uint32_t m = after;
     for (int d = d0 + per - 1; d >= d0; d--) if (d < la) {
         uint32_t v = tmin[d]; if (v < m) m = v;
         np[d] = (uint32_t)(W.off[w0 + m] + (uint64_t)d);   // node of a[:d+1] = character d of the first word with that prefix
+    }
     }
     }
 }
@@ -422,11 +470,64 @@ __global__ __launch_bounds__(256) void k_leaf_rank(Words W, Jobs J) {
     }
 }
 
-__device__ __forceinline__ int d_myers_any(const uint64_t (*sh_plane)[8], int need, const uint8_t *text, int m) {
+// k_leaf_rank for jobs with few leaves (a 100-200x site has a few dozen): one wave per leaf, no LDS, no barrier, and the
+// dependent loads that describe a leaf are resolved for 64 leaves at a time (lane k: the wave's k-th next leaf).
+__global__ __launch_bounds__(256) void k_leaf_rank_wave(Words W, Jobs J) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t wave = blockIdx.x * 4 + (threadIdx.x >> 6), n_waves = gridDim.x * 4;
+    const uint32_t n_leaf = W.n_list[0];
+    for (uint64_t it0 = wave; it0 < n_leaf; it0 += (uint64_t)n_waves * 64) {
+        uint32_t m_slot = 0, m_w0 = 0, m_nl = 0, m_off = 0, m_la = 0;
+        {
+            const uint64_t it = it0 + (uint64_t)lane * n_waves;
+            if (it < n_leaf) {
+                m_slot = W.leaf_list[it];
+                const uint32_t job = W.job[m_slot];
+                m_w0 = J.w0[job]; m_nl = J.nl[job];
+                const uint32_t wa = m_w0 + W.leaf_word[m_slot];
+                m_off = (uint32_t)W.off[wa]; m_la = W.len[wa];
+            }
+        }
+        for (int kk = 0; kk < 64 && it0 + (uint64_t)kk * n_waves < n_leaf; kk++) {   // wave-uniform
+            const uint32_t slot = __shfl(m_slot, kk, 64), w0 = __shfl(m_w0, kk, 64), nl = __shfl(m_nl, kk, 64);
+            const uint32_t off_a = __shfl(m_off, kk, 64);
+            const int la = (int)__shfl(m_la, kk, 64);
+            const uint32_t ka = slot - w0;
+            const uint8_t *a = W.ch + off_a;
+            const uint32_t *ta = W.npos + off_a;
+            uint32_t before = 0;
+            for (uint32_t kb = lane; kb < nl; kb += 64) {
+                if (kb == ka) continue;
+                const uint32_t wb = w0 + W.leaf_word[w0 + kb];
+                const int lb = (int)W.len[wb];
+                const uint64_t off_b = W.off[wb];
+                const int m = la < lb ? la : lb;
+                const int k = d_lcp(a, la, W.ch + off_b, lb);
+                if (k < m && W.npos[off_b + k] < ta[k]) before++;
+            }
+            for (int o = 32; o > 0; o >>= 1) before += __shfl_xor(before, o, 64);
+            if (lane == 0) W.leaf_rank[slot] = before;
+        }
+    }
+}
+
+// bit planes of a leaf's 4-bit codes, built by the whole wave: lane l looks at character 64*i + l, a ballot per code bit
+// is limb i of that plane.  The result is wave-uniform, so no LDS and no barrier is involved.
+__device__ __forceinline__ void d_planes_wave(const uint8_t *a, int la, int need, int lane, uint64_t (&pl)[4][8]) {
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        uint32_t c = 0;
+        if (i < need) { const int pos = i * 64 + lane; if (pos < la) c = a[pos]; }   // need is wave-uniform
+#pragma unroll
+        for (int p = 0; p < 4; p++) pl[p][i] = i < need ? __ballot((c >> p) & 1) : 0ull;
+    }
+}
+
+__device__ __forceinline__ int d_myers_any(const uint64_t (&planes)[4][8], int need, const uint8_t *text, int m) {
 #define MYERS_CASE(NL_)                                                                                  \
     {                                                                                                    \
         uint64_t pl[4][NL_];                                                                             \
-        _Pragma("unroll") for (int p = 0; p < 4; p++) _Pragma("unroll") for (int i = 0; i < NL_; i++) pl[p][i] = sh_plane[p][i]; \
+        _Pragma("unroll") for (int p = 0; p < 4; p++) _Pragma("unroll") for (int i = 0; i < NL_; i++) pl[p][i] = planes[p][i]; \
         return d_myers<NL_>(pl, text, m);                                                                \
     }
     switch (need) {
@@ -442,52 +543,52 @@ __device__ __forceinline__ int d_myers_any(const uint64_t (*sh_plane)[8], int ne
 // Edit-distance tests between leaves (get_sequence_clusters, findflanks.py:1041-1053).  Only connectivity and "has any
 // match" are needed downstream, so pairs inside an already known component are never tested:
 //   mode 0: the first N_PIVOTS leaves of the job against every later leaf;
-//   mode 1: every leaf outside the giant component against every leaf of a different component.
+//   mode 1: every leaf outside the giant component (W.out_list, written by k_components) against every leaf of a
+//           different component.
 // Every pair across two components of the mode-0 graph is tested, so the final components are those of the full graph.
-// One block per leaf slot a (the bit-vector pattern), threads over the partners.
-__global__ __launch_bounds__(256) void k_leaf_myers(Words W, Jobs J, int mode) {
-    __shared__ uint64_t sh_plane[4][8];
-    // work items: mode 0 = (job, pivot) pairs, mode 1 = the leaf list
-    const uint32_t n_items = mode == 0 ? J.n * N_PIVOTS : W.n_list[0];
-    for (uint32_t it = blockIdx.x; it < n_items; it += gridDim.x) {
-    __syncthreads();
-    uint32_t job, ka, slot;
-    if (mode == 0) { job = it / N_PIVOTS; ka = it % N_PIVOTS; slot = J.w0[job] + ka; }
-    else { slot = W.leaf_list[it]; job = W.job[slot]; ka = slot - J.w0[job]; }
-    uint32_t w0 = J.w0[job], R = J.R[job], nl = J.nl[job];
-    if (ka >= nl || nl < 2) continue;
-    uint32_t my_label = 0, giant = 0;
-    if (mode == 1) { my_label = W.label[slot]; giant = J.giant[job]; if (my_label == giant) continue; }
-    uint32_t wa = w0 + W.leaf_word[slot];
-    const uint8_t *a = W.ch + W.off[wa];
-    const int la = (int)W.len[wa];
-    const int need = (la + 63) >> 6;
-    if (need > 8) continue;   // cannot happen: words are capped at MAX_WORD_LEN
-    if (threadIdx.x < 32) {
-        int p = threadIdx.x >> 3, i = threadIdx.x & 7;
-        uint64_t v = 0;
-        if (i < need) for (int b = 0; b < 64; b++) { int pos = i * 64 + b; if (pos < la && ((a[pos] >> p) & 1)) v |= 1ull << b; }
-        sh_plane[p][i] = v;
-    }
-    __syncthreads();
-    const uint32_t rw = (R + 31) >> 5;
-    uint32_t *adj = J.adj + J.adj_off[job];
-    for (uint32_t kb = (mode == 0 ? ka + 1 : 0) + threadIdx.x; kb < nl; kb += blockDim.x) {
-        if (mode == 1) {
-            if (kb == ka) continue;
-            uint32_t lb_label = W.label[w0 + kb];
-            if (lb_label == my_label) continue;
-            if (lb_label != giant && kb < ka) continue;       // two outsiders: the lower slot's block takes the pair
+// The work item is (pattern leaf a, chunk of partners) and belongs to ONE WAVE: lane l of chunk c takes the partners
+// c*64 + l, + 64*n_chunks, ...  A site at 200x has a few dozen leaves and one chunk, a 1000x site hundreds of leaves in
+// up to 16 chunks: either way the GPU is filled with waves that each run one bit-vector recurrence, and nothing waits
+// at a barrier.
+__global__ __launch_bounds__(256) void k_leaf_myers(Words W, Jobs J, int mode, uint32_t n_chunks) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t wave = blockIdx.x * 4 + (threadIdx.x >> 6), n_waves = gridDim.x * 4;
+    const uint32_t n_items = (mode == 0 ? J.n * N_PIVOTS : W.n_list[2]) * n_chunks;
+    for (uint32_t it = wave; it < n_items; it += n_waves) {   // wave-uniform
+        uint32_t job, ka, slot, chunk;
+        if (mode == 0) { chunk = it / (J.n * N_PIVOTS); const uint32_t r = it % (J.n * N_PIVOTS); job = r / N_PIVOTS; ka = r % N_PIVOTS; slot = J.w0[job] + ka; }
+        else { chunk = it % n_chunks; slot = W.out_list[it / n_chunks]; job = W.job[slot]; ka = slot - J.w0[job]; }
+        const uint32_t w0 = J.w0[job], R = J.R[job], nl = J.nl[job];
+        if (ka >= nl || nl < 2) continue;
+        const uint32_t first = (mode == 0 ? ka + 1 : 0) + chunk * 64;
+        if (first >= nl) continue;
+        uint32_t my_label = 0, giant = 0;
+        if (mode == 1) { my_label = W.label[slot]; giant = J.giant[job]; }
+        const uint32_t wa = w0 + W.leaf_word[slot];
+        const uint8_t *a = W.ch + W.off[wa];
+        const int la = (int)W.len[wa];
+        const int need = (la + 63) >> 6;
+        if (need > 8) continue;   // cannot happen: words are capped at MAX_WORD_LEN
+        uint64_t planes[4][8];
+        d_planes_wave(a, la, need, lane, planes);
+        const uint32_t rw = (R + 31) >> 5;
+        uint32_t *adj = J.adj + J.adj_off[job];
+        for (uint32_t kb = first + lane; kb < nl; kb += 64 * n_chunks) {
+            if (mode == 1) {
+                if (kb == ka) continue;
+                const uint32_t lb_label = W.label[w0 + kb];
+                if (lb_label == my_label) continue;
+                if (lb_label != giant && kb < ka) continue;       // two outsiders: the lower slot's wave takes the pair
+            }
+            const uint32_t wb = w0 + W.leaf_word[w0 + kb];
+            const int lb = (int)W.len[wb];
+            const int m = la < lb ? la : lb;
+            const int d = d_myers_any(planes, need, W.ch + W.off[wb], m);
+            if (4 * d <= m) {   // similarity = 1 - d/m >= 0.75 (findflanks.py:1044-1048, quirk Q11)
+                atomicOr(&adj[(size_t)ka * rw + (kb >> 5)], 1u << (kb & 31));
+                atomicOr(&adj[(size_t)kb * rw + (ka >> 5)], 1u << (ka & 31));
+            }
         }
-        uint32_t wb = w0 + W.leaf_word[w0 + kb];
-        const int lb = (int)W.len[wb];
-        const int m = la < lb ? la : lb;
-        int d = d_myers_any(sh_plane, need, W.ch + W.off[wb], m);
-        if (4 * d <= m) {   // similarity = 1 - d/m >= 0.75 (findflanks.py:1044-1048, quirk Q11)
-            atomicOr(&adj[(size_t)ka * rw + (kb >> 5)], 1u << (kb & 31));
-            atomicOr(&adj[(size_t)kb * rw + (ka >> 5)], 1u << (ka & 31));
-        }
-    }
     }
 }
 
@@ -533,10 +634,26 @@ __global__ __launch_bounds__(256) void k_components(Words W, Jobs J, int final_p
         for (uint32_t p = 0; p < np; p++) if (label[p] == l) { atomicAdd(&pc[p], 1u); break; }
     }
     __syncthreads();
+    __shared__ uint32_t s_giant;
     if (threadIdx.x == 0) {
         uint32_t best = 0;
         for (uint32_t p = 1; p < np; p++) if (pc[p] > pc[best]) best = p;
-        J.giant[job] = label[best];
+        s_giant = label[best];
+        J.giant[job] = s_giant;
+    }
+    if (!final_pass) {   // list of the leaves outside the giant component for k_leaf_myers mode 1: one reservation per job
+        __shared__ uint32_t s_nout, s_obase;
+        if (threadIdx.x == 0) s_nout = 0;
+        __syncthreads();
+        const uint32_t giant = s_giant;
+        uint32_t mine = 0;
+        for (uint32_t a = threadIdx.x; a < nl; a += blockDim.x) if (label[a] != giant) mine++;
+        uint32_t at = mine ? atomicAdd(&s_nout, mine) : 0;
+        __syncthreads();
+        if (threadIdx.x == 0 && s_nout) s_obase = atomicAdd(&W.n_list[2], s_nout);
+        __syncthreads();
+        at += s_obase;
+        for (uint32_t a = threadIdx.x; a < nl; a += blockDim.x) if (label[a] != giant) W.out_list[at++] = w0 + a;
     }
     if (final_pass) {   // list of the cluster representatives for k_cluster_vote: one global reservation per job
         __shared__ uint32_t s_nrep, s_rbase;
@@ -569,22 +686,35 @@ __global__ __launch_bounds__(1024) void k_node_sums(Words W, Jobs J, uint32_t ma
     __syncthreads();
     const int lane = threadIdx.x & 63;
     const uint32_t w_end = (blockIdx.x + 1) * NS_WORDS < W.n ? (blockIdx.x + 1) * NS_WORDS : W.n;
-    for (uint32_t w = blockIdx.x * NS_WORDS + (threadIdx.x >> 6); w < w_end; w += blockDim.x >> 6) {
+    // a wave takes NS_WORDS / waves consecutive words.  Where a word's nodes are is five dependent loads away (job ->
+    // word range, covering leaf -> its word -> its npos row): lane i resolves that chain for the wave's i-th word, so
+    // the chains of all its words are in flight together, and the results are broadcast word by word.
+    const uint32_t wpw = NS_WORDS / (blockDim.x >> 6);
+    const uint32_t wbase = blockIdx.x * NS_WORDS + (threadIdx.x >> 6) * wpw;
+    uint32_t my_np = 0, my_q = 0;
+    int my_len = 0;
+    if ((uint32_t)lane < wpw && wbase + lane < w_end) {
+        const uint32_t w = wbase + lane;
         const uint32_t job = W.job[w], w0 = J.w0[job];
         const uint32_t k = W.cover[w];
-        if (k == 0xFFFFFFFFu) continue;   // cannot happen: every word is a prefix of a leaf
-        const uint32_t wl = w0 + W.leaf_word[w0 + k];
-        const uint32_t *np = W.npos + W.off[wl];
-        const uint8_t *q = W.q + W.off[w];
-        const int len = (int)W.len[w];
+        if (k != 0xFFFFFFFFu) {   // always: every word is a prefix of a leaf
+            const uint32_t wl = w0 + W.leaf_word[w0 + k];
+            my_np = (uint32_t)W.off[wl]; my_q = (uint32_t)W.off[w]; my_len = (int)W.len[w];   // offsets < 2^32 (checked by the host)
+        }
+    }
+    for (uint32_t i = 0; i < wpw; i++) {
+        const int len = __shfl(my_len, (int)i, 64);
+        if (!len) continue;
+        const uint32_t *np = W.npos + __shfl(my_np, (int)i, 64);
+        const uint8_t *q = W.q + __shfl(my_q, (int)i, 64);
         for (int d = lane; d < len; d += 64) {
             const uint32_t pos = np[d], qv = q[d];
             int sl = 0;
             for (; sl < NS_SLOTS; sl++) { uint32_t old = atomicCAS(&tk[sl * max_len + d], 0xFFFFFFFFu, pos); if (old == 0xFFFFFFFFu || old == pos) break; }
             if (sl < NS_SLOTS) {
-                const uint32_t i = sl * max_len + d;
-                atomicAdd(&tq[i], qv); atomicAdd(&tc[i], 1u);
-                if (d == len - 1) atomicAdd(&te[i], 1u);
+                const uint32_t i2 = sl * max_len + d;
+                atomicAdd(&tq[i2], qv); atomicAdd(&tc[i2], 1u);
+                if (d == len - 1) atomicAdd(&te[i2], 1u);
             } else {
                 atomicAdd(&W.agg[pos].q, qv); atomicAdd(&W.agg[pos].c, 1u);
                 if (d == len - 1) atomicAdd(&W.agg[pos].e, 1u);
@@ -776,17 +906,17 @@ int run_consensus(mfk_ctx *ctx, const DevReads &R, const DevParams &P, Consensus
     J.n = 2 * n_act;
     J.w0 = aalloc<uint32_t>(ctx, J.n); J.R = aalloc<uint32_t>(ctx, J.n); J.nl = aalloc<uint32_t>(ctx, J.n);
     J.adj_words = aalloc<uint32_t>(ctx, J.n); J.adj_off = aalloc<uint64_t>(ctx, (size_t)J.n + 1); J.best = aalloc<uint32_t>(ctx, J.n); J.giant = aalloc<uint32_t>(ctx, J.n); J.longest = aalloc<uint32_t>(ctx, 4 * (size_t)J.n);
-    W.first = aalloc<int32_t>(ctx, E); W.job = aalloc<uint32_t>(ctx, E); W.len = aalloc<uint32_t>(ctx, E);
+    W.first = aalloc<int32_t>(ctx, E); W.job = aalloc<uint32_t>(ctx, E); W.len = aalloc<uint32_t>(ctx, E); W.src = aalloc<WordSrc>(ctx, E);
     W.off = aalloc<uint64_t>(ctx, (size_t)E + 1); W.is_leaf = aalloc<uint8_t>(ctx, E); W.leaf_word = aalloc<uint32_t>(ctx, E);
     W.cl_count = aalloc<int32_t>(ctx, E); W.cl_len = aalloc<int32_t>(ctx, E); W.cl_key = aalloc<uint32_t>(ctx, E);
-    W.leaf_list = aalloc<uint32_t>(ctx, E); W.rep_list = aalloc<uint32_t>(ctx, E); W.share = aalloc<uint32_t>(ctx, E);
+    W.leaf_list = aalloc<uint32_t>(ctx, E); W.rep_list = aalloc<uint32_t>(ctx, E); W.share = aalloc<uint32_t>(ctx, E); W.out_list = aalloc<uint32_t>(ctx, E);
     {
         FillGroup z(ctx, 0), f(ctx, 0xFF);
         z.want(&wflag, E); z.want(&meta, 1); z.want(&W.nextra, E); z.want(&W.plen, E); z.want(&W.leaf_rank, E);
-        z.want(&W.has_match, E); z.want(&W.n_list, 2);
+        z.want(&W.has_match, E); z.want(&W.n_list, 4);
         f.want(&W.second, E); f.want(&W.label, E); f.want(&W.cover, E);
-        if (!wid || !J.w0 || !J.R || !J.nl || !J.adj_words || !J.adj_off || !J.best || !J.giant || !J.longest || !W.first || !W.job || !W.len || !W.off ||
-            !W.is_leaf || !W.leaf_word || !W.cl_count || !W.cl_len || !W.cl_key || !W.leaf_list || !W.rep_list || !W.share || z.commit() || f.commit()) return 1;
+        if (!wid || !J.w0 || !J.R || !J.nl || !J.adj_words || !J.adj_off || !J.best || !J.giant || !J.longest || !W.first || !W.job || !W.len || !W.src || !W.off ||
+            !W.is_leaf || !W.leaf_word || !W.cl_count || !W.cl_len || !W.cl_key || !W.leaf_list || !W.rep_list || !W.share || !W.out_list || z.commit() || f.commit()) return 1;
     }
     PROF_LAUNCH(k_word_flags, dim3(n_act), dim3(256), 0, st, io, wflag);
     KCHK();
@@ -806,6 +936,7 @@ int run_consensus(mfk_ctx *ctx, const DevReads &R, const DevParams &P, Consensus
     W.n = Wn;
     const unsigned ww = nblocks(Wn, 4);
     if (hm.err & ERR_READ_NUMBER) { snprintf(ctx->err, sizeof ctx->err, "READ NUMBER ERROR - ZERO OR MORE THAN TWO READS ASSOCIATED WITH QUERY NAME"); return 3; }
+    if (hm.err & ERR_NO_SEQUENCE) { snprintf(ctx->err, sizeof ctx->err, "a clipped read at a surviving site has no sequence in the pool (pack with pool='clipped')"); return 2; }
     if (hm.err & ERR_WORD_TOO_LONG) { snprintf(ctx->err, sizeof ctx->err, "soft clip longer than %d bases: not supported by this build", MAX_WORD_LEN); return 6; }
     {
         FillGroup z(ctx, 0);
@@ -816,11 +947,12 @@ int run_consensus(mfk_ctx *ctx, const DevReads &R, const DevParams &P, Consensus
     if (total_chars >= 0xFFFFFFF0ull) { snprintf(ctx->err, sizeof ctx->err, "more than 2^32 clipped bases at the surviving sites of one call"); return 1; }
     W.npos = aalloc<uint32_t>(ctx, (size_t)total_chars + 8);
     if (!W.ch || !W.q || !W.npos) return 1;
-    PROF_LAUNCH(k_word_fill, dim3(ww), dim3(256), 0, st, R, W, meta);
+    PROF_LAUNCH(k_word_fill, dim3(ww), dim3(256), 0, st, R, W);
     KCHK();
     PROF_LAUNCH(k_job_longest, dim3(J.n), dim3(256), 0, st, W, J);
     KCHK();
-    PROF_LAUNCH(k_leaf_flags, dim3(ww), dim3(256), 0, st, W, J);
+    const int lf = Wn >= (1u << 18) ? LF_WORDS : (Wn >= (1u << 17) ? 4 : (Wn >= (1u << 16) ? 2 : 1));
+    PROF_LAUNCH(k_leaf_flags, dim3(nblocks(Wn, 4 * (size_t)lf)), dim3(256), 0, st, W, J, lf);
     KCHK();
     PROF_LAUNCH(k_leaf_compact, dim3(J.n), dim3(256), 0, st, W, J);
     KCHK();
@@ -836,13 +968,20 @@ int run_consensus(mfk_ctx *ctx, const DevReads &R, const DevParams &P, Consensus
         PROF_LAUNCH(k_node_sums, dim3(nblocks(Wn, NS_WORDS)), dim3(1024), ns_lds, st, W, J, max_len);
         KCHK();
     }
-    PROF_LAUNCH(k_leaf_rank, dim3(g_leaf4), dim3(256), 0, st, W, J);
+    if (hm.max_R <= 256) { PROF_LAUNCH(k_leaf_rank_wave, dim3(g_leaf4), dim3(256), 0, st, W, J); }
+    else { PROF_LAUNCH(k_leaf_rank, dim3(g_leaf4), dim3(256), 0, st, W, J); }
     KCHK();
-    PROF_LAUNCH(k_leaf_myers, dim3(J.n * N_PIVOTS), dim3(256), 0, st, W, J, 0);
+    // partner chunks per pattern leaf: enough 64-lane chunks for the largest job, at most 16 (larger jobs stride)
+    uint32_t n_chunks = (hm.max_R + 63) / 64;
+    if (n_chunks < 1) n_chunks = 1;
+    if (n_chunks > 16) n_chunks = 16;
+    const uint64_t my_items = (uint64_t)J.n * N_PIVOTS * n_chunks;
+    const unsigned g_my0 = (unsigned)(my_items / 4 + 1 < 8192 ? my_items / 4 + 1 : 8192);
+    PROF_LAUNCH(k_leaf_myers, dim3(g_my0), dim3(256), 0, st, W, J, 0, n_chunks);
     KCHK();
     PROF_LAUNCH(k_components, dim3(J.n), dim3(256), 0, st, W, J, 0);
     KCHK();
-    PROF_LAUNCH(k_leaf_myers, dim3(g_leaf4), dim3(256), 0, st, W, J, 1);
+    PROF_LAUNCH(k_leaf_myers, dim3(g_leaf4), dim3(256), 0, st, W, J, 1, n_chunks);
     KCHK();
     PROF_LAUNCH(k_components, dim3(J.n), dim3(256), 0, st, W, J, 1);
     KCHK();

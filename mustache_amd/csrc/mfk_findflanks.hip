@@ -555,7 +555,9 @@ extern "C" int mfk_findflanks(mfk_ctx *ctx, const mfk_reads *reads, const mfk_pa
         PROF_LAUNCH(k_compact_sites, dim3(eb), dim3(256), 0, st, T, n_sites_p, (const uint32_t *)ascan, A);
         KCHK();
         if (stop_after >= MFK_STAGE_UNCLIPPED) {
-            PROF_LAUNCH(k_classify, dim3(n_act), dim3(1024), 0, st, R, P, A, n_act);   // few sites, ~1000 reads each: wide workgroups keep the gather chains short
+            // few sites (a deep isolate): wide workgroups keep each site's gather chain short; thousands of sites: narrow
+            // ones, so that four times as many sites are resident per CU
+            PROF_LAUNCH(k_classify, dim3(n_act), dim3(n_act >= 2048 ? 256 : 1024), 0, st, R, P, A, n_act);
             KCHK();
         }
         if (stop_after >= MFK_STAGE_RATIOS) {
@@ -685,7 +687,7 @@ extern "C" int mfk_recall(mfk_ctx *ctx, const mfk_reads *reads, const mfk_params
     for (int64_t i = 0; i < n_sites; i++) { hs[2 * i] = h_contig_id[i]; hs[2 * i + 1] = h_pos[i]; }
     HIPCHK(hipMemcpyAsync(d_sites, hs, bytes, hipMemcpyHostToDevice, st));
     HIPCHK(hipEventRecord(ctx->ev0, st));
-    PROF_LAUNCH(k_recall, dim3((unsigned)n_sites), dim3(1024), 0, st, R, P, (const int32_t *)d_sites, (uint32_t)n_sites, d_counts);
+    PROF_LAUNCH(k_recall, dim3((unsigned)n_sites), dim3(n_sites >= 2048 ? 256 : 1024), 0, st, R, P, (const int32_t *)d_sites, (uint32_t)n_sites, d_counts);
     KCHK();
     HIPCHK(hipEventRecord(ctx->ev1, st));
     if (int rc = read_back(ctx, d_counts, h_counts, 10 * (size_t)n_sites * 4)) return rc;

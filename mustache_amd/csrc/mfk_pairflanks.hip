@@ -609,10 +609,10 @@ extern "C" int mfk_pairflanks(mfk_ctx *ctx, const mfk_reads *reads, const mfk_pa
         PROF_LAUNCH(k_kept_keys, dim3(pb), dim3(256), 0, st, F, (const uint32_t *)order, (const uint32_t *)c5, (const uint32_t *)c3, (const uint8_t *)state, (const uint32_t *)kscan, nP, (const int32_t *)d_rank, kk, kv);
         KCHK();
         if (int rc = dev_sort_pairs64(ctx, kk, kk2, kv, kept, nP, 0, 64)) return rc;
-        PROF_LAUNCH(k_spanning, dim3(nP), dim3(1024), 0, st, R, P, F, (const uint32_t *)kept, (const uint32_t *)c5, (const uint32_t *)c3, nK_p, (const int32_t *)ir, spanning, jflag, d_pstats);
+        PROF_LAUNCH(k_spanning, dim3(nP), dim3(nP >= 2048 ? 256 : 1024), 0, st, R, P, F, (const uint32_t *)kept, (const uint32_t *)c5, (const uint32_t *)c3, nK_p, (const int32_t *)ir, spanning, jflag, d_pstats);
         KCHK();
         if (int rc = dev_excl_scan32(ctx, jflag, jscan, nP)) return rc;
-        PROF_LAUNCH(k_direct_repeats, dim3(nP), dim3(1024), 0, st, R, F, (const uint32_t *)kept, nK_p, (const uint32_t *)jflag, (const uint32_t *)jscan, (const uint32_t *)spanning,
+        PROF_LAUNCH(k_direct_repeats, dim3(nP), dim3(nP >= 2048 ? 256 : 1024), 0, st, R, F, (const uint32_t *)kept, nK_p, (const uint32_t *)jflag, (const uint32_t *)jscan, (const uint32_t *)spanning,
                     (const uint32_t *)c5, (const uint32_t *)c3, fin, fin_span, genome, (const int64_t *)d_goff, dr, stride, meta);
         KCHK();
         HIPCHK(hipEventRecord(ctx->ev1, st));

@@ -25,6 +25,7 @@ CONFIGS = {
     "C1_ecoli_100x": dict(contig_lens=(4_600_000,), coverage=100, n_insertions=20),
     "C2_saureus_1000x": dict(contig_lens=(2_800_000,), coverage=1000, n_insertions=20),
     "C3_klebsiella": dict(contig_lens=(5_300_000, 200_000, 120_000, 60_000, 9_000, 3_000), coverage=100, n_insertions=30),
+    "C5_tenth": dict(contig_lens=(5_000_000,), coverage=200, n_insertions=1_000),   # C5 at a tenth: quick to generate
     "C5_meta_50mb": dict(contig_lens=(50_000_000,), coverage=200, n_insertions=10_000),
 }
 
