@@ -150,6 +150,111 @@ __global__ __launch_bounds__(256) void k_clip_events(DevReads R, DevParams P, co
     for (uint32_t k = threadIdx.x; k < m; k += 256) if (s_base + k < cap) ev[s_base + k] = stage[k];
 }
 
+// ---- K1b: events straight into position buckets, sorted bucket by bucket in LDS ------------------------------------------
+// The event keys have to end up sorted by (gpos, side, read).  A device-wide sort of a few hundred thousand 64-bit keys is
+// ~17 short launches of rocPRIM's merge sort (100 us at C2, the largest single item of the step).  Instead the flat site
+// axis is cut into B equal position ranges ("buckets", B a power of two chosen from the read count so that a bucket holds
+// a few hundred keys); k_clip_events_bkt drops every key into its bucket (fixed capacity BKT_CAP, one returning atomic
+// per run of equal buckets inside a wave: the clips of a deep site arrive together and would otherwise queue on one
+// counter), and k_bucket_sort sorts each bucket in LDS (bitonic, one workgroup per bucket) and writes it at the prefix sum
+// of the bucket counts.  Buckets are monotone in gpos, so the concatenation is the sorted list.  A bucket that overflows
+// (a site deeper than BKT_CAP clips) makes the host fall back to the list + rocPRIM path: nothing is lost, only time.
+#define BKT_CAP 4096
+
+// where a lane's key goes inside its run of equal buckets: run = consecutive lanes with the same bucket; the run's first
+// lane reserves room for the whole run
+struct BktRun { int hl, len; bool head; };
+__device__ __forceinline__ BktRun d_bucket_run(bool has, uint32_t b, int lane) {
+    if (!has) b = 0xFFFFFFFFu;
+    const uint32_t prev = __shfl_up(b, 1, 64);
+    BktRun r;
+    r.head = has && (lane == 0 || prev != b);
+    const unsigned long long headmask = __ballot(r.head), hasmask = __ballot(has);
+    r.hl = 0; r.len = 0;
+    if (has) {
+        const unsigned long long below = headmask & ((2ull << lane) - 1ull);                // run heads at or below this lane
+        r.hl = 63 - __clzll((long long)below);
+        const unsigned long long breaks = (headmask | ~hasmask) & ~((2ull << r.hl) - 1ull);   // where the run ends
+        r.len = (breaks ? __ffsll((long long)breaks) - 1 : 64) - r.hl;
+    }
+    return r;
+}
+
+// same grid and per-read logic as k_clip_events
+__global__ __launch_bounds__(256) void k_clip_events_bkt(DevReads R, DevParams P, const uint64_t *list, const uint32_t *seg_count, uint32_t seg_cap,
+                                                         uint64_t *bkt, uint32_t *bkt_count, uint32_t B) {
+    const uint32_t cnt = seg_count[blockIdx.y * SEG_PAD];
+    const uint32_t n = cnt < seg_cap ? cnt : seg_cap;
+    list += (size_t)blockIdx.y * seg_cap;
+    const int lane = threadIdx.x & 63;
+    for (uint32_t b0 = blockIdx.x * 256; b0 < n; b0 += gridDim.x * 256) {   // block-uniform trip count
+        const uint32_t i = b0 + threadIdx.x;
+        uint64_t k5 = 0, k3 = 0;
+        bool h5 = false, h3 = false;
+        if (i < n) {
+            const uint64_t e = list[i];
+            const int64_t r = (int64_t)(e & 0x7fffffffu);
+            const uint8_t f = (uint8_t)(e >> 32);
+            const int lk = d_lkind(f), rk = d_rkind(f);
+            const bool both = lk && rk;
+            const int mq = R.mapq[r];
+            const int ql = both ? R.qlen[r] : 0, fo = both ? R.first_op_len[r] : 0, lo = both ? R.last_op_len[r] : 0;
+            const int32_t rs = lk ? R.ref_start[r] : 0, re = rk ? R.ref_end[r] : 0;
+            const uint32_t base = R.contig_base[R.contig_id[r]];
+            const int llen = lk == 1 ? fo : (lk == 2 ? 1 : 0), rlen = rk == 1 ? lo : (rk == 2 ? 1 : 0);
+            if (mq >= P.minq && !(both && ql - rlen - llen < P.minial)) {
+                if (rk) { const int32_t site = rk == 1 ? re : re - 1; k5 = ((uint64_t)(base + (uint32_t)(site + 1)) << 32) | (uint64_t)(uint32_t)r; h5 = true; }
+                if (lk) { const int32_t site = lk == 1 ? rs - 1 : rs; k3 = ((uint64_t)(base + (uint32_t)(site + 1)) << 32) | (1ull << 31) | (uint64_t)(uint32_t)r; h3 = true; }
+            }
+        }
+        // bucket = position range of the flat axis
+        uint32_t b5 = (uint32_t)(((k5 >> 32) * (uint64_t)B) / R.gpos_span), b3 = (uint32_t)(((k3 >> 32) * (uint64_t)B) / R.gpos_span);
+        if (b5 >= B) b5 = B - 1;
+        if (b3 >= B) b3 = B - 1;
+        // both reservations are issued before either result is needed: one atomic round trip per sweep, not two
+        const BktRun r5 = d_bucket_run(h5, b5, lane), r3 = d_bucket_run(h3, b3, lane);
+        uint32_t base5 = 0, base3 = 0;
+        if (r5.head) base5 = atomicAdd(&bkt_count[b5], (uint32_t)r5.len);
+        if (r3.head) base3 = atomicAdd(&bkt_count[b3], (uint32_t)r3.len);
+        base5 = __shfl(base5, r5.hl, 64);
+        base3 = __shfl(base3, r3.hl, 64);
+        if (h5) { const uint32_t slot = base5 + (uint32_t)(lane - r5.hl); if (slot < BKT_CAP) bkt[(size_t)b5 * BKT_CAP + slot] = k5; }
+        if (h3) { const uint32_t slot = base3 + (uint32_t)(lane - r3.hl); if (slot < BKT_CAP) bkt[(size_t)b3 * BKT_CAP + slot] = k3; }
+    }
+}
+
+// one workgroup per bucket: output offset = sum of the counts before it, bitonic sort in LDS, coalesced write
+#define BSORT_THREADS 1024
+__global__ __launch_bounds__(BSORT_THREADS) void k_bucket_sort(const uint64_t *bkt, const uint32_t *bkt_count, uint32_t B, uint64_t *out) {
+    __shared__ uint64_t keys[BKT_CAP];
+    __shared__ uint32_t red[BSORT_THREADS / 64];
+    const uint32_t b = blockIdx.x;
+    const uint32_t n = bkt_count[b];
+    if (n == 0 || n > BKT_CAP) return;   // block-uniform (an overflow never gets here: the host checks the counts first)
+    uint32_t part = 0;
+    for (uint32_t j = threadIdx.x; j < b; j += BSORT_THREADS) part += bkt_count[j];
+    for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = part;
+    uint32_t npad = 64;
+    while (npad < n) npad <<= 1;
+    const uint64_t *src = bkt + (size_t)b * BKT_CAP;
+    for (uint32_t i = threadIdx.x; i < npad; i += BSORT_THREADS) keys[i] = i < n ? src[i] : ~0ull;
+    __syncthreads();
+    uint32_t base = 0;
+    for (int w = 0; w < BSORT_THREADS / 64; w++) base += red[w];
+    for (uint32_t k = 2; k <= npad; k <<= 1)
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            for (uint32_t t = threadIdx.x; t < (npad >> 1); t += BSORT_THREADS) {
+                const uint32_t i = 2 * t - (t & (j - 1)), l = i + j;
+                const uint64_t x = keys[i], y = keys[l];
+                const bool up = (i & k) == 0;
+                if ((x > y) == up) { keys[i] = y; keys[l] = x; }
+            }
+            __syncthreads();
+        }
+    for (uint32_t i = threadIdx.x; i < n; i += BSORT_THREADS) out[base + i] = keys[i];
+}
+
 // ---- K2: per-event information ---------------------------------------------------------------------------------
 // info bits: 1 site head, 2 first read of its query name at this site-side, 4 meets_minlength, 8 side (0 = 5p, 1 = 3p)
 __global__ void k_event_info(DevReads R, DevParams P, const uint64_t *keys, uint32_t E, uint8_t *info, uint32_t *head) {
@@ -472,28 +577,49 @@ extern "C" int mfk_findflanks(mfk_ctx *ctx, const mfk_reads *reads, const mfk_pa
     if (nblk < 1) nblk = 1;
     uint32_t *d_stats = nullptr, *ev_count = nullptr;   // ev_count[0] events, [SEG_PAD * (1 + seg)] listed reads of a segment
     uint32_t E = 0;
-    uint64_t *ev = nullptr;
+    uint64_t *ev = nullptr, *bkt = nullptr;
+    uint32_t *bkt_count = nullptr;
     uint64_t cap64 = (uint64_t)R.n / 8 + 65536, seg_cap = cap64 / LIST_SEGS + 4096;   // clips are a few percent of the reads; grown on overflow
-    std::vector<uint32_t> h_cnt((size_t)SEG_PAD * (LIST_SEGS + 1));
-    for (int attempt = 0; attempt < 2; attempt++) {
+    std::vector<uint32_t> h_cnt((size_t)SEG_PAD * (LIST_SEGS + 1)), h_bkt;
+    // position buckets (K1b): about a thousand reads' worth of events per bucket, 64 .. 4096 buckets
+    uint32_t B = 64;
+    while (B < 4096 && (uint64_t)B * 16 * 1024 < (uint64_t)R.n) B <<= 1;
+    const char *nb_env = getenv("MFK_NO_BUCKET_SORT");
+    bool bucketed = !(nb_env && *nb_env && *nb_env != '0') && R.gpos_span > 0;
+    for (int attempt = 0; attempt < 3; attempt++) {
         if (cap64 > 2 * (uint64_t)R.n + 16) cap64 = 2 * (uint64_t)R.n + 16;
         if (cap64 > 0xFFFFFFF0ull || seg_cap > 0x7FFFFFF0ull) { snprintf(ctx->err, sizeof ctx->err, "more than 2^32 soft-clip events in one call"); return 1; }
-        ev = aalloc<uint64_t>(ctx, (size_t)cap64);
+        if (bucketed) bkt = aalloc<uint64_t>(ctx, (size_t)B * BKT_CAP);
+        else ev = aalloc<uint64_t>(ctx, (size_t)cap64);
         uint64_t *list = aalloc<uint64_t>(ctx, (size_t)seg_cap * LIST_SEGS);
-        if (!ev || !list) return 1;
+        if ((bucketed ? !bkt : !ev) || !list) return 1;
         FillGroup z(ctx, 0);
         z.want(&d_stats, MFK_N_STATS); z.want(&ev_count, h_cnt.size());
+        if (bucketed) z.want(&bkt_count, B);
         if (z.commit()) return 1;
         PROF_LAUNCH(k_scan_clips, dim3(nblk), dim3(SCAN_THREADS), 0, st, R, list, ev_count + SEG_PAD, (uint32_t)seg_cap);
         KCHK();
-        PROF_LAUNCH(k_clip_events, dim3(8, LIST_SEGS), dim3(256), 0, st, R, P, (const uint64_t *)list, (const uint32_t *)(ev_count + SEG_PAD), (uint32_t)seg_cap, ev, ev_count, (uint32_t)cap64);
+        if (bucketed) {
+            PROF_LAUNCH(k_clip_events_bkt, dim3(16, LIST_SEGS), dim3(256), 0, st, R, P, (const uint64_t *)list, (const uint32_t *)(ev_count + SEG_PAD), (uint32_t)seg_cap, bkt, bkt_count, B);
+        } else {
+            PROF_LAUNCH(k_clip_events, dim3(8, LIST_SEGS), dim3(256), 0, st, R, P, (const uint64_t *)list, (const uint32_t *)(ev_count + SEG_PAD), (uint32_t)seg_cap, ev, ev_count, (uint32_t)cap64);
+        }
         KCHK();
-        if (int rc = read_back(ctx, ev_count, h_cnt.data(), h_cnt.size() * 4)) return rc;
-        E = h_cnt[0];
-        uint64_t seg_max = 0, listed = 0;
+        {
+            ReadBatch rb(ctx);
+            rb.add(ev_count, h_cnt.data(), h_cnt.size() * 4);
+            if (bucketed) { h_bkt.resize(B); rb.add(bkt_count, h_bkt.data(), (size_t)B * 4); }
+            if (int rc = rb.flush()) return rc;
+        }
+        uint64_t seg_max = 0, listed = 0, bmax = 0, bsum = 0;
         for (int sgi = 0; sgi < LIST_SEGS; sgi++) { uint64_t c = h_cnt[(size_t)SEG_PAD * (1 + sgi)]; listed += c; if (c > seg_max) seg_max = c; }
-        if (seg_max <= seg_cap && (uint64_t)E <= cap64) break;
+        if (bucketed) { for (uint32_t c : h_bkt) { bsum += c; if (c > bmax) bmax = c; } }
+        if (bsum > 0xFFFFFFF0ull) { snprintf(ctx->err, sizeof ctx->err, "more than 2^32 soft-clip events in one call"); return 1; }
+        E = bucketed ? (uint32_t)bsum : h_cnt[0];
+        if (seg_max <= seg_cap && (bucketed ? bmax <= BKT_CAP : (uint64_t)E <= cap64)) break;
+        if (attempt == 2) { snprintf(ctx->err, sizeof ctx->err, "soft-clip event buffers still too small after two retries"); return 1; }
         if (seg_max > seg_cap) { seg_cap = seg_max + 16; if (cap64 < 2 * listed + 16) cap64 = 2 * listed + 16; }   // every read was counted: exact sizes
+        else if (bucketed) { bucketed = false; if (cap64 < 2 * listed + 16) cap64 = 2 * listed + 16; }               // a site deeper than a bucket: list + device-wide sort
         else cap64 = (uint64_t)E + 16;                                                                            // every event was counted
     }
     ctx->stats[10] = E;
@@ -506,7 +632,10 @@ extern "C" int mfk_findflanks(mfk_ctx *ctx, const mfk_reads *reads, const mfk_pa
     if (E > 0) {
         ev_sorted = aalloc<uint64_t>(ctx, E);
         if (!ev_sorted) return 1;
-        if (int rc = dev_sort_keys64(ctx, ev, ev_sorted, E, 0, 64)) return rc;
+        if (bucketed) {
+            PROF_LAUNCH(k_bucket_sort, dim3(B), dim3(BSORT_THREADS), 0, st, (const uint64_t *)bkt, (const uint32_t *)bkt_count, B, ev_sorted);
+            KCHK();
+        } else if (int rc = dev_sort_keys64(ctx, ev, ev_sorted, E, 0, 64)) return rc;
         ev_info = aalloc<uint8_t>(ctx, E);
         uint32_t *head = aalloc<uint32_t>(ctx, E), *head_scan = aalloc<uint32_t>(ctx, (size_t)E + 1);
         T.gpos = aalloc<uint32_t>(ctx, E); T.contig = aalloc<int32_t>(ctx, E);

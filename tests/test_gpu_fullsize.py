@@ -31,9 +31,13 @@ def _same(a, b, dtype, skip=()):
             assert np.array_equal(a[n], b[n]), n
 
 
-@pytest.mark.parametrize("name,seed", [("tiny", 3), ("C3_klebsiella", 4), ("C1_ecoli_100x", 5), ("C2_saureus_1000x", 6)])
+DEEP = dict(contig_lens=(20_000,), coverage=6000, n_insertions=1)   # one site with more clips than a position bucket holds
+
+
+@pytest.mark.parametrize("name,seed", [("tiny", 3), ("C3_klebsiella", 4), ("C1_ecoli_100x", 5), ("C2_saureus_1000x", 6),
+                                       ("C5_tenth", 7), ("deep", 8)])
 def test_fullsize_matches_oracle(hip, oracle, name, seed):
-    packed, genome, truth = synth_packed(**CONFIGS[name], seed=seed)
+    packed, genome, truth = synth_packed(**(DEEP if name == "deep" else CONFIGS[name]), seed=seed)
     ff, pf, off, opf = _both(hip, oracle, packed, genome)
     _same(ff["flanks"], off["flanks"], lib.FLANK_DTYPE)
     assert ff["seqs"] == off["seqs"]
@@ -58,3 +62,15 @@ def test_idempotent_and_order_independent_of_pool_extras(hip):
     a = hip.run_findflanks(rd, lib.make_params())
     b = hip.run_findflanks(rd, lib.make_params())
     assert a["seqs"] == b["seqs"] and a["flanks"].tobytes() == b["flanks"].tobytes()
+
+
+def test_list_and_device_sort_path_gives_the_same_bytes(hip, monkeypatch):
+    """The event keys reach their sorted order through position buckets (LDS sorts) or, when a bucket would overflow,
+    through the list + rocPRIM sort: both paths must agree byte for byte."""
+    packed, genome, _ = synth_packed(**CONFIGS["tiny"], seed=11)
+    rd = device_reads(hip, packed, "cuda:0")
+    a = hip.run_findflanks(rd, lib.make_params())
+    monkeypatch.setenv("MFK_NO_BUCKET_SORT", "1")
+    b = hip.run_findflanks(rd, lib.make_params())
+    assert a["seqs"] == b["seqs"] and a["flanks"].tobytes() == b["flanks"].tobytes() and a["sites"].tobytes() == b["sites"].tobytes()
+    assert list(a["stats"]) == list(b["stats"]) and len(a["flanks"]) > 0
