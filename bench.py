@@ -34,8 +34,11 @@ def algorithmic_bytes(kernel, meta):
         return listed * (8 + 7) + ev * 8       # list entry + mapq, contig_id, one position column (7 B) + one key per event
     if kernel == "k_classify":
         return meta["join_visits"] * 13        # ref_start, ref_end (8 B) + mapq, flags, link (5 B) per (site, read) visit
-    if kernel.startswith("rocprim::radix_sort_keys"):
+    if kernel.startswith("rocprim::radix_sort_keys") or kernel == "k_bucket_sort":
         return ev * 8 * 2                      # a sort has to read and write every key once
+    if kernel == "k_direct_repeats":
+        # (150 x 1.5 + 8) B per read over a pair's 50-bp window; a window of W bp at coverage c sees c (150 + W) / 150 reads
+        return int(meta["pairs"] * meta["coverage"] * (150 + 50) / 150 * (150 * 1.5 + 8))
     if kernel == "k_event_info":
         return ev * (8 + 4 + 2 + 1 + 4)        # key, link, contig_id, info out, head out
     return None
@@ -106,11 +109,12 @@ def main():
     for _ in range(warm_calls):
         ff, pf = step()
     full = hip.profile_totals()
-    watched = ["k_scan_clips", "k_clip_events"]
+    scan_kernels = ["k_scan_clips", "k_clip_events_bkt", "k_clip_events"]   # _bkt: bucketed path; plain: list + rocPRIM sort fallback
+    watched = list(scan_kernels)
     if full:
         watched.insert(0, max(full.items(), key=lambda kv: kv[1][0])[0])
     else:                                   # --warmup 0: no ranking yet, watch the usual suspects
-        watched = ["rocprim::radix_sort_keys"] + watched
+        watched = ["k_direct_repeats"] + watched
 
     def barrier():
         if world > 1:
@@ -144,7 +148,8 @@ def main():
         flags = packed.flags
         meta = {"n_reads": packed.n_reads, "clipped_reads": int(((flags & 15) != 0).sum()),
                 "events": int(ff["stats"][10]),
-                "join_visits": int(ff["stats"][3]) * 3 * int(CONFIGS[args.config]["coverage"])}
+                "join_visits": int(ff["stats"][3]) * 3 * int(CONFIGS[args.config]["coverage"]),
+                "pairs": int(pf["stats"][1]), "coverage": int(CONFIGS[args.config]["coverage"])}
         # per-kernel rows (name, avg ms per launch, launches, total ms).  Shares and the device total come from the fully
         # bracketed warm-up steps; the durations of the watched kernels come from the timed region.
         full_table = sorted(((nm, ms / max(calls, 1), calls, ms) for nm, (ms, calls) in full.items()), key=lambda r: -r[3])
@@ -155,7 +160,7 @@ def main():
         roofline = None
         if table:
             def entry(names):
-                rows = [r for r in table if any(r[0].startswith(nm) for nm in names)]
+                rows = [r for r in table if r[0] in names]
                 if not rows:
                     return None
                 ms = sum(r[1] for r in rows)                       # one launch of each per step
@@ -171,11 +176,12 @@ def main():
                 e["traffic"] = sum(tr) if all(t is not None for t in tr) else None
                 return e
 
-            # dominant kernel = largest share of device time.  No kernel dominates this path at C2 (the largest is ~9 % of
-            # the device time, the step is a chain of ~70 short launches), so the read scan -- the two kernels that touch
+            # dominant kernel = largest share of device time.  No kernel dominates this path at C2 (the largest is ~8 % of
+            # the device time, the step is a chain of ~70 short launches, and the largest ones are per-pair / per-cluster
+            # latency chains without a streaming model: achieved = null for those), so the read scan -- the two kernels that touch
             # every read and carry the path's algorithmic bytes -- is reported beside it.
             roofline = entry([table[0][0]])
-            roofline["read_scan"] = entry(["k_scan_clips", "k_clip_events"])
+            roofline["read_scan"] = entry(scan_kernels)
             roofline["top5_by_time"] = [{"kernel": r[0], "avg_ms": round(r[1], 5), "launches_per_step": r[2] // warm_calls,
                                          "share": round(share[r[0]], 3)} for r in full_table[:5]]
         if args.dump_profile:

@@ -196,6 +196,33 @@ int mfk_recall(mfk_ctx *ctx, const mfk_reads *reads, const mfk_params *params, c
  * An empty sequence is the reference's IndexError: return code 7. */
 int mfk_overlap(mfk_ctx *ctx, const char *seqs5, const int64_t *off5, const char *seqs3, const int64_t *off3, int64_t n, int32_t *out);
 
+/* inferseq-reference / inferseq-assembly: pairing of the flank alignments (replaces what InferSequence does after the
+ * aligner has run: __prefilter_reads inferseq.py:103-126, AlignedPairs.add_read / match_forward_reverse 214-290,
+ * filter_smallest_overlapping 321-362, filter_pairs_max_internal_softclip_prop 364-380, filter_best_alignments 305-318,
+ * filter_pairs_size 382-390, in the order of infer_sequences 50-70).  The aligner (bowtie2 --local --all) stays
+ * external, as in the reference.  One record per alignment of a flank, HOST array in BAM order: */
+typedef struct mfk_aln {
+    int32_t group;                 /* dense id of query_name.split('_')[0] (the pair)                    */
+    int32_t name;                  /* dense id of the whole query_name                                   */
+    int32_t mate;                  /* 1 if query_name.split('_')[-1] == '1', else 2                      */
+    int32_t is_reverse;
+    int32_t contig_id;
+    int32_t ref_start, ref_end;
+    int32_t contig_len;            /* len(genome_dict[reference_name]) (inferseq.py:38, 121)             */
+    int32_t qlen;                  /* len(query_sequence)                                                */
+    int32_t left_clip, right_clip; /* CIGAR S length at that end, 0 if none (sctools.py:57-67, 78-97)     */
+    int32_t aln_len;               /* query_alignment_length                                             */
+    int32_t nm, as;                /* NM and AS tags                                                     */
+} mfk_aln;
+/* *n_pairs = surviving (forward, reverse) alignment pairs; fetch gives their indices into alns, ordered by group and,
+ * inside a group, by creation order (forward reads of mate 1, of mate 2, then reverse reads of mate 1, of mate 2, each
+ * in BAM order).  Two behaviours of the reference depend on set iteration order; the build fixes them: duplicates keep
+ * the pair created first, ties of get_smallest_window_pair go to the pair created first.  A read with
+ * aln_len == 0 is the reference's ZeroDivisionError: return code 7. */
+int mfk_inferseq_pairs(mfk_ctx *ctx, const mfk_aln *alns, int64_t n, double min_perc_identity, double max_internal_softclip_prop,
+                       int64_t max_inferseq_size, int64_t min_inferseq_size, int64_t *n_pairs);
+int mfk_inferseq_pairs_fetch(mfk_ctx *ctx, int32_t *forward, int32_t *reverse);
+
 /* time spent in device work of the last compute call, milliseconds (HIP events on the ctx stream) */
 double mfk_last_device_ms(mfk_ctx *ctx);
 

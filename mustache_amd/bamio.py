@@ -71,26 +71,29 @@ class BamReader:
             if l_seq and quals[0] == 0xFF:
                 quals = None
             o += l_seq
-            md = _find_md(buf, o)
+            tags = _parse_tags(buf, o)
             cigartuples = [(c & 15, c >> 4) for c in cig] if (n_cig and not flag & 4 and ref_id >= 0) else None
             yield AlignedRead(qname, names[ref_id] if ref_id >= 0 else None, pos, mapq, cigartuples, seq, quals,
-                              md=md, flag=flag, reference_id=ref_id)
+                              flag=flag, reference_id=ref_id, tags=tags)
 
 
-_TAG_SIZE = {b"A": 1, b"c": 1, b"C": 1, b"s": 2, b"S": 2, b"i": 4, b"I": 4, b"f": 4}
+_TAG_FMT = {b"A": "<c", b"c": "<b", b"C": "<B", b"s": "<h", b"S": "<H", b"i": "<i", b"I": "<I", b"f": "<f"}
+_TAG_SIZE = {k: struct.calcsize(v) for k, v in _TAG_FMT.items()}
 
 
-def _find_md(buf, o):
-    n = len(buf)
+def _parse_tags(buf, o):
+    """Optional fields of a record -> dict (integers, floats, characters and strings; arrays are skipped)."""
+    n, out = len(buf), {}
     while o + 3 <= n:
-        tag, typ = buf[o:o + 2], buf[o + 2:o + 3]
+        tag, typ = buf[o:o + 2].decode("ascii", "replace"), buf[o + 2:o + 3]
         o += 3
-        if typ in _TAG_SIZE:
+        if typ in _TAG_FMT:
+            v, = struct.unpack_from(_TAG_FMT[typ], buf, o)
+            out[tag] = v.decode("ascii", "replace") if typ == b"A" else v
             o += _TAG_SIZE[typ]
         elif typ in (b"Z", b"H"):
             e = buf.index(b"\0", o)
-            if tag == b"MD":
-                return buf[o:e].decode()
+            out[tag] = buf[o:e].decode()
             o = e + 1
         elif typ == b"B":
             sub = buf[o:o + 1]
@@ -98,7 +101,7 @@ def _find_md(buf, o):
             o += 5 + cnt * _TAG_SIZE[sub]
         else:
             raise ValueError("bad BAM tag type %r" % typ)
-    return None
+    return out
 
 
 def _reg2bin(beg, end):

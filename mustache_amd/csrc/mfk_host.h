@@ -41,6 +41,7 @@ struct mfk_ctx {
     std::vector<mfk_pair> pairs;
     std::string strs;
     int64_t pstats[MFK_N_STATS];
+    std::vector<int32_t> isq_f, isq_r;   // inferseq pairing result (mfk_inferseq_pairs)
     std::vector<int32_t> ir_ov;     // external inverted-repeat table for the next pairflanks call: rows i5 i3 has a1s a1e a2s a2e, sorted
 };
 

@@ -56,7 +56,11 @@ PAIR_DTYPE = np.dtype([(n, np.int32) for n in (
     "total_count_5p", "total_count_3p", "spanning_count", "has_ir", "ir_length", "ir5_len", "ir3_len", "dr_len",
     "dr_ref_len")] + [(n, np.int64) for n in ("ir5_off", "ir3_off", "dr_ref_off", "dr_reads_off")])
 
-assert SITE_DTYPE.itemsize == 56 and FLANK_DTYPE.itemsize == 72 and PAIR_DTYPE.itemsize == 96
+ALN_DTYPE = np.dtype([(n, np.int32) for n in (
+    "group", "name", "mate", "is_reverse", "contig_id", "ref_start", "ref_end", "contig_len", "qlen", "left_clip",
+    "right_clip", "aln_len", "nm", "as")])
+
+assert ALN_DTYPE.itemsize == 56 and SITE_DTYPE.itemsize == 56 and FLANK_DTYPE.itemsize == 72 and PAIR_DTYPE.itemsize == 96
 
 # CLI defaults are authoritative (reference main.py:68-78, 102-107), not the class defaults
 RECALL_COUNTS = ("softclip_count_5p", "softclip_count_3p", "runthrough_count", "small_insertion_count_5p",
@@ -116,6 +120,8 @@ class Binding:
         f("recall", C.c_int, [_p, C.POINTER(MfkReads), C.POINTER(MfkParams), _p, _p, C.c_int64, _p])
         f("overlap", C.c_int, [_p, _p, _p, _p, _p, C.c_int64, _p])
         f("pairflanks_set_ir", C.c_int, [_p, C.c_int64, _p, _p, _p])
+        f("inferseq_pairs", C.c_int, [_p, _p, C.c_int64, C.c_double, C.c_double, C.c_int64, C.c_int64, C.POINTER(C.c_int64)])
+        f("inferseq_pairs_fetch", C.c_int, [_p, _p, _p])
         if hasattr(self.so, prefix + "profile_enable"):
             f("profile_enable", C.c_int, [_p, C.c_int])
             f("profile_fetch", C.c_int, [_p, _p, C.c_int64, _p, _p, C.c_int64, C.POINTER(C.c_int64)])
@@ -236,6 +242,17 @@ class Binding:
         self._check(self.overlap(self.ctx, b5.ctypes.data, o5.ctypes.data, b3.ctypes.data, o3.ctypes.data, len(seqs5),
                                  out.ctypes.data))
         return out
+
+    def run_inferseq_pairs(self, alns, min_perc_identity, max_internal_softclip_prop, max_inferseq_size, min_inferseq_size):
+        """alns: ALN_DTYPE array in BAM order -> (forward, reverse) int32 index arrays of the surviving pairs."""
+        a = np.ascontiguousarray(alns, dtype=ALN_DTYPE)
+        n = C.c_int64(0)
+        self._check(self.inferseq_pairs(self.ctx, a.ctypes.data, a.shape[0], float(min_perc_identity),
+                                        float(max_internal_softclip_prop), int(max_inferseq_size), int(min_inferseq_size),
+                                        C.byref(n)))
+        fwd, rev = np.zeros(max(n.value, 1), dtype=np.int32), np.zeros(max(n.value, 1), dtype=np.int32)
+        self._check(self.inferseq_pairs_fetch(self.ctx, fwd.ctypes.data, rev.ctypes.data))
+        return fwd[:n.value], rev[:n.value]
 
     def profile(self, on=True):
         """Start (and clear) or stop per-kernel HIP-event timing of the compute calls."""

@@ -117,5 +117,30 @@ def inferseq_overlap(pairsfile, min_overlap_score, min_overlap_perc_identity, mi
     _inferseq_overlap(pairsfile, min_overlap_score, min_overlap_perc_identity, min_inferseq_size, output_file, device=device)
 
 
+@cli.command(name="inferseq-reference", short_help="Infers the identity of an inserted sequence by aligning flank pairs to a reference genome.")
+@click.argument("pairsfile", type=click.Path(exists=True))
+@click.argument("inferseq_reference", type=click.Path(exists=True))
+@click.option("--min_perc_identity", "-minident", default=0.95)
+@click.option("--max_internal_softclip_prop", "-maxclip", default=0.05)
+@click.option("--max_inferseq_size", "-maxsize", default=200000)
+@click.option("--min_inferseq_size", "-minsize", default=30)
+@click.option("--keep-intermediate/--no-keep-intermediate", default=False)
+@click.option("--output_file", "-o", default="mustache.inferseq_reference.tsv")
+@click.option("--device", default="cuda:0", help="GPU to run on (not in the reference).")
+@click.option("--alignments-bam", "alignments_bam", type=click.Path(exists=True), default=None,
+              help="Flank alignments made beforehand (bowtie2 --local --all, NM and AS tags) instead of running bowtie2 "
+                   "here (not in the reference).")
+def inferseq_reference(pairsfile, inferseq_reference, min_perc_identity, max_internal_softclip_prop, max_inferseq_size,
+                       min_inferseq_size, keep_intermediate, output_file, device, alignments_bam):
+    """reference main.py:143-164"""
+    from .inferseq import _inferseq_reference
+    log_params(command="inferseq_reference", pairsfile=pairsfile, inferseq_reference=inferseq_reference,
+               min_perc_identity=min_perc_identity, max_internal_softclip_prop=max_internal_softclip_prop,
+               max_inferseq_size=max_inferseq_size, min_inferseq_size=min_inferseq_size,
+               keep_intermediate=keep_intermediate, output_file=output_file)
+    _inferseq_reference(pairsfile, inferseq_reference, min_perc_identity, max_internal_softclip_prop, max_inferseq_size,
+                        min_inferseq_size, keep_intermediate, output_file, device=device, alignments_bam=alignments_bam)
+
+
 if __name__ == "__main__":
     cli()

@@ -73,6 +73,26 @@ class AlignedRead:
         return self._reference_end
 
     @property
+    def is_reverse(self):
+        return bool(self.flag & 16)
+
+    @property
+    def query_alignment_length(self):
+        """Query bases inside the alignment: the sequence without its soft-clipped ends (pysam semantics)."""
+        n = len(self.query_sequence or "")
+        ct = self.cigartuples or []
+        lo, hi = 0, len(ct)
+        while lo < hi and ct[lo][0] == CHARD_CLIP:
+            lo += 1
+        while hi > lo and ct[hi - 1][0] == CHARD_CLIP:
+            hi -= 1
+        if lo < hi and ct[lo][0] == CSOFT_CLIP:
+            n -= ct[lo][1]
+        if hi - lo > 1 and ct[hi - 1][0] == CSOFT_CLIP:
+            n -= ct[hi - 1][1]
+        return n
+
+    @property
     def cigarstring(self):
         return cigar_to_string(self.cigartuples)
 

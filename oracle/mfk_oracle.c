@@ -146,6 +146,7 @@ typedef struct {
     mfk_flank *flanks; int64_t n_flanks; char *seqs; int64_t seq_bytes;
     mfk_pair *pairs; int64_t n_pairs; char *strs; int64_t str_bytes;
     int64_t pstats[MFK_N_STATS];
+    int32_t *isq_f, *isq_r; int64_t n_isq;   /* result of the last mfko_inferseq_pairs */
     int32_t *ir_ov; int64_t n_ir_ov;   /* external inverted-repeat table for the next pairflanks call: i5 i3 has a1s a1e a2s a2e */
     char err[512];
 } octx;
@@ -939,6 +940,132 @@ int mfko_overlap(void *c, const char *seqs5, const int64_t *off5, const char *se
         int32_t *o = out + 6 * k;
         o[0] = (int32_t)best_score; o[1] = (int32_t)best_mm; o[2] = (int32_t)best_rs; o[3] = (int32_t)best_re; o[4] = (int32_t)best_qs; o[5] = (int32_t)best_qe;
     }
+    return 0;
+}
+
+/* ---- inferseq: pairing of flank alignments, inferseq.py:50-70 with AlignedPairs 185-395, written the way the reference
+ * does it: four lists and four "position -> read" maps per pair id, sorted position lists with strict neighbours, a list
+ * of pairs that is filtered four times.  Set-iteration order of the reference is replaced by creation order. ---- */
+typedef struct { int32_t contig, pos, read; } posmap_t;          /* dict[reference_name][position] = read (last one wins) */
+static void pm_set(posmap_t **m, int *n, int32_t contig, int32_t pos, int32_t read) {
+    for (int i = 0; i < *n; i++) if ((*m)[i].contig == contig && (*m)[i].pos == pos) { (*m)[i].read = read; return; }
+    *m = (posmap_t *)realloc(*m, (size_t)(*n + 1) * sizeof(posmap_t));
+    (*m)[*n].contig = contig; (*m)[*n].pos = pos; (*m)[*n].read = read; (*n)++;
+}
+/* misc.takeClosestLarger / takeClosestSmaller over the keys of one contig: smallest key > x / largest key < x */
+static int32_t pm_closest(const posmap_t *m, int n, int32_t contig, int32_t x, int larger) {
+    int32_t best = -1, bestpos = 0;
+    for (int i = 0; i < n; i++) {
+        if (m[i].contig != contig) continue;
+        if (larger ? m[i].pos <= x : m[i].pos >= x) continue;
+        if (best < 0 || (larger ? m[i].pos < bestpos : m[i].pos > bestpos)) { best = m[i].read; bestpos = m[i].pos; }
+    }
+    return best;
+}
+typedef struct { int32_t f, r; int alive; } ipair_t;
+
+int mfko_inferseq_pairs(void *c, const mfk_aln *A, int64_t n, double min_perc_identity, double max_internal_softclip_prop,
+                        int64_t max_size, int64_t min_size, int64_t *n_pairs) {
+    octx *C = (octx *)c;
+    if (!C || n < 0 || !n_pairs) return 1;
+    C->err[0] = 0;
+    free(C->isq_f); free(C->isq_r); C->isq_f = C->isq_r = NULL; C->n_isq = 0;
+    *n_pairs = 0;
+    if (n == 0) return 0;
+    int32_t n_groups = 0;
+    for (int64_t i = 0; i < n; i++) if (A[i].group + 1 > n_groups) n_groups = A[i].group + 1;
+    char *keep = (char *)calloc((size_t)n, 1);
+    /* __prefilter_reads inferseq.py:103-126 */
+    for (int64_t i = 0; i < n; i++) {
+        if (A[i].aln_len == 0) { snprintf(C->err, sizeof C->err, "ZeroDivisionError: alignment %lld has query_alignment_length 0 (pysamtools.py:176)", (long long)i); free(keep); return 7; }
+        double identity = (double)(A[i].aln_len - A[i].nm) / (double)A[i].aln_len;
+        if (identity < min_perc_identity) continue;
+        if (!A[i].is_reverse) { if (A[i].left_clip > 0 && A[i].left_clip > 1 && A[i].ref_start - 1 >= 0) continue; }
+        else { if (A[i].right_clip > 0 && A[i].right_clip > 1 && A[i].ref_end < A[i].contig_len) continue; }
+        keep[i] = 1;
+    }
+    C->isq_f = (int32_t *)malloc((size_t)(2 * n + 1) * sizeof(int32_t)); C->isq_r = (int32_t *)malloc((size_t)(2 * n + 1) * sizeof(int32_t));
+    for (int32_t g = 0; g < n_groups; g++) {
+        /* add_read 214-230: lists in BAM order + position maps */
+        ivec lists[4] = {{0}}; posmap_t *maps[4] = {0}; int nmap[4] = {0};   /* 0 fwd mate1, 1 fwd mate2, 2 rev mate1, 3 rev mate2 */
+        for (int64_t i = 0; i < n; i++) {
+            if (A[i].group != g || !keep[i]) continue;
+            int k = (A[i].is_reverse ? 2 : 0) + (A[i].mate == 1 ? 0 : 1);
+            iv_push(&lists[k], (int32_t)i);
+            pm_set(&maps[k], &nmap[k], A[i].contig_id, A[i].is_reverse ? A[i].ref_end : A[i].ref_start, (int32_t)i);
+        }
+        /* match_forward_reverse 232-256 */
+        ipair_t *P = (ipair_t *)malloc((size_t)(lists[0].n + lists[1].n + lists[2].n + lists[3].n + 1) * sizeof(ipair_t));
+        int np = 0;
+        for (int k = 0; k < 4; k++)
+            for (int64_t t = 0; t < lists[k].n; t++) {
+                int32_t rd = lists[k].v[t], f, r;
+                if (k < 2) {   /* forward read: closest reverse read of the other mate, 258-272 */
+                    int other = A[rd].mate == 1 ? 3 : 2;
+                    r = pm_closest(maps[other], nmap[other], A[rd].contig_id, A[rd].ref_start, 1); f = rd;
+                } else {       /* reverse read: closest forward read of the other mate, 275-289 */
+                    int other = A[rd].mate == 1 ? 1 : 0;
+                    f = pm_closest(maps[other], nmap[other], A[rd].contig_id, A[rd].ref_end, 0); r = rd;
+                }
+                if (f < 0 || r < 0) continue;
+                int dup = 0;   /* the `added` set of name tuples */
+                for (int q = 0; q < np && !dup; q++)
+                    dup = A[P[q].f].name == A[f].name && A[P[q].f].contig_id == A[f].contig_id && A[P[q].f].ref_start == A[f].ref_start && A[P[q].f].ref_end == A[f].ref_end &&
+                          A[P[q].r].name == A[r].name && A[P[q].r].contig_id == A[r].contig_id && A[P[q].r].ref_start == A[r].ref_start && A[P[q].r].ref_end == A[r].ref_end;
+                if (!dup) { P[np].f = f; P[np].r = r; P[np].alive = 1; np++; }
+            }
+        /* filter_smallest_overlapping 321-362 */
+        char *kp = (char *)calloc((size_t)np + 1, 1);
+        for (int p = 0; p < np; p++) {
+            int nf = 0, nr = 0;
+            for (int q = 0; q < np; q++) {
+                if (A[P[q].f].name == A[P[p].f].name && A[P[q].f].ref_start == A[P[p].f].ref_start) nf++;
+                if (A[P[q].r].name == A[P[p].r].name && A[P[q].r].ref_end == A[P[p].r].ref_end) nr++;
+            }
+            if (nf == 1 && nr == 1) { kp[p] = 1; continue; }
+            int best = -1; int64_t bl = 0;
+            for (int q = 0; q < np; q++) {
+                int inf = A[P[q].f].name == A[P[p].f].name && A[P[q].f].ref_start == A[P[p].f].ref_start;
+                int inr = A[P[q].r].name == A[P[p].r].name && A[P[q].r].ref_end == A[P[p].r].ref_end;
+                int in = (nf > 1 && nr == 1) ? inf : (nf == 1 && nr > 1) ? inr : (inf || inr);
+                if (!in) continue;
+                int64_t len = (int64_t)A[P[q].r].ref_end - A[P[q].f].ref_start;
+                if (best < 0 || len < bl) { best = q; bl = len; }
+            }
+            if (best >= 0) kp[best] = 1;
+        }
+        for (int p = 0; p < np; p++) P[p].alive = kp[p];
+        free(kp);
+        /* filter_pairs_max_internal_softclip_prop 364-380 */
+        for (int p = 0; p < np; p++) {
+            if (!P[p].alive) continue;
+            const mfk_aln *f = &A[P[p].f], *r = &A[P[p].r];
+            if (f->right_clip > 0 && f->ref_end < r->ref_end && (double)f->right_clip / (double)f->qlen > max_internal_softclip_prop) P[p].alive = 0;
+            else if (r->left_clip > 0 && r->ref_start > f->ref_start && (double)r->left_clip / (double)r->qlen > max_internal_softclip_prop) P[p].alive = 0;
+        }
+        /* filter_best_alignments 305-318 */
+        int64_t best_as = INT64_MIN;
+        for (int p = 0; p < np; p++) if (P[p].alive) { int64_t s = (int64_t)A[P[p].f].as + A[P[p].r].as; if (s > best_as) best_as = s; }
+        for (int p = 0; p < np; p++) if (P[p].alive && (int64_t)A[P[p].f].as + A[P[p].r].as != best_as) P[p].alive = 0;
+        /* filter_pairs_size 382-390 */
+        for (int p = 0; p < np; p++) {
+            if (!P[p].alive) continue;
+            int64_t len = (int64_t)A[P[p].r].ref_end - A[P[p].f].ref_start;
+            if (len < min_size || len > max_size) P[p].alive = 0;
+        }
+        for (int p = 0; p < np; p++) if (P[p].alive) { C->isq_f[C->n_isq] = P[p].f; C->isq_r[C->n_isq] = P[p].r; C->n_isq++; }
+        free(P);
+        for (int k = 0; k < 4; k++) { iv_free(&lists[k]); free(maps[k]); }
+    }
+    free(keep);
+    *n_pairs = C->n_isq;
+    return 0;
+}
+
+int mfko_inferseq_pairs_fetch(void *c, int32_t *forward, int32_t *reverse) {
+    octx *C = (octx *)c;
+    if (!C) return 1;
+    if (C->n_isq) { memcpy(forward, C->isq_f, (size_t)C->n_isq * sizeof(int32_t)); memcpy(reverse, C->isq_r, (size_t)C->n_isq * sizeof(int32_t)); }
     return 0;
 }
 

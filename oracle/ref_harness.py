@@ -217,3 +217,44 @@ def reference_modules():
     install_stubs()
     from mustache import sctools, misc, flanktrie, pysamtools
     return sctools, misc, flanktrie, pysamtools
+
+
+def run_inferseq(pairs, genome, reads, min_perc_identity=0.95, max_internal_softclip_prop=0.05, max_inferseq_size=200000,
+                 min_inferseq_size=30, method_name="inferred_reference", shuffle_seed=None):
+    """Run the reference's InferSequence (inferseq.py:16-183) on given flank alignments: everything infer_sequences
+    (50-70) does AFTER the external aligner has run.  ``reads`` stand in for the aligner's BAM (bowtie2 is not in this
+    image); the calls below are the body of infer_sequences from line 56 on, private names spelled out.
+    Returns the TSV text of the frame make_dataframe builds.
+
+    ``shuffle_seed``: the reference keeps its candidate pairs in ``set``s of objects that hash by address, so where two
+    candidates tie (get_smallest_window_pair, inferseq.py:355-362) its result depends on memory layout.  With a seed the
+    pair objects get random hashes for this run (a class attribute set at run time, nothing in the reference's files is
+    touched): a result that changes with the seed is order dependent and no use as a golden vector."""
+    install_stubs()
+    import random
+    from mustache import inferseq as _m
+    from mustache.inferseq import InferSequence
+    if shuffle_seed is not None:
+        rnd, cache = random.Random(shuffle_seed), {}
+        _m.AlignedPair.__hash__ = lambda self: cache.setdefault(id(self), rnd.getrandbits(60))
+    gkey = "__genome_%d.fa" % id(genome)
+    _registry["genome"][gkey] = genome
+    try:
+        inf = InferSequence(pairs, gkey, min_perc_identity, max_internal_softclip_prop, max_inferseq_size,
+                            min_inferseq_size, True, method_name, "/tmp")
+        inf.bam = list(reads)
+        inf._InferSequence__prefilter_reads()
+        for read in inf.bam:
+            name = read.query_name.split("_")[0]
+            inf.all_aligned_pairs[name].add_read(read)
+        inf._InferSequence__match_forward_reverse_reads()
+        inf._InferSequence__filter_smallest_overlapping()
+        inf._InferSequence__filter_pairs_max_internal_softclip_prop()
+        inf._InferSequence__filter_best_alignments()
+        inf._InferSequence__filter_pairs_size()
+        df = inf.make_dataframe()
+    finally:
+        del _registry["genome"][gkey]
+        if shuffle_seed is not None:
+            _m.AlignedPair.__hash__ = object.__hash__
+    return df.to_csv(sep="\t", index=False)

@@ -5,7 +5,7 @@ import pytest
 from click.testing import CliRunner
 
 from mustache_amd import bamio
-from mustache_amd.main import cli, findflanks, inferseq_overlap, pairflanks, recall
+from mustache_amd.main import cli, findflanks, inferseq_overlap, inferseq_reference, pairflanks, recall
 from tests import util
 
 FINDFLANKS_FLAGS = {  # long, short, default   (reference main.py:68-78)
@@ -30,8 +30,14 @@ OVERLAP_FLAGS = {  # reference main.py:169-173
     "min_inferseq_size": ("-minsize", 30), "output_file": ("-o", "mustache.inferseq_overlap.tsv")}
 
 
+INFERSEQ_REFERENCE_FLAGS = {  # reference main.py:147-152
+    "min_perc_identity": ("-minident", 0.95), "max_internal_softclip_prop": ("-maxclip", 0.05),
+    "max_inferseq_size": ("-maxsize", 200000), "min_inferseq_size": ("-minsize", 30),
+    "output_file": ("-o", "mustache.inferseq_reference.tsv")}
+
+
 @pytest.mark.parametrize("cmd,flags", [(findflanks, FINDFLANKS_FLAGS), (pairflanks, PAIRFLANKS_FLAGS), (recall, RECALL_FLAGS),
-                                       (inferseq_overlap, OVERLAP_FLAGS)])
+                                       (inferseq_overlap, OVERLAP_FLAGS), (inferseq_reference, INFERSEQ_REFERENCE_FLAGS)])
 def test_flags_and_defaults(cmd, flags):
     opts = {p.name: p for p in cmd.params if hasattr(p, "opts") and p.opts and p.opts[0].startswith("--")}
     for name, (short, default) in flags.items():
