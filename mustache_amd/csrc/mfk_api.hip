@@ -21,7 +21,10 @@ mfk_ctx *mfk_create(int device_id) {
     memset(ctx->stats, 0, sizeof ctx->stats);
     memset(ctx->pstats, 0, sizeof ctx->pstats);
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return nullptr; }
-    if (hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess) { delete ctx; return nullptr; }
+    if (hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking) != hipSuccess) { (void)hipStreamDestroy(ctx->stream); delete ctx; return nullptr; }
+    if (hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) != hipSuccess) { delete ctx; return nullptr; }
     return ctx;
 }
 
@@ -29,11 +32,15 @@ void mfk_destroy(mfk_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
+    (void)hipStreamSynchronize(ctx->stream2);
     for (auto &c : ctx->chunks) (void)hipFree(c.p);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     for (auto e : ctx->prof_events) (void)hipEventDestroy(e);
     (void)hipEventDestroy(ctx->ev0);
     (void)hipEventDestroy(ctx->ev1);
+    (void)hipEventDestroy(ctx->ev_fork);
+    (void)hipEventDestroy(ctx->ev_join);
+    (void)hipStreamDestroy(ctx->stream2);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -95,6 +102,13 @@ void prof_begin(mfk_ctx *ctx, const char *name) {
     }
     ctx->prof_names.push_back(name);
     (void)hipEventRecord(ctx->prof_events[ctx->prof_used], ctx->stream);
+}
+
+bool prof_brackets(mfk_ctx *ctx, const char *name) {
+    if (!ctx->prof_on) return false;
+    if (ctx->prof_filter.empty()) return true;
+    for (auto &f : ctx->prof_filter) if (f == name) return true;
+    return false;
 }
 
 void prof_end(mfk_ctx *ctx) {

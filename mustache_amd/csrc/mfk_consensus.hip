@@ -960,6 +960,32 @@ int run_consensus(mfk_ctx *ctx, const DevReads &R, const DevParams &P, Consensus
     if (!lcpm) return 1;
     // per-leaf / per-cluster kernels: fixed grids over the device-side lists (the host never learns the list sizes)
     const unsigned g_leaf1 = Wn < 8192 ? Wn : 8192, g_leaf4 = Wn < 2048 ? Wn : 2048, g_rep = Wn < 1024 ? Wn : 1024;
+    // Two chains that do not depend on each other follow: (A) trie nodes of the leaves -> node sums -> DFS ranks, and
+    // (B) edit distances of the pivots -> components -> the remaining cross-component pairs -> components.  With a few
+    // dozen jobs (a deep isolate) neither fills the GPU, so (B) runs on the side stream while (A) runs here; with
+    // thousands of jobs both fill it and the overlap costs nothing.  When one of these kernels is being timed (HIP events
+    // on this stream) everything stays on one stream so that the durations mean what they say.
+    static const char *const chain_kernels[] = {"k_leaf_first", "k_node_sums", "k_leaf_rank", "k_leaf_rank_wave", "k_leaf_myers", "k_components"};
+    bool two_streams = true;
+    for (const char *nm : chain_kernels) if (prof_brackets(ctx, nm)) two_streams = false;
+    hipStream_t sb = two_streams ? ctx->stream2 : st;
+    if (two_streams) { HIPCHK(hipEventRecord(ctx->ev_fork, st)); HIPCHK(hipStreamWaitEvent(sb, ctx->ev_fork, 0)); }
+    // partner chunks per pattern leaf: enough 64-lane chunks for the largest job, at most 16 (larger jobs stride)
+    uint32_t n_chunks = (hm.max_R + 63) / 64;
+    if (n_chunks < 1) n_chunks = 1;
+    if (n_chunks > 16) n_chunks = 16;
+    const uint64_t my_items = (uint64_t)J.n * N_PIVOTS * n_chunks;
+    const unsigned g_my0 = (unsigned)(my_items / 4 + 1 < 8192 ? my_items / 4 + 1 : 8192);
+    // chain (B)
+    PROF_LAUNCH(k_leaf_myers, dim3(g_my0), dim3(256), 0, sb, W, J, 0, n_chunks);
+    KCHK();
+    PROF_LAUNCH(k_components, dim3(J.n), dim3(256), 0, sb, W, J, 0);
+    KCHK();
+    PROF_LAUNCH(k_leaf_myers, dim3(g_leaf4), dim3(256), 0, sb, W, J, 1, n_chunks);
+    KCHK();
+    PROF_LAUNCH(k_components, dim3(J.n), dim3(256), 0, sb, W, J, 1);
+    KCHK();
+    // chain (A)
     PROF_LAUNCH(k_leaf_first, dim3(g_leaf1), dim3(64), 0, st, W, J, lcpm);
     KCHK();
     const uint32_t max_len = hm.max_len ? hm.max_len : 1;
@@ -971,20 +997,7 @@ int run_consensus(mfk_ctx *ctx, const DevReads &R, const DevParams &P, Consensus
     if (hm.max_R <= 256) { PROF_LAUNCH(k_leaf_rank_wave, dim3(g_leaf4), dim3(256), 0, st, W, J); }
     else { PROF_LAUNCH(k_leaf_rank, dim3(g_leaf4), dim3(256), 0, st, W, J); }
     KCHK();
-    // partner chunks per pattern leaf: enough 64-lane chunks for the largest job, at most 16 (larger jobs stride)
-    uint32_t n_chunks = (hm.max_R + 63) / 64;
-    if (n_chunks < 1) n_chunks = 1;
-    if (n_chunks > 16) n_chunks = 16;
-    const uint64_t my_items = (uint64_t)J.n * N_PIVOTS * n_chunks;
-    const unsigned g_my0 = (unsigned)(my_items / 4 + 1 < 8192 ? my_items / 4 + 1 : 8192);
-    PROF_LAUNCH(k_leaf_myers, dim3(g_my0), dim3(256), 0, st, W, J, 0, n_chunks);
-    KCHK();
-    PROF_LAUNCH(k_components, dim3(J.n), dim3(256), 0, st, W, J, 0);
-    KCHK();
-    PROF_LAUNCH(k_leaf_myers, dim3(g_leaf4), dim3(256), 0, st, W, J, 1, n_chunks);
-    KCHK();
-    PROF_LAUNCH(k_components, dim3(J.n), dim3(256), 0, st, W, J, 1);
-    KCHK();
+    if (two_streams) { HIPCHK(hipEventRecord(ctx->ev_join, sb)); HIPCHK(hipStreamWaitEvent(st, ctx->ev_join, 0)); }
     size_t lds = (size_t)max_len * 16 * 8;
     if (lds > 64 * 1024) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_cluster_vote), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     io.cons_stride = (max_len + 7) & ~7u;

@@ -17,7 +17,9 @@ struct Chunk { char *p; size_t cap, used; };
 struct mfk_ctx {
     int device;
     hipStream_t stream;
+    hipStream_t stream2;            // side stream for kernel chains that do not depend on each other (consensus stage)
     hipEvent_t ev0, ev1;
+    hipEvent_t ev_fork, ev_join;
     double last_ms;
     std::vector<Chunk> chunks;      // device arena
     void *pinned; size_t pinned_cap;
@@ -60,6 +62,7 @@ struct mfk_ctx {
 void prof_begin(mfk_ctx *ctx, const char *name);
 void prof_end(mfk_ctx *ctx);
 void prof_collect(mfk_ctx *ctx);               // call after the stream has been synchronised
+bool prof_brackets(mfk_ctx *ctx, const char *name);   // would a launch of this kernel be bracketed by timing events now?
 #define PROF_LAUNCH(kern, grid, block, lds, stream, ...)                      \
     do {                                                                      \
         prof_begin(ctx, #kern);                                               \
