@@ -87,7 +87,7 @@ int mfk_profile_fetch(mfk_ctx *ctx, char *names, int64_t names_cap, double *ms, 
 
 }  // extern "C"
 
-void prof_begin(mfk_ctx *ctx, const char *name) {
+void prof_begin(mfk_ctx *ctx, const char *name, hipStream_t stream) {
     if (!ctx->prof_on) return;
     ctx->prof_skip = false;
     if (!ctx->prof_filter.empty()) {
@@ -101,20 +101,13 @@ void prof_begin(mfk_ctx *ctx, const char *name) {
         ctx->prof_events.push_back(a); ctx->prof_events.push_back(b);
     }
     ctx->prof_names.push_back(name);
-    (void)hipEventRecord(ctx->prof_events[ctx->prof_used], ctx->stream);
+    (void)hipEventRecord(ctx->prof_events[ctx->prof_used], stream ? stream : ctx->stream);
 }
 
-bool prof_brackets(mfk_ctx *ctx, const char *name) {
-    if (!ctx->prof_on) return false;
-    if (ctx->prof_filter.empty()) return true;
-    for (auto &f : ctx->prof_filter) if (f == name) return true;
-    return false;
-}
-
-void prof_end(mfk_ctx *ctx) {
+void prof_end(mfk_ctx *ctx, hipStream_t stream) {
     if (ctx->prof_skip) { ctx->prof_skip = false; return; }
     if (!ctx->prof_on || ctx->prof_names.size() * 2 != ctx->prof_used + 2) return;
-    (void)hipEventRecord(ctx->prof_events[ctx->prof_used + 1], ctx->stream);
+    (void)hipEventRecord(ctx->prof_events[ctx->prof_used + 1], stream ? stream : ctx->stream);
     ctx->prof_used += 2;
 }
 

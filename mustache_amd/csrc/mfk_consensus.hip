@@ -963,13 +963,10 @@ int run_consensus(mfk_ctx *ctx, const DevReads &R, const DevParams &P, Consensus
     // Two chains that do not depend on each other follow: (A) trie nodes of the leaves -> node sums -> DFS ranks, and
     // (B) edit distances of the pivots -> components -> the remaining cross-component pairs -> components.  With a few
     // dozen jobs (a deep isolate) neither fills the GPU, so (B) runs on the side stream while (A) runs here; with
-    // thousands of jobs both fill it and the overlap costs nothing.  When one of these kernels is being timed (HIP events
-    // on this stream) everything stays on one stream so that the durations mean what they say.
-    static const char *const chain_kernels[] = {"k_leaf_first", "k_node_sums", "k_leaf_rank", "k_leaf_rank_wave", "k_leaf_myers", "k_components"};
-    bool two_streams = true;
-    for (const char *nm : chain_kernels) if (prof_brackets(ctx, nm)) two_streams = false;
-    hipStream_t sb = two_streams ? ctx->stream2 : st;
-    if (two_streams) { HIPCHK(hipEventRecord(ctx->ev_fork, st)); HIPCHK(hipStreamWaitEvent(sb, ctx->ev_fork, 0)); }
+    // thousands of jobs both fill it and the overlap costs nothing.  (Timing events of a launch go to the stream of that launch.)
+    hipStream_t sb = ctx->stream2;
+    HIPCHK(hipEventRecord(ctx->ev_fork, st));
+    HIPCHK(hipStreamWaitEvent(sb, ctx->ev_fork, 0));
     // partner chunks per pattern leaf: enough 64-lane chunks for the largest job, at most 16 (larger jobs stride)
     uint32_t n_chunks = (hm.max_R + 63) / 64;
     if (n_chunks < 1) n_chunks = 1;
@@ -997,7 +994,8 @@ int run_consensus(mfk_ctx *ctx, const DevReads &R, const DevParams &P, Consensus
     if (hm.max_R <= 256) { PROF_LAUNCH(k_leaf_rank_wave, dim3(g_leaf4), dim3(256), 0, st, W, J); }
     else { PROF_LAUNCH(k_leaf_rank, dim3(g_leaf4), dim3(256), 0, st, W, J); }
     KCHK();
-    if (two_streams) { HIPCHK(hipEventRecord(ctx->ev_join, sb)); HIPCHK(hipStreamWaitEvent(st, ctx->ev_join, 0)); }
+    HIPCHK(hipEventRecord(ctx->ev_join, sb));
+    HIPCHK(hipStreamWaitEvent(st, ctx->ev_join, 0));
     size_t lds = (size_t)max_len * 16 * 8;
     if (lds > 64 * 1024) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_cluster_vote), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     io.cons_stride = (max_len + 7) & ~7u;

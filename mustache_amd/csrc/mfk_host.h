@@ -59,15 +59,14 @@ struct mfk_ctx {
 
 #define KCHK() HIPCHK(hipGetLastError())
 
-void prof_begin(mfk_ctx *ctx, const char *name);
-void prof_end(mfk_ctx *ctx);
+void prof_begin(mfk_ctx *ctx, const char *name, hipStream_t stream = nullptr);   // events go to `stream` (default: the ctx stream)
+void prof_end(mfk_ctx *ctx, hipStream_t stream = nullptr);
 void prof_collect(mfk_ctx *ctx);               // call after the stream has been synchronised
-bool prof_brackets(mfk_ctx *ctx, const char *name);   // would a launch of this kernel be bracketed by timing events now?
 #define PROF_LAUNCH(kern, grid, block, lds, stream, ...)                      \
     do {                                                                      \
-        prof_begin(ctx, #kern);                                               \
+        prof_begin(ctx, #kern, stream);                                       \
         hipLaunchKernelGGL(kern, grid, block, lds, stream, __VA_ARGS__);      \
-        prof_end(ctx);                                                        \
+        prof_end(ctx, stream);                                                \
     } while (0)
 
 // arena ----------------------------------------------------------------------------------------------------------

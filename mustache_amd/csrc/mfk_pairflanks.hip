@@ -287,14 +287,14 @@ __device__ __forceinline__ bool d_spans(const DevReads &R, const DevParams &P, i
            !(d_large_insertion_at(R, P, r, f, pos3) || d_large_insertion_at(R, P, r, f, pos5));
 }
 
-// + filter_junction_spanning pairflanks.py:421-431 (float64, strict <, quirk P9) by the block's first thread
-__global__ __launch_bounds__(1024) void k_spanning(DevReads R, DevParams P, FlankDev F, const uint32_t *kept, const uint32_t *c5, const uint32_t *c3, const uint32_t *n_kept,
-                                                  const int32_t *ir, uint32_t *spanning, uint32_t *jflag, uint32_t *pstats) {
+// One workgroup per CANDIDATE pair (spanning[c]): the count does not depend on the assignment, so it runs on the side
+// stream while the inverted-repeat alignment and assign_pairs run on the main one; k_pair_finish picks the kept pairs'
+// counts and applies filter_junction_spanning.
+__global__ __launch_bounds__(1024) void k_spanning(DevReads R, DevParams P, FlankDev F, const uint32_t *c5, const uint32_t *c3, uint32_t n_cand, uint32_t *spanning) {
     __shared__ uint32_t cnt;
     __shared__ int64_t range[2];
-    uint32_t k = blockIdx.x;
-    if (k >= *n_kept) return;
-    uint32_t c = kept[k];
+    const uint32_t c = blockIdx.x;
+    if (c >= n_cand) return;
     const int32_t contig = F.contig[c5[c]], pos5 = F.pos[c5[c]], pos3 = F.pos[c3[c]];
     const int32_t clen = R.contig_len[contig];
     int32_t start = pos3 - 1, end = pos5 + 2;
@@ -324,23 +324,40 @@ __global__ __launch_bounds__(1024) void k_spanning(DevReads R, DevParams P, Flan
     for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o, 64);
     if ((threadIdx.x & 63) == 0 && mine) atomicAdd(&cnt, mine);
     __syncthreads();
-    if (threadIdx.x == 0) {
-        spanning[k] = cnt;
-        double total = (double)((int64_t)F.total[c5[c]] + (int64_t)F.total[c3[c]]) / 2;
-        double prop = (double)cnt / total;
-        jflag[k] = prop < P.maxjsp ? 1u : 0u;
-        if (ir[6 * c]) atomicAdd(&pstats[2], 1u);
-        if (cnt > 0) atomicAdd(&pstats[3], 1u);
-    }
+    if (threadIdx.x == 0) spanning[c] = cnt;
 }
+
+// kept pair k (candidate kept[k]): its spanning count + filter_junction_spanning pairflanks.py:421-431 (float64, strict <,
+// quirk P9) + the logged counters
+__global__ void k_pair_finish(DevParams P, FlankDev F, const uint32_t *kept, const uint32_t *c5, const uint32_t *c3, const uint32_t *n_kept, const int32_t *ir,
+                              const uint32_t *span_all, uint32_t *spanning, uint32_t *jflag, uint32_t *pstats) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= *n_kept) return;
+    const uint32_t c = kept[k], cnt = span_all[c];
+    spanning[k] = cnt;
+    double total = (double)((int64_t)F.total[c5[c]] + (int64_t)F.total[c3[c]]) / 2;
+    double prop = (double)cnt / total;
+    jflag[k] = prop < P.maxjsp ? 1u : 0u;
+    if (ir[6 * c]) atomicAdd(&pstats[2], 1u);
+    if (cnt > 0) atomicAdd(&pstats[3], 1u);
+}
+
+// final rows: the kept pairs that pass the junction filter, in kept order
+__global__ void k_pair_final(const uint32_t *kept, const uint32_t *n_kept, const uint32_t *jflag, const uint32_t *jscan, const uint32_t *spanning, uint32_t *fin, uint32_t *fin_span) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= *n_kept || !jflag[k]) return;
+    fin[jscan[k]] = kept[k];
+    fin_span[jscan[k]] = spanning[k];
+}
+
 
 // ---- get_direct_repeats ---------------------------------------------------------------------------------------------------
 #define DR_WIN 50
 #define DR_SEGS 1536
-// per final pair: dr_out[k*stride ...] = reference repeat, dr_out[k*stride + half ...] = reads consensus
-// one block per kept pair; pairs that fail the junction filter are skipped, the others write output row jscan[k]
-__global__ __launch_bounds__(1024) void k_direct_repeats(DevReads R, FlankDev F, const uint32_t *kept, const uint32_t *n_kept, const uint32_t *jflag, const uint32_t *jscan,
-                                                        const uint32_t *spanning, const uint32_t *c5, const uint32_t *c3, uint32_t *fin, uint32_t *fin_span,
+// per candidate pair c: dr_out[c*stride ...] = reference repeat, dr_out[c*stride + half ...] = reads consensus.
+// One block per CANDIDATE pair (like k_spanning, on the side stream next to the inverted-repeat alignment); the host
+// takes the rows of the final pairs.
+__global__ __launch_bounds__(1024) void k_direct_repeats(DevReads R, FlankDev F, uint32_t n_cand, const uint32_t *c5, const uint32_t *c3,
                                                         const uint8_t *genome, const int64_t *goff, char *dr_out, uint32_t stride, int32_t *dr_meta /* 3 per pair: ref_len, reads_len, err */) {
     __shared__ uint32_t sum[DR_WIN][17];
     __shared__ uint32_t firstr[DR_WIN][17];
@@ -351,10 +368,8 @@ __global__ __launch_bounds__(1024) void k_direct_repeats(DevReads R, FlankDev F,
     __shared__ int32_t seg_lo[DR_SEGS], seg_hi[DR_SEGS];
     __shared__ uint32_t seg_r[DR_SEGS], nseg;
     const char codes[17] = "=ACMGRSVTWYHKDBN";
-    if (blockIdx.x >= *n_kept || !jflag[blockIdx.x]) return;
-    const uint32_t k = jscan[blockIdx.x];      // output row
-    const uint32_t c = kept[blockIdx.x];
-    if (threadIdx.x == 0) { fin[k] = c; fin_span[k] = spanning[blockIdx.x]; }
+    if (blockIdx.x >= n_cand) return;
+    const uint32_t c = blockIdx.x, k = c;      // output row = candidate
     const int32_t contig = F.contig[c5[c]], end = F.pos[c5[c]], start = F.pos[c3[c]];
     const int64_t glen = goff[contig + 1] - goff[contig];
     const uint8_t *g = genome + goff[contig];
@@ -578,7 +593,7 @@ extern "C" int mfk_pairflanks(mfk_ctx *ctx, const mfk_reads *reads, const mfk_pa
         uint32_t *best5 = aalloc<uint32_t>(ctx, nF), *best3 = aalloc<uint32_t>(ctx, nF);
         uint8_t *used5 = aalloc<uint8_t>(ctx, nF), *used3 = aalloc<uint8_t>(ctx, nF), *state = aalloc<uint8_t>(ctx, nP);
         uint32_t *kflag = aalloc<uint32_t>(ctx, nP), *kscan = aalloc<uint32_t>(ctx, (size_t)nP + 1), *jscan = aalloc<uint32_t>(ctx, (size_t)nP + 1);
-        uint32_t *kept = aalloc<uint32_t>(ctx, nP), *spanning = aalloc<uint32_t>(ctx, nP);
+        uint32_t *kept = aalloc<uint32_t>(ctx, nP), *spanning = aalloc<uint32_t>(ctx, nP), *span_all = aalloc<uint32_t>(ctx, nP);
         uint32_t *fin = aalloc<uint32_t>(ctx, nP), *fin_span = aalloc<uint32_t>(ctx, nP);
         int32_t *meta = aalloc<int32_t>(ctx, 3 * (size_t)nP);
         stride = 2 * (((uint32_t)P.maxdr + 1 + 15) & ~15u);
@@ -587,10 +602,21 @@ extern "C" int mfk_pairflanks(mfk_ctx *ctx, const mfk_reads *reads, const mfk_pa
         z.want(&d_pstats, MFK_N_STATS); z.want(&kv, nP); z.want(&jflag, nP); z.want(&dr, (size_t)nP * stride);
         f.want(&kk, nP);   // unused sort keys stay ~0 and sort behind the kept pairs
         if (!c5 || !c3 || !ir || !keys || !keys2 || !kk2 || !vals || !order || !best5 || !best3 || !used5 || !used3 || !state || !kflag || !kscan || !jscan ||
-            !kept || !spanning || !fin || !fin_span || !meta || z.commit() || f.commit()) return 1;
+            !kept || !spanning || !span_all || !fin || !fin_span || !meta || z.commit() || f.commit()) return 1;
         const unsigned pb = nblocks(nP, 256);
         PROF_LAUNCH(k_pair_window<true>, dim3(fb), dim3(256), 0, st, F, P.maxdr, sorted, (uint32_t *)nullptr, (const uint32_t *)coff, c5, c3);
         KCHK();
+        // Side stream: spanning reads and direct repeats of every candidate (they depend on the positions only).  Main
+        // stream: inverted repeats -> assign_pairs.  (Timing events of a launch go to the stream of that launch.)
+        hipStream_t sb = ctx->stream2;
+        HIPCHK(hipEventRecord(ctx->ev_fork, st));
+        HIPCHK(hipStreamWaitEvent(sb, ctx->ev_fork, 0));
+        PROF_LAUNCH(k_spanning, dim3(nP), dim3(nP >= 2048 ? 256 : 1024), 0, sb, R, P, F, (const uint32_t *)c5, (const uint32_t *)c3, nP, span_all);
+        KCHK();
+        PROF_LAUNCH(k_direct_repeats, dim3(nP), dim3(nP >= 2048 ? 256 : 1024), 0, sb, R, F, nP, (const uint32_t *)c5, (const uint32_t *)c3,
+                    genome, (const int64_t *)d_goff, dr, stride, meta);
+        KCHK();
+        HIPCHK(hipEventRecord(ctx->ev_join, sb));
         if (ir_tab.empty()) {
             PROF_LAUNCH(k_inverted_repeat, dim3(nP), dim3(64), 0, st, F, (const uint32_t *)c5, (const uint32_t *)c3, nP, ir, keys, vals);
             KCHK();
@@ -609,11 +635,12 @@ extern "C" int mfk_pairflanks(mfk_ctx *ctx, const mfk_reads *reads, const mfk_pa
         PROF_LAUNCH(k_kept_keys, dim3(pb), dim3(256), 0, st, F, (const uint32_t *)order, (const uint32_t *)c5, (const uint32_t *)c3, (const uint8_t *)state, (const uint32_t *)kscan, nP, (const int32_t *)d_rank, kk, kv);
         KCHK();
         if (int rc = dev_sort_pairs64(ctx, kk, kk2, kv, kept, nP, 0, 64)) return rc;
-        PROF_LAUNCH(k_spanning, dim3(nP), dim3(nP >= 2048 ? 256 : 1024), 0, st, R, P, F, (const uint32_t *)kept, (const uint32_t *)c5, (const uint32_t *)c3, nK_p, (const int32_t *)ir, spanning, jflag, d_pstats);
+        HIPCHK(hipStreamWaitEvent(st, ctx->ev_join, 0));
+        PROF_LAUNCH(k_pair_finish, dim3(pb), dim3(256), 0, st, P, F, (const uint32_t *)kept, (const uint32_t *)c5, (const uint32_t *)c3, nK_p, (const int32_t *)ir,
+                    (const uint32_t *)span_all, spanning, jflag, d_pstats);
         KCHK();
         if (int rc = dev_excl_scan32(ctx, jflag, jscan, nP)) return rc;
-        PROF_LAUNCH(k_direct_repeats, dim3(nP), dim3(nP >= 2048 ? 256 : 1024), 0, st, R, F, (const uint32_t *)kept, nK_p, (const uint32_t *)jflag, (const uint32_t *)jscan, (const uint32_t *)spanning,
-                    (const uint32_t *)c5, (const uint32_t *)c3, fin, fin_span, genome, (const int64_t *)d_goff, dr, stride, meta);
+        PROF_LAUNCH(k_pair_final, dim3(pb), dim3(256), 0, st, (const uint32_t *)kept, nK_p, (const uint32_t *)jflag, (const uint32_t *)jscan, (const uint32_t *)spanning, fin, fin_span);
         KCHK();
         HIPCHK(hipEventRecord(ctx->ev1, st));
         h_fin.resize(nP); h_span.resize(nP); h_meta.resize(3 * (size_t)nP); h_dr.resize((size_t)nP * stride);
@@ -638,7 +665,7 @@ extern "C" int mfk_pairflanks(mfk_ctx *ctx, const mfk_reads *reads, const mfk_pa
     for (uint32_t k = 0; k < nFin; k++) {
         uint32_t c = h_fin[k], a = h_c5[c], b = h_c3[c];
         const mfk_flank &f5 = flanks[a], &f3 = flanks[b];
-        const int32_t *m = &h_meta[3 * (size_t)k];
+        const int32_t *m = &h_meta[3 * (size_t)c];
         if (m[2] == 2) { snprintf(ctx->err, sizeof ctx->err, "ValueError: direct-repeat bounds %d..%d fall outside the target window (pairflanks.py:323)", f3.pos + 1, f5.pos); return 5; }
         if (m[2] == 1) { snprintf(ctx->err, sizeof ctx->err, "a read over a direct-repeat window has no sequence in the pool"); return 4; }
         mfk_pair o; memset(&o, 0, sizeof o);
@@ -657,8 +684,8 @@ extern "C" int mfk_pairflanks(mfk_ctx *ctx, const mfk_reads *reads, const mfk_pa
             o.ir_length = o.ir5_len;
         }
         o.dr_ref_len = m[0]; o.dr_len = m[1];
-        o.dr_ref_off = (int64_t)ctx->strs.size(); ctx->strs.append(h_dr.data() + (size_t)k * stride, (size_t)m[0]);
-        o.dr_reads_off = (int64_t)ctx->strs.size(); ctx->strs.append(h_dr.data() + (size_t)k * stride + stride / 2, (size_t)m[1]);
+        o.dr_ref_off = (int64_t)ctx->strs.size(); ctx->strs.append(h_dr.data() + (size_t)c * stride, (size_t)m[0]);
+        o.dr_reads_off = (int64_t)ctx->strs.size(); ctx->strs.append(h_dr.data() + (size_t)c * stride + stride / 2, (size_t)m[1]);
         ctx->pairs.push_back(o);
     }
     if (n_pairs_out) *n_pairs_out = (int64_t)ctx->pairs.size();
