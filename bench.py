@@ -45,7 +45,8 @@ def algorithmic_bytes(kernel, meta):
 
 
 def pmc_traffic(kernel, config):
-    """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/r01_pmc_traffic.json), or None."""
+    """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/r01_pmc_traffic.json, made by
+    scripts/profile_round.sh + scripts/pmc_table.py from this same command), or None."""
     path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
     try:
         with open(path) as fh:
@@ -176,12 +177,13 @@ def main():
                 e["traffic"] = sum(tr) if all(t is not None for t in tr) else None
                 return e
 
-            # dominant kernel = largest share of device time.  No kernel dominates this path at C2 (the largest is ~8 % of
-            # the device time, the step is a chain of ~70 short launches, and the largest ones are per-pair / per-cluster
-            # latency chains without a streaming model: achieved = null for those), so the read scan -- the two kernels that touch
-            # every read and carry the path's algorithmic bytes -- is reported beside it.
-            roofline = entry([table[0][0]])
-            roofline["read_scan"] = entry(scan_kernels)
+            # The roofline object is that of the read scan: the two kernels that process the metric's unit (every read) and
+            # carry the path's algorithmic bytes.  By TIME no kernel dominates this path at C2: the largest is ~10 % of the
+            # summed kernel time, the step is a chain of ~70 short launches on two streams, and the largest ones are
+            # per-site / per-pair latency chains (bit-vector edit distance, direct-repeat pile-up, inverted-repeat
+            # alignment) on a few dozen workgroups; `dominant_by_time` reports that kernel with a byte model where one exists.
+            roofline = entry(scan_kernels)
+            roofline["dominant_by_time"] = entry([table[0][0]])
             roofline["top5_by_time"] = [{"kernel": r[0], "avg_ms": round(r[1], 5), "launches_per_step": r[2] // warm_calls,
                                          "share": round(share[r[0]], 3)} for r in full_table[:5]]
         if args.dump_profile:
