@@ -389,9 +389,13 @@ __global__ __launch_bounds__(64) void k_leaf_first(Words W, Jobs J, uint16_t *lc
 }
 
 // ---- leaf pairs: edit distance (Myers / Hyyro bit-vector, global alignment) + DFS order ------------------------------
+// The match vectors Eq(c) of the pattern come from a table in LDS (one 64-bit limb per code and limb, limb-major so the
+// 16 codes of a limb lie in 16 different banks): one LDS read per limb and step instead of rebuilding Eq from the four
+// bit planes.  The reads of MY_BATCH steps are issued together.
+#define MY_BATCH 4
 template <int NL>
-__device__ __forceinline__ int d_myers(const uint64_t (&plane)[4][NL], const uint8_t *text, int m) {
-    // pattern = leaf a (bit planes of its 4-bit codes), text = b[0:m); returns D(a[0:m), b[0:m))
+__device__ __forceinline__ int d_myers(const uint64_t *peq, const uint8_t *text, int m) {
+    // pattern = leaf a (peq[limb * 16 + code]), text = b[0:m); returns D(a[0:m), b[0:m))
     uint64_t Pv[NL], Mv[NL];
 #pragma unroll
     for (int i = 0; i < NL; i++) { Pv[i] = ~0ull; Mv[i] = 0ull; }
@@ -402,34 +406,43 @@ __device__ __forceinline__ int d_myers(const uint64_t (&plane)[4][NL], const uin
     for (int o = 0; o < m; o += 8) {
         const uint64_t chunk = next;
         if (o + 8 < m) next = *reinterpret_cast<const uint64_t *>(text + o + 8);   // in flight while this chunk is processed
-        int lim = m - o < 8 ? m - o : 8;
-        for (int s = 0; s < lim; s++) {
-            uint32_t c = (uint32_t)(chunk >> (8 * s)) & 0xFF;
-            uint64_t carry_add = 0, carry_ph = 1, carry_mh = 0;   // carry_ph = 1: D[0][j] = j (global alignment)
 #pragma unroll
-            for (int i = 0; i < NL; i++) {
-                uint64_t Eq = ~0ull;
+        for (int h = 0; h < 8; h += MY_BATCH) {
+            if (o + h >= m) break;
+            uint64_t Eqs[MY_BATCH][NL];
 #pragma unroll
-                for (int p = 0; p < 4; p++) Eq &= ((c >> p) & 1) ? plane[p][i] : ~plane[p][i];
-                if (c > 15) Eq = 0;
-                uint64_t pv = Pv[i], mv = Mv[i];
-                uint64_t Xv = Eq | mv;
-                uint64_t X = Eq & pv;
-                uint64_t sum = X + pv;
-                uint64_t c1 = sum < X ? 1ull : 0ull;
-                uint64_t sum2 = sum + carry_add;
-                uint64_t c2 = sum2 < sum ? 1ull : 0ull;
-                carry_add = c1 | c2;
-                uint64_t Xh = (sum2 ^ pv) | Eq;
-                uint64_t Ph = mv | ~(Xh | pv);
-                uint64_t Mh = pv & Xh;
-                if (i == tl) { if (Ph & tb) score++; else if (Mh & tb) score--; }
-                uint64_t ph_out = Ph >> 63, mh_out = Mh >> 63;
-                Ph = (Ph << 1) | carry_ph;
-                Mh = (Mh << 1) | carry_mh;
-                carry_ph = ph_out; carry_mh = mh_out;
-                Pv[i] = Mh | ~(Xv | Ph);
-                Mv[i] = Ph & Xv;
+            for (int s = 0; s < MY_BATCH; s++) {
+                const uint32_t c = (uint32_t)(chunk >> (8 * (h + s))) & 0xFF;
+#pragma unroll
+                for (int i = 0; i < NL; i++) Eqs[s][i] = c > 15 ? 0ull : peq[i * 16 + (c & 15)];
+            }
+            const int lim = m - o - h < MY_BATCH ? m - o - h : MY_BATCH;
+#pragma unroll
+            for (int s = 0; s < MY_BATCH; s++) {
+                if (s >= lim) break;
+                uint64_t carry_add = 0, carry_ph = 1, carry_mh = 0;   // carry_ph = 1: D[0][j] = j (global alignment)
+#pragma unroll
+                for (int i = 0; i < NL; i++) {
+                    const uint64_t Eq = Eqs[s][i];
+                    uint64_t pv = Pv[i], mv = Mv[i];
+                    uint64_t Xv = Eq | mv;
+                    uint64_t X = Eq & pv;
+                    uint64_t sum = X + pv;
+                    uint64_t c1 = sum < X ? 1ull : 0ull;
+                    uint64_t sum2 = sum + carry_add;
+                    uint64_t c2 = sum2 < sum ? 1ull : 0ull;
+                    carry_add = c1 | c2;
+                    uint64_t Xh = (sum2 ^ pv) | Eq;
+                    uint64_t Ph = mv | ~(Xh | pv);
+                    uint64_t Mh = pv & Xh;
+                    if (i == tl) { if (Ph & tb) score++; else if (Mh & tb) score--; }
+                    uint64_t ph_out = Ph >> 63, mh_out = Mh >> 63;
+                    Ph = (Ph << 1) | carry_ph;
+                    Mh = (Mh << 1) | carry_mh;
+                    carry_ph = ph_out; carry_mh = mh_out;
+                    Pv[i] = Mh | ~(Xv | Ph);
+                    Mv[i] = Ph & Xv;
+                }
             }
         }
     }
@@ -511,33 +524,31 @@ __global__ __launch_bounds__(256) void k_leaf_rank_wave(Words W, Jobs J) {
     }
 }
 
-// bit planes of a leaf's 4-bit codes, built by the whole wave: lane l looks at character 64*i + l, a ballot per code bit
-// is limb i of that plane.  The result is wave-uniform, so no LDS and no barrier is involved.
-__device__ __forceinline__ void d_planes_wave(const uint8_t *a, int la, int need, int lane, uint64_t (&pl)[4][8]) {
-#pragma unroll
-    for (int i = 0; i < 8; i++) {
+// Match-vector table of a leaf, built by the whole wave into its part of LDS: lane l looks at character 64*i + l, a
+// ballot per code bit gives limb i of the four bit planes (wave-uniform), lane c < 16 combines them into Eq(c) of that limb.
+__device__ __forceinline__ void d_peq_wave(const uint8_t *a, int la, int need, int lane, uint64_t *peq) {
+    for (int i = 0; i < need; i++) {   // need is wave-uniform
         uint32_t c = 0;
-        if (i < need) { const int pos = i * 64 + lane; if (pos < la) c = a[pos]; }   // need is wave-uniform
+        const int pos = i * 64 + lane;
+        if (pos < la) c = a[pos];
+        uint64_t eq = ~0ull;
 #pragma unroll
-        for (int p = 0; p < 4; p++) pl[p][i] = i < need ? __ballot((c >> p) & 1) : 0ull;
+        for (int p = 0; p < 4; p++) { const uint64_t pl = __ballot((c >> p) & 1); eq &= ((lane >> p) & 1) ? pl : ~pl; }
+        // positions beyond the leaf carry code 0 in the planes: they sit above bit m-1 of every test, where they cannot
+        // reach the score bit (carries only travel upwards)
+        if (lane < 16) peq[i * 16 + lane] = eq;
     }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 }
 
-__device__ __forceinline__ int d_myers_any(const uint64_t (&planes)[4][8], int need, const uint8_t *text, int m) {
-#define MYERS_CASE(NL_)                                                                                  \
-    {                                                                                                    \
-        uint64_t pl[4][NL_];                                                                             \
-        _Pragma("unroll") for (int p = 0; p < 4; p++) _Pragma("unroll") for (int i = 0; i < NL_; i++) pl[p][i] = planes[p][i]; \
-        return d_myers<NL_>(pl, text, m);                                                                \
-    }
+__device__ __forceinline__ int d_myers_any(const uint64_t *peq, int need, const uint8_t *text, int m) {
     switch (need) {
-        case 1: MYERS_CASE(1)
-        case 2: MYERS_CASE(2)
-        case 3: MYERS_CASE(3)
-        case 4: MYERS_CASE(4)
-        default: MYERS_CASE(8)
+        case 1: return d_myers<1>(peq, text, m);
+        case 2: return d_myers<2>(peq, text, m);
+        case 3: return d_myers<3>(peq, text, m);
+        case 4: return d_myers<4>(peq, text, m);
+        default: return d_myers<8>(peq, text, m);
     }
-#undef MYERS_CASE
 }
 
 // Edit-distance tests between leaves (get_sequence_clusters, findflanks.py:1041-1053).  Only connectivity and "has any
@@ -551,7 +562,9 @@ __device__ __forceinline__ int d_myers_any(const uint64_t (&planes)[4][8], int n
 // up to 16 chunks: either way the GPU is filled with waves that each run one bit-vector recurrence, and nothing waits
 // at a barrier.
 __global__ __launch_bounds__(256) void k_leaf_myers(Words W, Jobs J, int mode, uint32_t n_chunks) {
+    __shared__ uint64_t s_peq[4][8 * 16];   // per wave: Eq[limb][code] of its current pattern leaf
     const int lane = threadIdx.x & 63;
+    uint64_t *peq = s_peq[threadIdx.x >> 6];
     const uint32_t wave = blockIdx.x * 4 + (threadIdx.x >> 6), n_waves = gridDim.x * 4;
     const uint32_t n_items = (mode == 0 ? J.n * N_PIVOTS : W.n_list[2]) * n_chunks;
     for (uint32_t it = wave; it < n_items; it += n_waves) {   // wave-uniform
@@ -569,8 +582,7 @@ __global__ __launch_bounds__(256) void k_leaf_myers(Words W, Jobs J, int mode, u
         const int la = (int)W.len[wa];
         const int need = (la + 63) >> 6;
         if (need > 8) continue;   // cannot happen: words are capped at MAX_WORD_LEN
-        uint64_t planes[4][8];
-        d_planes_wave(a, la, need, lane, planes);
+        d_peq_wave(a, la, need, lane, peq);
         const uint32_t rw = (R + 31) >> 5;
         uint32_t *adj = J.adj + J.adj_off[job];
         for (uint32_t kb = first + lane; kb < nl; kb += 64 * n_chunks) {
@@ -583,7 +595,7 @@ __global__ __launch_bounds__(256) void k_leaf_myers(Words W, Jobs J, int mode, u
             const uint32_t wb = w0 + W.leaf_word[w0 + kb];
             const int lb = (int)W.len[wb];
             const int m = la < lb ? la : lb;
-            const int d = d_myers_any(planes, need, W.ch + W.off[wb], m);
+            const int d = d_myers_any(peq, need, W.ch + W.off[wb], m);
             if (4 * d <= m) {   // similarity = 1 - d/m >= 0.75 (findflanks.py:1044-1048, quirk Q11)
                 atomicOr(&adj[(size_t)ka * rw + (kb >> 5)], 1u << (kb & 31));
                 atomicOr(&adj[(size_t)kb * rw + (ka >> 5)], 1u << (ka & 31));
@@ -607,23 +619,39 @@ __global__ __launch_bounds__(256) void k_components(Words W, Jobs J, int final_p
         for (uint32_t x = 0; x < rw; x++) if (adj[(size_t)a * rw + x]) { any = true; break; }
         W.has_match[w0 + a] = any ? 1 : 0;
     }
-    for (int iter = 0; iter < (int)nl + 1; iter++) {
+    // Labels are written by atomics (L2) and read around the L1 (agent-scope relaxed loads), so every wave of the block
+    // sees the current value after the barrier.
+#define LBL(i) __hip_atomic_load(&label[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+    // Every edge is handled by its higher-numbered end only (the adjacency is symmetric): that leaf pulls the smaller
+    // label and pushes its own to the neighbour when that one's is larger.  The pivots' rows (hundreds of bits at a
+    // deep site: a pivot matches nearly every leaf) are therefore never walked; their few lower neighbours do the work.
+    for (int iter = 0; iter < (int)nl + 2; iter++) {
         __syncthreads();
         if (threadIdx.x == 0) changed = 0;
         __syncthreads();
         for (uint32_t a = threadIdx.x; a < nl; a += blockDim.x) {
-            uint32_t l = label[a];
-            for (uint32_t x = 0; x < rw; x++) {
+            const uint32_t l0 = LBL(a);
+            uint32_t l = l0;
+            const uint32_t xa = a >> 5, low = (1u << (a & 31)) - 1u;
+            for (uint32_t x = 0; x <= xa; x++) {
                 uint32_t bits = adj[(size_t)a * rw + x];
-                while (bits) { int b = __builtin_ctz(bits); bits &= bits - 1; uint32_t lb = label[x * 32 + b]; if (lb < l) l = lb; }
+                if (x == xa) bits &= low;
+                while (bits) { int b = __builtin_ctz(bits); bits &= bits - 1; uint32_t lb = LBL(x * 32 + b); if (lb < l) l = lb; }
             }
-            uint32_t ll = label[l];   // pointer jumping
+            uint32_t ll = LBL(l);   // pointer jumping
             if (ll < l) l = ll;
-            if (l < label[a]) { label[a] = l; changed = 1; }
+            if (l < l0) { atomicMin(&label[a], l); changed = 1; }
+            for (uint32_t x = 0; x <= xa; x++) {
+                uint32_t bits = adj[(size_t)a * rw + x];
+                if (x == xa) bits &= low;
+                while (bits) { int b = __builtin_ctz(bits); bits &= bits - 1; if (LBL(x * 32 + b) > l) { atomicMin(&label[x * 32 + b], l); changed = 1; } }
+            }
         }
         __syncthreads();
         if (!changed) break;
     }
+#undef LBL
+    __syncthreads();
     // the largest component among those of the first N_PIVOTS leaves (k_leaf_myers mode 1 skips its members)
     __shared__ uint32_t pc[N_PIVOTS];
     if (threadIdx.x < N_PIVOTS) pc[threadIdx.x] = 0;
@@ -753,12 +781,18 @@ __global__ __launch_bounds__(256) void k_leaf_share(Words W, Jobs J, const uint1
 // one block per cluster (representative leaf slot): column vote over the sub-trie of its leaves (make_consensus_word
 // flanktrie.py:306-342), merged count (make_subtrie 89-118) and the cluster's place in the reference's list order.
 // A member leaf adds the nodes of its path from depth share(l) on.  dynamic LDS: hq[max_len*16] (u32) | hc[max_len*16]
-__global__ __launch_bounds__(512) void k_cluster_vote(DevParams P, Words W, Jobs J, uint32_t max_len, char *cl_chars, uint32_t cl_stride) {
+// The walk of one member is a chain of dependent loads (word offset -> npos -> node sums), so the members of a tile of
+// leaves are first compacted into an LDS list (offset, length, share resolved by one thread per leaf, all at once), then
+// dealt to the waves CV_BATCH at a time: a wave has the loads of CV_BATCH members in flight before the first LDS add.
+#define CV_THREADS 512
+#define CV_BATCH 4
+__global__ __launch_bounds__(CV_THREADS) void k_cluster_vote(DevParams P, Words W, Jobs J, uint32_t max_len, char *cl_chars, uint32_t cl_stride) {
     extern __shared__ __align__(16) unsigned char smem[];
     uint32_t *hq = reinterpret_cast<uint32_t *>(smem);
     uint32_t *hc = hq + (size_t)max_len * 16;
     __shared__ int s_maxd, s_stop;
-    __shared__ uint32_t s_minrank, s_words;
+    __shared__ uint32_t s_minrank, s_words, s_nmem[2];
+    __shared__ uint32_t s_moff[CV_THREADS], s_mls[CV_THREADS];   // members of the tile: word offset, len | share << 16
     const int lane = threadIdx.x & 63;
     const uint32_t wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
     const uint32_t n_rep = W.n_list[1];
@@ -767,34 +801,64 @@ __global__ __launch_bounds__(512) void k_cluster_vote(DevParams P, Words W, Jobs
     const uint32_t slot = W.rep_list[it];
     const uint32_t job = W.job[slot], w0 = J.w0[job], nl = J.nl[job], ka = slot - w0;
     for (uint32_t d = threadIdx.x; d < max_len * 16; d += blockDim.x) { hq[d] = 0; hc[d] = 0; }
-    if (threadIdx.x == 0) { s_maxd = 0; s_minrank = 0xFFFFFFFFu; s_words = 0; }
+    if (threadIdx.x == 0) { s_maxd = 0; s_minrank = 0xFFFFFFFFu; s_words = 0; s_nmem[0] = 0; s_nmem[1] = 0; }
     __syncthreads();
     uint32_t words = 0;
     int maxlen = 0; uint32_t minrank = 0xFFFFFFFFu;
-    // lanes look at 64 leaves at a time; the members among them are then walked one by one by the whole wave
-    for (uint32_t k0 = wave * 64; k0 < nl; k0 += nwaves * 64) {
-        const uint32_t kl = k0 + lane;
+    uint32_t tile = 0;
+    for (uint32_t k0 = 0; k0 < nl; k0 += blockDim.x, tile ^= 1u) {
+        const uint32_t kl = k0 + threadIdx.x;
         const bool member = kl < nl && W.label[w0 + kl] == ka;
-        uint32_t m_wl = 0, m_len = 0, m_share = 0;
+        uint32_t m_off = 0, m_ls = 0;
         if (member) {
-            m_wl = w0 + W.leaf_word[w0 + kl]; m_len = W.len[m_wl]; m_share = W.share[w0 + kl];
-            if ((int)m_len > maxlen) maxlen = (int)m_len;
+            const uint32_t wl = w0 + W.leaf_word[w0 + kl], len = W.len[wl], share = W.share[w0 + kl];
+            m_off = (uint32_t)W.off[wl];   // offsets < 2^32 (checked by the host)
+            m_ls = len | (share << 16);
+            if ((int)len > maxlen) maxlen = (int)len;
             const uint32_t rk = W.leaf_rank[w0 + kl]; if (rk < minrank) minrank = rk;
         }
-        unsigned long long todo = __ballot(member);
-        while (todo) {
-            const int src = __builtin_ctzll(todo); todo &= todo - 1;
-            const uint32_t wl = __shfl(m_wl, src, 64);
-            const int len = (int)__shfl(m_len, src, 64), share = (int)__shfl(m_share, src, 64);
-            const uint64_t o = W.off[wl];
-            for (int d = share + lane; d < len; d += 64) {
-                const NodeSum ns = W.agg[W.npos[o + d]];
-                const uint32_t code = W.ch[o + d] & 15;
-                atomicAdd(&hq[d * 16 + code], ns.q);
-                atomicAdd(&hc[d * 16 + code], ns.c);
-                words += ns.e;                               // words ending here: prefixes of a leaf of the cluster
+        const unsigned long long mb = __ballot(member);
+        uint32_t base = 0;
+        if (lane == 0 && mb) base = atomicAdd(&s_nmem[tile], (uint32_t)__popcll(mb));
+        base = __shfl(base, 0, 64);
+        if (member) { const uint32_t at = base + (uint32_t)__popcll(mb & ((1ull << lane) - 1ull)); s_moff[at] = m_off; s_mls[at] = m_ls; }
+        __syncthreads();
+        const uint32_t nm = s_nmem[tile];
+        if (threadIdx.x == 0) s_nmem[tile ^ 1u] = 0;   // next tile's counter: last read before the barrier that ended the previous tile
+        for (uint32_t i = wave * CV_BATCH; i < nm; i += nwaves * CV_BATCH) {
+            uint32_t o[CV_BATCH], np[CV_BATCH], code[CV_BATCH];
+            int len[CV_BATCH], d[CV_BATCH];
+            bool ok[CV_BATCH];
+            NodeSum ns[CV_BATCH];
+#pragma unroll
+            for (int u = 0; u < CV_BATCH; u++) {
+                const bool in = i + u < nm;
+                o[u] = in ? s_moff[i + u] : 0u;
+                const uint32_t ls = in ? s_mls[i + u] : 0u;
+                len[u] = (int)(ls & 0xFFFFu); d[u] = (int)(ls >> 16) + lane;
+                ok[u] = d[u] < len[u];
+                np[u] = 0; code[u] = 0;
+                if (ok[u]) { np[u] = W.npos[(size_t)o[u] + d[u]]; code[u] = W.ch[(size_t)o[u] + d[u]] & 15; }
             }
+#pragma unroll
+            for (int u = 0; u < CV_BATCH; u++) { ns[u].q = 0; ns[u].c = 0; ns[u].e = 0; if (ok[u]) ns[u] = W.agg[np[u]]; }
+#pragma unroll
+            for (int u = 0; u < CV_BATCH; u++) if (ok[u]) {
+                atomicAdd(&hq[d[u] * 16 + code[u]], ns[u].q);
+                atomicAdd(&hc[d[u] * 16 + code[u]], ns[u].c);
+                words += ns[u].e;                            // words ending here: prefixes of a leaf of the cluster
+            }
+#pragma unroll
+            for (int u = 0; u < CV_BATCH; u++)               // a path longer than 64 below its shared depth
+                for (int dd = d[u] + 64; dd < len[u]; dd += 64) {
+                    const NodeSum n2 = W.agg[W.npos[(size_t)o[u] + dd]];
+                    const uint32_t c2 = W.ch[(size_t)o[u] + dd] & 15;
+                    atomicAdd(&hq[dd * 16 + c2], n2.q);
+                    atomicAdd(&hc[dd * 16 + c2], n2.c);
+                    words += n2.e;
+                }
         }
+        __syncthreads();
     }
     if (maxlen) atomicMax(&s_maxd, maxlen);
     if (minrank != 0xFFFFFFFFu) atomicMin(&s_minrank, minrank);
@@ -1004,7 +1068,7 @@ int run_consensus(mfk_ctx *ctx, const DevReads &R, const DevParams &P, Consensus
     if (!io.cons_chars || !cl_chars) return 1;
     PROF_LAUNCH(k_leaf_share, dim3(g_leaf4), dim3(256), 0, st, W, J, (const uint16_t *)lcpm);
     KCHK();
-    PROF_LAUNCH(k_cluster_vote, dim3(g_rep), dim3(512), lds, st, P, W, J, max_len, cl_chars, io.cons_stride);
+    PROF_LAUNCH(k_cluster_vote, dim3(g_rep), dim3(CV_THREADS), lds, st, P, W, J, max_len, cl_chars, io.cons_stride);
     KCHK();
     PROF_LAUNCH(k_job_best, dim3(J.n), dim3(256), 0, st, P, W, J, io, (const char *)cl_chars, io.cons_stride);
     KCHK();
