@@ -14,17 +14,25 @@ mfk_ctx *mfk_create(int device_id) {
     ctx->last_ms = 0.0;
     ctx->pinned = nullptr;
     ctx->pinned_cap = 0;
+    ctx->gather_count = nullptr;
+    ctx->gather_flag = nullptr; ctx->gather_flag_dev = nullptr;
+    ctx->gather_seq = 0;
     ctx->err[0] = 0;
     ctx->prof_on = false;
     ctx->prof_skip = false;
     ctx->prof_used = 0;
     memset(ctx->stats, 0, sizeof ctx->stats);
     memset(ctx->pstats, 0, sizeof ctx->pstats);
+    if (hipMalloc((void **)&ctx->gather_count, 256) != hipSuccess || hipMemset(ctx->gather_count, 0, 256) != hipSuccess) { delete ctx; return nullptr; }
+    if (hipHostMalloc((void **)&ctx->gather_flag, 256, hipHostMallocMapped) != hipSuccess || hipHostGetDevicePointer((void **)&ctx->gather_flag_dev, ctx->gather_flag, 0) != hipSuccess) { delete ctx; return nullptr; }
+    ctx->gather_flag[0] = 0;
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return nullptr; }
     if (hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking) != hipSuccess) { (void)hipStreamDestroy(ctx->stream); delete ctx; return nullptr; }
+    if (hipStreamCreateWithFlags(&ctx->stream3, hipStreamNonBlocking) != hipSuccess) { (void)hipStreamDestroy(ctx->stream2); (void)hipStreamDestroy(ctx->stream); delete ctx; return nullptr; }
     if (hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) != hipSuccess) { delete ctx; return nullptr; }
+        hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_join3, hipEventDisableTiming) != hipSuccess) { delete ctx; return nullptr; }
     return ctx;
 }
 
@@ -33,13 +41,18 @@ void mfk_destroy(mfk_ctx *ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     (void)hipStreamSynchronize(ctx->stream2);
+    (void)hipStreamSynchronize(ctx->stream3);
     for (auto &c : ctx->chunks) (void)hipFree(c.p);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+    if (ctx->gather_count) (void)hipFree(ctx->gather_count);
+    if (ctx->gather_flag) (void)hipHostFree(ctx->gather_flag);
     for (auto e : ctx->prof_events) (void)hipEventDestroy(e);
     (void)hipEventDestroy(ctx->ev0);
     (void)hipEventDestroy(ctx->ev1);
     (void)hipEventDestroy(ctx->ev_fork);
     (void)hipEventDestroy(ctx->ev_join);
+    (void)hipEventDestroy(ctx->ev_join3);
+    (void)hipStreamDestroy(ctx->stream3);
     (void)hipStreamDestroy(ctx->stream2);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -168,10 +181,13 @@ int read_back(mfk_ctx *ctx, const void *dev, void *host, size_t bytes) {
 }
 
 // up to GATHER_MAX pieces of device memory -> one staging buffer in pinned host memory, written by the kernel itself
-// (zero-copy): a read-back of many small result arrays is one launch instead of one copy per array
+// (zero-copy): a read-back of many small result arrays is one launch instead of one copy per array.  The kernel then
+// publishes a sequence number behind its data (every thread fences its stores system-wide, the last block to finish
+// stores the number with release semantics) and the host polls that word instead of sleeping in a stream
+// synchronisation: 6.8 us instead of 11 us per read-back on this box (scripts/micro/sync_cost.hip).
 #define GATHER_MAX 16
 struct GatherArgs { const uint8_t *src[GATHER_MAX]; uint32_t bytes[GATHER_MAX], off[GATHER_MAX]; int n; };
-__global__ __launch_bounds__(256) void k_gather(GatherArgs g, uint8_t *dst) {
+__global__ __launch_bounds__(256) void k_gather(GatherArgs g, uint8_t *dst, uint32_t *count, uint32_t *flag, uint32_t seq) {
     for (int i = blockIdx.y; i < g.n; i += gridDim.y) {
         const uint8_t *src = g.src[i];
         uint8_t *out = dst + g.off[i];
@@ -184,13 +200,22 @@ __global__ __launch_bounds__(256) void k_gather(GatherArgs g, uint8_t *dst) {
         } else
             for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < nb; k += gridDim.x * blockDim.x) out[k] = src[k];
     }
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t n_blocks = gridDim.x * gridDim.y;
+        if (atomicAdd(count, 1u) == n_blocks - 1) {
+            atomicExch(count, 0u);   // ready for the next gather on this stream
+            __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
 }
 
 int ReadBatch::flush() {
     if (items.empty()) return 0;
     char *pin = (char *)pinned_buf(ctx, total);
     if (!pin) { snprintf(ctx->err, sizeof ctx->err, "pinned allocation failed"); return 1; }
-    bool small = items.size() > 1 && items.size() <= GATHER_MAX && total < ((size_t)1 << 24);
+    bool small = items.size() <= GATHER_MAX && total < ((size_t)1 << 24);
     void *dpin = nullptr;
     if (small && hipHostGetDevicePointer(&dpin, pin, 0) != hipSuccess) small = false;
     if (small) {
@@ -198,11 +223,22 @@ int ReadBatch::flush() {
         size_t biggest = 0;
         for (int i = 0; i < g.n; i++) { g.src[i] = (const uint8_t *)items[i].dev; g.bytes[i] = (uint32_t)items[i].bytes; g.off[i] = (uint32_t)items[i].off; if (items[i].bytes > biggest) biggest = items[i].bytes; }
         unsigned bx = (unsigned)((biggest / 4 + 255) / 256); if (bx < 1) bx = 1; if (bx > 64) bx = 64;
-        hipLaunchKernelGGL(k_gather, dim3(bx, g.n), dim3(256), 0, ctx->stream, g, (uint8_t *)dpin);
+        uint32_t seq = ++ctx->gather_seq;
+        if (seq == 0) seq = ++ctx->gather_seq;
+        volatile uint32_t *hflag = ctx->gather_flag;   // sequence numbers only grow: no reset needed between gathers
+        hipLaunchKernelGGL(k_gather, dim3(bx, g.n), dim3(256), 0, ctx->stream, g, (uint8_t *)dpin, ctx->gather_count, ctx->gather_flag_dev, seq);
         KCHK();
-    } else
+        // poll; if the number does not arrive (a fault in an earlier kernel), the stream synchronisation reports why
+        bool seen = false;
+        for (uint64_t spin = 0; spin < ((uint64_t)1 << 26); spin++) {
+            if (__atomic_load_n((const uint32_t *)hflag, __ATOMIC_ACQUIRE) == seq) { seen = true; break; }
+            if ((spin & 0xFFFFF) == 0xFFFFF && hipStreamQuery(ctx->stream) != hipErrorNotReady) break;
+        }
+        if (!seen) HIPCHK(hipStreamSynchronize(ctx->stream));
+    } else {
         for (auto &it : items) HIPCHK(hipMemcpyAsync(pin + it.off, it.dev, it.bytes, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipStreamSynchronize(ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+    }
     for (auto &it : items) memcpy(it.host, pin + it.off, it.bytes);
     items.clear(); total = 0;
     return 0;

@@ -19,10 +19,14 @@ struct mfk_ctx {
     hipStream_t stream;
     hipStream_t stream2;            // side stream for kernel chains that do not depend on each other (consensus stage)
     hipEvent_t ev0, ev1;
-    hipEvent_t ev_fork, ev_join;
+    hipStream_t stream3;            // second side stream (pairflanks: spanning reads next to the direct repeats)
+    hipEvent_t ev_fork, ev_join, ev_join3;
     double last_ms;
     std::vector<Chunk> chunks;      // device arena
     void *pinned; size_t pinned_cap;
+    uint32_t *gather_count;         // device word: blocks of the current gather that have finished (the last one resets it)
+    uint32_t *gather_flag, *gather_flag_dev;   // pinned word of its own (host / device address) the sequence number lands in
+    uint32_t gather_seq;            // sequence number the gather kernel publishes behind its data; the host polls for it
     char err[1024];
     // optional per-kernel timing (mfk_profile_enable): HIP events around every launch on the ctx stream
     bool prof_on;

@@ -280,6 +280,92 @@ __global__ void k_kept_keys(FlankDev F, const uint32_t *order, const uint32_t *c
     vals[o] = c;
 }
 
+// assign_pairs for up to PA_MAX candidates in ONE launch of one workgroup (a deep isolate has a few dozen candidates, and
+// five launches -- two device-wide sorts among them -- cost more than the work): stable sort by the assign key (rank =
+// number of candidates that sort before), the greedy exclusion rounds of k_assign, then the kept pairs ranked by
+// (contig, pos_5p, pos_3p).  Same results as the sort / k_assign / scan / k_kept_keys / sort chain below.
+#define PA_MAX 1024
+#define PA_SMALL 256   // the host takes this path up to here: the rank sorts are quadratic, 1000 candidates are faster through rocPRIM
+__global__ __launch_bounds__(PA_MAX) void k_assign_small(FlankDev F, const uint64_t *keys, const uint32_t *c5, const uint32_t *c3, uint32_t n, uint32_t nF,
+                                                         const int32_t *contig_rank, uint32_t *best5, uint32_t *best3, uint8_t *used5, uint8_t *used3,
+                                                         uint32_t *kept, uint32_t *n_kept) {
+    __shared__ uint64_t sk[PA_MAX];
+    __shared__ uint32_t order[PA_MAX], kc[PA_MAX];
+    __shared__ uint8_t state[PA_MAX];
+    __shared__ uint32_t sh[16];
+    __shared__ int undecided;
+    const uint32_t t = threadIdx.x;
+    const uint64_t key = t < n ? keys[t] : ~0ull;
+    sk[t] = key;
+    state[t] = 0;
+    for (uint32_t i = t; i < nF; i += blockDim.x) { best5[i] = 0xFFFFFFFFu; best3[i] = 0xFFFFFFFFu; used5[i] = 0; used3[i] = 0; }
+    __syncthreads();
+    if (t < n) {
+        uint32_t rank = 0;
+        for (uint32_t q = 0; q < n; q++) { const uint64_t kq = sk[q]; rank += (kq < key || (kq == key && q < t)) ? 1u : 0u; }
+        order[rank] = t;
+    }
+    __syncthreads();
+    // greedy exclusion (pairflanks.py:233-245): p = sorted position
+    const uint32_t p = t;
+    uint32_t a = 0, b = 0, c = 0;
+    if (p < n) { c = order[p]; a = c5[c]; b = c3[c]; }
+    for (uint32_t round = 0; round <= n; round++) {
+        if (t == 0) undecided = 0;
+        __syncthreads();
+        if (p < n && !state[p]) {
+            if (used5[a] || used3[b]) state[p] = 2;
+            else { atomicMin(&best5[a], p); atomicMin(&best3[b], p); undecided = 1; }
+        }
+        __syncthreads();
+        if (!undecided) break;
+        if (p < n && !state[p] && best5[a] == p && best3[b] == p) { state[p] = 1; used5[a] = 1; used3[b] = 1; }
+        __syncthreads();
+        if (p < n && !state[p]) { best5[a] = 0xFFFFFFFFu; best3[b] = 0xFFFFFFFFu; }
+        __syncthreads();
+    }
+    __syncthreads();
+    // kept pairs in sorted_pairs order, then ranked by sort_values(['contig','pos_5p','pos_3p']) (pairflanks.py:248)
+    const uint32_t flag = (p < n && state[p] == 1) ? 1u : 0u;
+    uint32_t nk;
+    const uint32_t o = block_excl_scan(flag, sh, &nk);
+    __syncthreads();
+    if (flag) {
+        uint32_t diff = (uint32_t)(F.pos[a] - F.pos[b]);
+        if (diff > 0xFFFF) diff = 0xFFFF;
+        sk[o] = ((uint64_t)(uint32_t)contig_rank[F.contig[a]] << 48) | ((uint64_t)(uint32_t)(F.pos[a] + 1) << 16) | (uint64_t)(0xFFFFu - diff);
+        kc[o] = c;
+    }
+    __syncthreads();
+    if (t < nk) {
+        const uint64_t k2 = sk[t];
+        uint32_t rank = 0;
+        for (uint32_t q = 0; q < nk; q++) { const uint64_t kq = sk[q]; rank += (kq < k2 || (kq == k2 && q < t)) ? 1u : 0u; }
+        kept[rank] = kc[t];
+    }
+    if (t == 0) *n_kept = nk;
+}
+
+// k_pair_finish + scan + k_pair_final for up to PA_MAX kept pairs, one workgroup
+__global__ __launch_bounds__(PA_MAX) void k_pair_finish_small(DevParams P, FlankDev F, const uint32_t *kept, const uint32_t *c5, const uint32_t *c3, const uint32_t *n_kept, const int32_t *ir,
+                                                              const uint32_t *span_all, uint32_t *fin, uint32_t *fin_span, uint32_t *n_fin, uint32_t *pstats) {
+    __shared__ uint32_t sh[16];
+    const uint32_t k = threadIdx.x, nk = *n_kept;
+    uint32_t flag = 0, c = 0, cnt = 0;
+    if (k < nk) {
+        c = kept[k]; cnt = span_all[c];
+        const double total = (double)((int64_t)F.total[c5[c]] + (int64_t)F.total[c3[c]]) / 2;
+        const double prop = (double)cnt / total;
+        flag = prop < P.maxjsp ? 1u : 0u;   // filter_junction_spanning pairflanks.py:421-431 (float64, strict <, quirk P9)
+        if (ir[6 * c]) atomicAdd(&pstats[2], 1u);
+        if (cnt > 0) atomicAdd(&pstats[3], 1u);
+    }
+    uint32_t nf;
+    const uint32_t o = block_excl_scan(flag, sh, &nf);
+    if (flag) { fin[o] = c; fin_span[o] = cnt; }
+    if (threadIdx.x == 0) *n_fin = nf;
+}
+
 // ---- count_insertion_spanning_reads -------------------------------------------------------------------------------------
 __device__ __forceinline__ bool d_spans(const DevReads &R, const DevParams &P, int64_t r, uint8_t f, int32_t pos3, int32_t pos5) {
     // pairflanks.py:381-383, insertion_spanning_length = 10 (quirk P7)
@@ -606,17 +692,19 @@ extern "C" int mfk_pairflanks(mfk_ctx *ctx, const mfk_reads *reads, const mfk_pa
         const unsigned pb = nblocks(nP, 256);
         PROF_LAUNCH(k_pair_window<true>, dim3(fb), dim3(256), 0, st, F, P.maxdr, sorted, (uint32_t *)nullptr, (const uint32_t *)coff, c5, c3);
         KCHK();
-        // Side stream: spanning reads and direct repeats of every candidate (they depend on the positions only).  Main
-        // stream: inverted repeats -> assign_pairs.  (Timing events of a launch go to the stream of that launch.)
-        hipStream_t sb = ctx->stream2;
+        // Side streams: direct repeats and spanning reads of every candidate (they depend on the positions only), each on
+        // its own stream.  Main stream: inverted repeats -> assign_pairs.  (Timing events of a launch go to the stream of that launch.)
+        hipStream_t sb = ctx->stream2, sc = ctx->stream3;
         HIPCHK(hipEventRecord(ctx->ev_fork, st));
         HIPCHK(hipStreamWaitEvent(sb, ctx->ev_fork, 0));
-        PROF_LAUNCH(k_spanning, dim3(nP), dim3(nP >= 2048 ? 256 : 1024), 0, sb, R, P, F, (const uint32_t *)c5, (const uint32_t *)c3, nP, span_all);
-        KCHK();
+        HIPCHK(hipStreamWaitEvent(sc, ctx->ev_fork, 0));
         PROF_LAUNCH(k_direct_repeats, dim3(nP), dim3(nP >= 2048 ? 256 : 1024), 0, sb, R, F, nP, (const uint32_t *)c5, (const uint32_t *)c3,
                     genome, (const int64_t *)d_goff, dr, stride, meta);
         KCHK();
         HIPCHK(hipEventRecord(ctx->ev_join, sb));
+        PROF_LAUNCH(k_spanning, dim3(nP), dim3(nP >= 2048 ? 256 : 1024), 0, sc, R, P, F, (const uint32_t *)c5, (const uint32_t *)c3, nP, span_all);
+        KCHK();
+        HIPCHK(hipEventRecord(ctx->ev_join3, sc));
         if (ir_tab.empty()) {
             PROF_LAUNCH(k_inverted_repeat, dim3(nP), dim3(64), 0, st, F, (const uint32_t *)c5, (const uint32_t *)c3, nP, ir, keys, vals);
             KCHK();
@@ -627,21 +715,34 @@ extern "C" int mfk_pairflanks(mfk_ctx *ctx, const mfk_reads *reads, const mfk_pa
             PROF_LAUNCH(k_ir_lookup, dim3(pb), dim3(256), 0, st, F, (const uint32_t *)c5, (const uint32_t *)c3, nP, (const int32_t *)d_tab_ir, (uint32_t)(ir_tab.size() / 7), ir, keys, vals, d_pstats + 15);
             KCHK();
         }
+        const uint32_t *nK_p = kscan + nP;
+        if (nP <= PA_SMALL) {
+            // few candidates (a deep isolate): assign_pairs in one launch, the junction filter in another
+            PROF_LAUNCH(k_assign_small, dim3(1), dim3(PA_MAX), 0, st, F, (const uint64_t *)keys, (const uint32_t *)c5, (const uint32_t *)c3, nP, nF, (const int32_t *)d_rank,
+                        best5, best3, used5, used3, kept, kscan + nP);
+            KCHK();
+            HIPCHK(hipStreamWaitEvent(st, ctx->ev_join, 0));
+            HIPCHK(hipStreamWaitEvent(st, ctx->ev_join3, 0));
+            PROF_LAUNCH(k_pair_finish_small, dim3(1), dim3(PA_MAX), 0, st, P, F, (const uint32_t *)kept, (const uint32_t *)c5, (const uint32_t *)c3, nK_p, (const int32_t *)ir,
+                        (const uint32_t *)span_all, fin, fin_span, jscan + nP, d_pstats);
+            KCHK();
+        } else {
         if (int rc = dev_sort_pairs64(ctx, keys, keys2, vals, order, nP, 0, 56)) return rc;
         PROF_LAUNCH(k_assign, dim3(1), dim3(1024), 0, st, (const uint32_t *)order, (const uint32_t *)c5, (const uint32_t *)c3, nP, nF, best5, best3, used5, used3, state, kflag);
         KCHK();
         if (int rc = dev_excl_scan32(ctx, kflag, kscan, nP)) return rc;
-        const uint32_t *nK_p = kscan + nP;
         PROF_LAUNCH(k_kept_keys, dim3(pb), dim3(256), 0, st, F, (const uint32_t *)order, (const uint32_t *)c5, (const uint32_t *)c3, (const uint8_t *)state, (const uint32_t *)kscan, nP, (const int32_t *)d_rank, kk, kv);
         KCHK();
         if (int rc = dev_sort_pairs64(ctx, kk, kk2, kv, kept, nP, 0, 64)) return rc;
         HIPCHK(hipStreamWaitEvent(st, ctx->ev_join, 0));
+        HIPCHK(hipStreamWaitEvent(st, ctx->ev_join3, 0));
         PROF_LAUNCH(k_pair_finish, dim3(pb), dim3(256), 0, st, P, F, (const uint32_t *)kept, (const uint32_t *)c5, (const uint32_t *)c3, nK_p, (const int32_t *)ir,
                     (const uint32_t *)span_all, spanning, jflag, d_pstats);
         KCHK();
         if (int rc = dev_excl_scan32(ctx, jflag, jscan, nP)) return rc;
         PROF_LAUNCH(k_pair_final, dim3(pb), dim3(256), 0, st, (const uint32_t *)kept, nK_p, (const uint32_t *)jflag, (const uint32_t *)jscan, (const uint32_t *)spanning, fin, fin_span);
         KCHK();
+        }
         HIPCHK(hipEventRecord(ctx->ev1, st));
         h_fin.resize(nP); h_span.resize(nP); h_meta.resize(3 * (size_t)nP); h_dr.resize((size_t)nP * stride);
         h_c5.resize(nP); h_c3.resize(nP); h_ir.resize(6 * (size_t)nP);
