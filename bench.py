@@ -65,6 +65,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-insertions", type=int, default=20)
     ap.add_argument("--dump-profile", default=None, help="write the per-kernel table to this file")
+    ap.add_argument("--isolates", type=int, default=12, help="isolates per GPU of --config C4_ecoli_batch (96 over 8 GPUs)")
     args = ap.parse_args()
 
     import numpy as np
@@ -86,19 +87,42 @@ def main():
     from mustache_amd.synth import CONFIGS, synth_packed
 
     t0 = time.time()
-    packed, genome, truth = synth_packed(**CONFIGS[args.config], seed=100 + rank)
+    batch = None
+    if args.config == "C4_ecoli_batch":
+        # BASELINE configs[3]: a batch of E. coli isolates per GPU (96 over the 8 GPUs of a node), run as ONE call per stage
+        # (mustache_amd/cohort.py); the per-rank candidate-site tables are merged by the all-gather
+        from mustache_amd import cohort
+        cfg = dict(CONFIGS["C1_ecoli_100x"])
+        packs, genomes, truths = [], [], []
+        for i in range(args.isolates):
+            p_, g_, t_ = synth_packed(**cfg, seed=1000 * (rank + 1) + i)
+            packs.append(p_); genomes.append(g_); truths.append(t_)
+        batch = cohort.concat_samples(packs, ["isolate%d" % (rank * args.isolates + i) for i in range(args.isolates)])
+        packed = batch.packed
+        truth = [t for ts in truths for t in ts]
+        g, goff = cohort.batch_genome(batch, genomes)
+        ranks = cohort.batch_contig_ranks(batch)
+        cpu_args = (packs[0], genomes[0], truths[0])
+    else:
+        cfg = dict(CONFIGS[args.config])
+        packed, genome, truth = synth_packed(**cfg, seed=100 + rank)
+        g, goff = pfh.genome_arrays(genome, packed.contig_names)
+        ranks = pfh.contig_ranks(packed.contig_names)
+        cpu_args = (packed, genome, truth)
     gen_s = time.time() - t0
     hip = lib.load(local_rank)
     params = lib.make_params()
     reads = device_reads(hip, packed, device)
-    g, goff = pfh.genome_arrays(genome, packed.contig_names)
     g_dev = torch.from_numpy(g).to(device)
-    ranks = pfh.contig_ranks(packed.contig_names)
 
     def step():
         ff = hip.run_findflanks(reads, params)
         pf = hip.run_pairflanks(reads, params, ff["flanks"], ff["seqs"], ranks, g_dev, goff)
-        if world > 1:
+        if batch is not None:
+            per_sample = cohort.split_flanks(batch, ff)          # per-isolate tables, as the per-sample runs give them
+            if world > 1:
+                cohort.cohort_table(per_sample, sample_numbers=[rank * args.isolates + i for i in range(args.isolates)], device=device)
+        elif world > 1:
             allgather_flanks(ff["flanks"], ff["seqs"], device)
         return ff, pf
 
@@ -149,8 +173,8 @@ def main():
         flags = packed.flags
         meta = {"n_reads": packed.n_reads, "clipped_reads": int(((flags & 15) != 0).sum()),
                 "events": int(ff["stats"][10]),
-                "join_visits": int(ff["stats"][3]) * 3 * int(CONFIGS[args.config]["coverage"]),
-                "pairs": int(pf["stats"][1]), "coverage": int(CONFIGS[args.config]["coverage"])}
+                "join_visits": int(ff["stats"][3]) * 3 * int(cfg["coverage"]),
+                "pairs": int(pf["stats"][1]), "coverage": int(cfg["coverage"])}
         # per-kernel rows (name, avg ms per launch, launches, total ms).  Shares and the device total come from the fully
         # bracketed warm-up steps; the durations of the watched kernels come from the timed region.
         full_table = sorted(((nm, ms / max(calls, 1), calls, ms) for nm, (ms, calls) in full.items()), key=lambda r: -r[3])
@@ -198,13 +222,14 @@ def main():
                 fh.write("device ms per step (sum of kernels, bracketed steps) %.4f, wall ms per step (timed) %.4f\n" % (dev_ms or 0.0, ms_per_step))
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
-            cpu = cpu_baseline(packed, genome, truth, params, args.cpu_sample_insertions)
+            cpu = cpu_baseline(cpu_args[0], cpu_args[1], cpu_args[2], params, args.cpu_sample_insertions)
         out = {"metric": "aligned reads/sec (findflanks+pairflanks, whole node)", "value": round(value, 1), "unit": "reads/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8/int32 (+f64 ratio tests)",
                "data": "synthetic",
-               "config": {"workload": args.config, "reads_per_gpu": packed.n_reads, "genome_bp": int(sum(CONFIGS[args.config]["contig_lens"])),
-                          "coverage": CONFIGS[args.config]["coverage"], "read_length": 150, "insertions": len(truth),
+               "config": {"workload": args.config, "reads_per_gpu": packed.n_reads, "genome_bp": int(sum(cfg["contig_lens"])) * (args.isolates if batch is not None else 1),
+                          "isolates_per_gpu": args.isolates if batch is not None else 1,
+                          "coverage": cfg["coverage"], "read_length": 150, "insertions": len(truth),
                           "flank_rows": int(len(ff["flanks"])), "pairs": int(len(pf["pairs"])), "sharding": "sample per GPU",
                           "device_ms_per_step": round(dev_ms, 4) if dev_ms else None, "generate_s": round(gen_s, 1)},
                "roofline": roofline, "cpu_baseline": cpu}
