@@ -3,7 +3,7 @@
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--config NAME]
 
-A step is one pass of the hot path over one resident batch: ``mfk_findflanks`` (read scan -> sites -> filters -> site x read
+A step is one pass of the hot path over one resident batch (``mfk_flankpairs``): ``mfk_findflanks`` (read scan -> sites -> filters -> site x read
 join -> consensus) followed by ``mfk_pairflanks`` (window join, inverted repeats, assignment, spanning reads, direct
 repeats) on the packed alignments that already sit in HBM.  The workload is synthetic simulated-insertion alignments
 (mustache_amd/synth.py); the default is BASELINE.json configs[1], "S. aureus single isolate at 1000x" (2.8 Mb, 2x150 bp,
@@ -116,8 +116,7 @@ def main():
     g_dev = torch.from_numpy(g).to(device)
 
     def step():
-        ff = hip.run_findflanks(reads, params)
-        pf = hip.run_pairflanks(reads, params, ff["flanks"], ff["seqs"], ranks, g_dev, goff)
+        ff, pf = hip.run_flankpairs(reads, params, ranks, g_dev, goff)   # mfk_findflanks then mfk_pairflanks inside one library call
         if batch is not None:
             per_sample = cohort.split_flanks(batch, ff)          # per-isolate tables, as the per-sample runs give them
             if world > 1:

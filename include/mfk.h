@@ -168,6 +168,15 @@ int mfk_pairflanks_fetch(mfk_ctx *ctx, mfk_pair *pairs, char *strs, int64_t *sta
 /* pairflanks stats[0]: candidate pairs (pair_all_nearby_flanks), [1]: assigned, [2]: with IR, [3]: spanning_count>0,
  * [4]: after filter_junction_spanning. */
 
+/* findflanks followed by pairflanks on the same resident reads in ONE call: what the workflow does per sample with two
+ * processes and a TSV in between (Snakefile:64-109: rule findflanks, then rule pairflanks on its output).  The flank
+ * table of the first stage goes to the second without leaving the library; both results are then fetched with
+ * mfk_findflanks_fetch / mfk_pairflanks_fetch exactly as after the separate calls, and are the same bytes.  The reads
+ * must carry the sequence pool both stages need (pool = clipped reads and the reads over direct-repeat windows, or all). */
+int mfk_flankpairs(mfk_ctx *ctx, const mfk_reads *reads, const mfk_params *params, const int32_t *h_contig_rank,
+                   const uint8_t *genome, const int64_t *h_genome_off, int64_t *n_sites, int64_t *n_flanks,
+                   int64_t *seq_bytes, int64_t *n_pairs, int64_t *str_bytes);
+
 /* Inverted-repeat results from an external detector for the NEXT mfk_pairflanks call on this ctx -- the escape hatch
  * for sites that have EMBOSS einverted, which is what the reference runs (embosstools.py:8-26, pairflanks.py:172-219).
  * One row per candidate pair (pair_all_nearby_flanks, pairflanks.py:138-169): flank row indices and ir = has_ir,

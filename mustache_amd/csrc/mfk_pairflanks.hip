@@ -802,6 +802,21 @@ extern "C" int mfk_pairflanks_fetch(mfk_ctx *ctx, mfk_pair *pairs, char *strs, i
     return 0;
 }
 
+// both stages in one call: the host flank table of the first feeds the second directly (no caller in between)
+extern "C" int mfk_flankpairs(mfk_ctx *ctx, const mfk_reads *reads, const mfk_params *params, const int32_t *h_contig_rank, const uint8_t *genome,
+                              const int64_t *h_genome_off, int64_t *n_sites, int64_t *n_flanks, int64_t *seq_bytes, int64_t *n_pairs, int64_t *str_bytes) {
+    if (!ctx) return 1;
+    if (n_pairs) *n_pairs = 0;
+    if (str_bytes) *str_bytes = 0;
+    if (int rc = mfk_findflanks(ctx, reads, params, MFK_STAGE_ALL, n_sites, n_flanks, seq_bytes)) return rc;
+    const double ms_find = ctx->last_ms;
+    ctx->pairs.clear(); ctx->strs.clear();
+    memset(ctx->pstats, 0, sizeof ctx->pstats);
+    int rc = mfk_pairflanks(ctx, reads, params, ctx->flanks.data(), ctx->seqs.data(), (int64_t)ctx->flanks.size(), h_contig_rank, genome, h_genome_off, n_pairs, str_bytes);
+    ctx->last_ms += ms_find;
+    return rc;
+}
+
 // External inverted-repeat results for the NEXT mfk_pairflanks call on this ctx (e.g. parsed from EMBOSS einverted, which
 // is what the reference runs: embosstools.py:8-26, pairflanks.py:172-219).  One row per candidate pair.
 extern "C" int mfk_pairflanks_set_ir(mfk_ctx *ctx, int64_t n, const int32_t *index_5p, const int32_t *index_3p, const int32_t *ir) {

@@ -116,6 +116,8 @@ class Binding:
         f("pairflanks", C.c_int, [_p, C.POINTER(MfkReads), C.POINTER(MfkParams), _p, _p, C.c_int64, _p, _p, _p,
                                   C.POINTER(C.c_int64), C.POINTER(C.c_int64)])
         f("pairflanks_fetch", C.c_int, [_p, _p, _p, _p])
+        if hasattr(self.so, prefix + "flankpairs"):
+            f("flankpairs", C.c_int, [_p, C.POINTER(MfkReads), C.POINTER(MfkParams), _p, _p, _p] + [C.POINTER(C.c_int64)] * 5)
         f("ir_detect", C.c_int, [_p, _p, _p, C.c_int64, _p])
         f("recall", C.c_int, [_p, C.POINTER(MfkReads), C.POINTER(MfkParams), _p, _p, C.c_int64, _p])
         f("overlap", C.c_int, [_p, _p, _p, _p, _p, C.c_int64, _p])
@@ -199,6 +201,26 @@ class Binding:
         stats = np.zeros(N_STATS, dtype=np.int64)
         self._check(self.pairflanks_fetch(self.ctx, pairs.ctypes.data, strs.ctypes.data, stats.ctypes.data))
         return {"pairs": pairs, "strs": strs[:sb.value].tobytes(), "stats": stats}
+
+    def run_flankpairs(self, reads, params, contig_rank, genome, genome_off):
+        """findflanks + pairflanks in one library call (mfk_flankpairs) -> (findflanks result, pairflanks result), the
+        same dicts ``run_findflanks`` / ``run_pairflanks`` return."""
+        rank = np.ascontiguousarray(contig_rank, dtype=np.int32)
+        goff = np.ascontiguousarray(genome_off, dtype=np.int64)
+        ns, nf, sb, npairs, pb = (C.c_int64(0) for _ in range(5))
+        self._check(self.flankpairs(self.ctx, C.byref(reads), C.byref(params), rank.ctypes.data, _ptr(genome), goff.ctypes.data,
+                                    C.byref(ns), C.byref(nf), C.byref(sb), C.byref(npairs), C.byref(pb)))
+        sites = np.zeros(ns.value, dtype=SITE_DTYPE)
+        flanks = np.zeros(nf.value, dtype=FLANK_DTYPE)
+        seqs = np.zeros(max(sb.value, 1), dtype=np.uint8)
+        stats = np.zeros(N_STATS, dtype=np.int64)
+        self._check(self.findflanks_fetch(self.ctx, sites.ctypes.data, flanks.ctypes.data, seqs.ctypes.data, stats.ctypes.data))
+        pairs = np.zeros(npairs.value, dtype=PAIR_DTYPE)
+        strs = np.zeros(max(pb.value, 1), dtype=np.uint8)
+        pstats = np.zeros(N_STATS, dtype=np.int64)
+        self._check(self.pairflanks_fetch(self.ctx, pairs.ctypes.data, strs.ctypes.data, pstats.ctypes.data))
+        return ({"sites": sites, "flanks": flanks, "seqs": seqs[:sb.value].tobytes(), "stats": stats},
+                {"pairs": pairs, "strs": strs[:pb.value].tobytes(), "stats": pstats})
 
     def set_pair_ir(self, index_5p, index_3p, ir):
         """Inverted-repeat results of an external detector for the next run_pairflanks (ir: [n, 5] has, a1s, a1e, a2s, a2e)."""

@@ -1080,3 +1080,12 @@ int mfko_pairflanks_set_ir(void *c, int64_t n, const int32_t *index_5p, const in
     C->n_ir_ov = n;
     return 0;
 }
+
+/* findflanks then pairflanks on its table (see mfk_flankpairs): the oracle simply runs the two restatements in a row */
+int mfko_flankpairs(void *c, const mfk_reads *R, const mfk_params *P, const int32_t *contig_rank, const uint8_t *genome,
+                    const int64_t *genome_off, int64_t *n_sites, int64_t *n_flanks, int64_t *seq_bytes, int64_t *n_pairs, int64_t *str_bytes) {
+    octx *C = (octx *)c;
+    int rc = mfko_findflanks(c, R, P, MFK_STAGE_ALL, n_sites, n_flanks, seq_bytes);
+    if (rc) return rc;
+    return mfko_pairflanks(c, R, P, C->flanks, C->seqs, C->n_flanks, contig_rank, genome, genome_off, n_pairs, str_bytes);
+}

@@ -1,6 +1,7 @@
-"""One synthetic BASELINE config through the HIP library and the CPU oracle, with timings (run on the GPU box).
+"""Full-size parity run (test infrastructure, not collected by pytest): one synthetic BASELINE config through the HIP
+library and the CPU oracle, with timings (run on the GPU box; C5 needs ~100 s of oracle time, too long for the suite).
 
-    python scripts/run_config.py --config C5_meta_50mb --seed 7 [--out gpurun_out/c5.json]
+    python tests/run_config.py --config C5_meta_50mb --seed 7 [--out gpurun_out/c5.json]
 """
 import argparse
 import json

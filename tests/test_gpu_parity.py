@@ -4,6 +4,8 @@ import numpy as np
 import pytest
 
 from mustache_amd import lib
+from mustache_amd import pairflanks as pfh
+from mustache_amd.findflanks import device_reads
 from mustache_amd.pack import pack_reads
 from mustache_amd.simulate import simulate_readset
 from tests import util
@@ -150,3 +152,25 @@ def test_overlap_golden_bit_exact(hip, oracle):
     assert np.array_equal(hip.run_overlap(s5, s3), oracle.run_overlap(s5, s3))
     with pytest.raises(lib.MfkError):
         hip.run_overlap(["ACGT"], [""])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["sim_a", "sim_c", "quirks"])
+def test_flankpairs_one_call_equals_two(hip, name):
+    """mfk_flankpairs = mfk_findflanks followed by mfk_pairflanks on its table: the same bytes from both."""
+    import torch
+    case = util.load_json(name)
+    rs = util.case_readset(case)
+    packed = pack_reads(rs.contigs, rs, pool="all")
+    R = device_reads(hip, packed, "cuda:0")
+    params = lib.make_params(**dict(case["findflanks_params"], **case["pairflanks_params"]))
+    g, goff = pfh.genome_arrays(case["genome"], packed.contig_names)
+    gd = torch.from_numpy(g).to("cuda:0")
+    ranks = pfh.contig_ranks(packed.contig_names)
+    ff = hip.run_findflanks(R, params)
+    pf = hip.run_pairflanks(R, params, ff["flanks"], ff["seqs"], ranks, gd, goff)
+    ff2, pf2 = hip.run_flankpairs(R, params, ranks, gd, goff)
+    assert ff2["flanks"].tobytes() == ff["flanks"].tobytes() and ff2["seqs"] == ff["seqs"] and ff2["sites"].tobytes() == ff["sites"].tobytes()
+    assert list(ff2["stats"]) == list(ff["stats"])
+    assert pf2["pairs"].tobytes() == pf["pairs"].tobytes() and pf2["strs"] == pf["strs"] and list(pf2["stats"]) == list(pf["stats"])
+    assert len(pf["pairs"]) > 0

@@ -3,6 +3,7 @@
 import numpy as np
 import pytest
 
+from mustache_amd import lib
 from mustache_amd.pack import pack_reads
 from tests import util
 
@@ -75,3 +76,20 @@ def test_oracle_reproduces_reference_overlap(oracle):
     assert sum(len(e["overlap_tsv"].splitlines()) > 1 for e in vec["tables"]) >= 5
     with pytest.raises(Exception):
         oracle.run_overlap(["ACGT"], [""])
+
+
+def test_flankpairs_one_call_equals_two_oracle(oracle):
+    """The fused entry point (mfk_flankpairs) against the two calls, through the oracle's copy of the signature."""
+    from mustache_amd import pairflanks as pfh
+    case = util.load_json("sim_b")
+    rs = util.case_readset(case)
+    packed = pack_reads(rs.contigs, rs, pool="all")
+    R = oracle.reads(packed)
+    params = lib.make_params(**dict(case["findflanks_params"], **case["pairflanks_params"]))
+    g, goff = pfh.genome_arrays(case["genome"], packed.contig_names)
+    ranks = pfh.contig_ranks(packed.contig_names)
+    ff = oracle.run_findflanks(R, params)
+    pf = oracle.run_pairflanks(R, params, ff["flanks"], ff["seqs"], ranks, g, goff)
+    ff2, pf2 = oracle.run_flankpairs(R, params, ranks, g, goff)
+    assert ff2["flanks"].tobytes() == ff["flanks"].tobytes() and ff2["seqs"] == ff["seqs"]
+    assert pf2["pairs"].tobytes() == pf["pairs"].tobytes() and pf2["strs"] == pf["strs"] and len(pf["pairs"]) > 0
