@@ -244,13 +244,44 @@ int ReadBatch::flush() {
     return 0;
 }
 
+// fills of a phase: [0, n_zero) 16-byte pieces of zeros, then ones up to n_total -- one launch for both groups (a
+// hipMemsetAsync each costs a launch of its own plus more host time than a kernel launch)
+__global__ __launch_bounds__(256) void k_fill2(uint4 *p, size_t n_zero, size_t n_total) {
+    const uint4 z = make_uint4(0u, 0u, 0u, 0u), o = make_uint4(~0u, ~0u, ~0u, ~0u);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_total; i += (size_t)gridDim.x * blockDim.x) p[i] = i < n_zero ? z : o;
+}
+
+static int fill_launch(mfk_ctx *ctx, char *p, size_t zero_bytes, size_t one_bytes) {
+    const size_t n_zero = zero_bytes / 16, n_total = (zero_bytes + one_bytes) / 16;   // group sizes are multiples of 256
+    if (!n_total) return 0;
+    size_t blocks = (n_total + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(k_fill2, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, (uint4 *)p, n_zero, n_total);
+    KCHK();
+    return 0;
+}
+
 int FillGroup::commit() {
     if (reqs.empty()) return 0;
     char *p = (char *)arena_alloc(ctx, total);
     if (!p) return 1;
     for (auto &r : reqs) *r.out = p + r.off;
+    if (value == 0) return fill_launch(ctx, p, total, 0);
+    if (value == 0xFF) return fill_launch(ctx, p, 0, total);
     HIPCHK(hipMemsetAsync(p, value, total, ctx->stream));
     return 0;
+}
+
+// a zero group and a 0xFF group in one arena block and one launch
+int fill_commit2(FillGroup &z, FillGroup &f) {
+    mfk_ctx *ctx = z.ctx;
+    if (z.reqs.empty()) return f.commit();
+    if (f.reqs.empty()) return z.commit();
+    char *p = (char *)arena_alloc(ctx, z.total + f.total);
+    if (!p) return 1;
+    for (auto &r : z.reqs) *r.out = p + r.off;
+    for (auto &r : f.reqs) *r.out = p + z.total + r.off;
+    return fill_launch(ctx, p, z.total, f.total);
 }
 
 void *pinned_buf(mfk_ctx *ctx, size_t bytes) {

@@ -92,46 +92,50 @@ __device__ __forceinline__ int d_lcp(const uint8_t *a, int la, const uint8_t *b,
 }
 
 // ---- words ------------------------------------------------------------------------------------------------------
-// one block per active site: which of its events start a word (first read of its query name on a kept side)
-__global__ __launch_bounds__(256) void k_word_flags(ConsensusIO io, uint32_t *flag) {
-    const uint32_t k = blockIdx.x;
-    if (k >= io.n_act) return;
-    const uint32_t st = io.act_st[k];
-    if (!(st & 4)) return;
-    const uint32_t s = io.act_site[k], mid = io.site_ev_mid[s];
-    for (uint32_t e = io.site_ev_begin[s] + threadIdx.x; e < io.site_ev_end[s]; e += blockDim.x) {
-        const uint32_t side = e >= mid ? 1u : 0u;
-        if ((st & (1u << side)) && (io.ev_info[e] & 2)) flag[e] = 1;
-    }
-}
-
-__global__ void k_job_meta(ConsensusIO io, const uint32_t *wid, Jobs J, CMeta *meta) {
+// words of a job = the first reads of the distinct query names of its site-side, i.e. the events with info bit 2: their
+// number is the site's distinct-name count (k_site_accumulate), so the word ranges come from a scan over the job slots
+// and no flag array / scan over all events is needed
+__global__ void k_job_meta(ConsensusIO io, Jobs J, CMeta *meta) {
     uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= J.n) return;
     uint32_t k = j >> 1, side = j & 1;
     uint32_t st = io.act_st[k];
-    uint32_t w0 = 0, R = 0;
-    if ((st & 4) && (st & (1u << side))) {
-        uint32_t s = io.act_site[k];
-        uint32_t b = side == 0 ? io.site_ev_begin[s] : io.site_ev_mid[s];
-        uint32_t e = side == 0 ? io.site_ev_mid[s] : io.site_ev_end[s];
-        w0 = wid[b]; R = wid[e] - wid[b];
-    }
-    J.w0[j] = w0; J.R[j] = R; J.nl[j] = 0; J.best[j] = 0xFFFFFFFFu;
+    uint32_t R = 0;
+    if ((st & 4) && (st & (1u << side))) R = io.act_cnt2[j];
+    J.R[j] = R; J.nl[j] = 0; J.best[j] = 0xFFFFFFFFu;
     J.adj_words[j] = R * ((R + 31) >> 5);
     if (R) atomicMax(&meta->max_R, R);
 }
 
 // first / second read of every word (combine_softclip_seq_quals_*: one or two reads per name, findflanks.py:932-1027);
-// one block per active site
-__global__ __launch_bounds__(256) void k_word_reads(DevReads R, DevParams P, ConsensusIO io, const uint32_t *wflag, const uint32_t *wid, Words W) {
+// one block per active site.  Phase 1 numbers the word-starting events of each kept side (block scan over the side's
+// events, offset by the job's first word) into wid[]; phase 2 fills the word table and attaches the second reads.
+__global__ __launch_bounds__(256) void k_word_reads(DevReads R, DevParams P, ConsensusIO io, const uint32_t *w0, uint32_t *wid, Words W) {
+    __shared__ uint32_t sh[8];
     const uint32_t k = blockIdx.x;
     if (k >= io.n_act) return;
     const uint32_t st = io.act_st[k];
     if (!(st & 4)) return;
     const uint32_t s = io.act_site[k], ev_mid = io.site_ev_mid[s];
-    for (uint32_t e = io.site_ev_begin[s] + threadIdx.x; e < io.site_ev_end[s]; e += blockDim.x) {
-        const int side = e >= ev_mid ? 1 : 0;
+    const uint32_t ev_b = io.site_ev_begin[s], ev_e = io.site_ev_end[s];
+    const uint32_t mid = ev_mid == 0xFFFFFFFFu ? ev_e : ev_mid;   // no 3p event at the site
+    for (int side = 0; side < 2; side++) {
+        if (!(st & (1u << side))) continue;   // block-uniform
+        const uint32_t b = side == 0 ? ev_b : mid, e = side == 0 ? mid : ev_e;
+        uint32_t running = w0[2 * k + side];
+        for (uint32_t t0 = b; t0 < e; t0 += blockDim.x) {
+            const uint32_t ev = t0 + threadIdx.x;
+            const uint32_t f = (ev < e && (io.ev_info[ev] & 2)) ? 1u : 0u;
+            uint32_t tot;
+            const uint32_t off = block_excl_scan(f, sh, &tot);
+            if (f) wid[ev] = running + off;
+            running += tot;
+            __syncthreads();
+        }
+    }
+    __syncthreads();
+    for (uint32_t e = ev_b + threadIdx.x; e < ev_e; e += blockDim.x) {
+        const int side = e >= mid ? 1 : 0;
         if (!(st & (1u << side))) continue;
         const uint8_t in = io.ev_info[e];
         const uint64_t key = io.ev_keys[e];
@@ -153,12 +157,12 @@ __global__ __launch_bounds__(256) void k_word_reads(DevReads R, DevParams P, Con
         }
         if (root < 0) continue;   // cannot happen: info bit 2 is clear exactly when such a read exists
         // its event: binary search by key in this site-side's range
-        uint32_t lo = side == 0 ? io.site_ev_begin[s] : ev_mid;
-        uint32_t hi = side == 0 ? ev_mid : io.site_ev_end[s];
+        uint32_t lo = side == 0 ? ev_b : mid;
+        uint32_t hi = side == 0 ? mid : ev_e;
         const uint32_t hi0 = hi;
         const uint64_t want = (key & ~(uint64_t)0x7fffffffu) | (uint64_t)root;
         while (lo < hi) { uint32_t m = (lo + hi) >> 1; if (io.ev_keys[m] < want) lo = m + 1; else hi = m; }
-        if (lo >= hi0 || io.ev_keys[lo] != want || !wflag[lo]) continue;
+        if (lo >= hi0 || io.ev_keys[lo] != want || !(io.ev_info[lo] & 2)) continue;
         const uint32_t w = wid[lo];
         atomicAdd(&W.nextra[w], 1u);
         W.second[w] = (int32_t)r;
@@ -961,14 +965,14 @@ int run_consensus(mfk_ctx *ctx, const DevReads &R, const DevParams &P, Consensus
     const uint32_t E = io.n_events, n_act = io.n_act;
     io.cons_chars = nullptr; io.cons_stride = 0;
     if (!E || !n_act) return 0;
-    // words of the active sites: flags -> ids.  The word tables are sized by the event count (an upper bound), so the
-    // host reads the sizes it needs (words, adjacency words, characters, longest word) back in ONE batch.
-    uint32_t *wflag = nullptr, *wid = aalloc<uint32_t>(ctx, (size_t)E + 1);
+    // words of the active sites: job sizes -> word ranges -> ids.  The word tables are sized by the event count (an upper
+    // bound), so the host reads the sizes it needs (words, adjacency words, characters, longest word) back in ONE batch.
+    uint32_t *wid = aalloc<uint32_t>(ctx, (size_t)E + 1);   // word of a word-starting event (active sites only)
     CMeta *meta = nullptr;
     Words W; memset(&W, 0, sizeof W);
     Jobs J; memset(&J, 0, sizeof J);
     J.n = 2 * n_act;
-    J.w0 = aalloc<uint32_t>(ctx, J.n); J.R = aalloc<uint32_t>(ctx, J.n); J.nl = aalloc<uint32_t>(ctx, J.n);
+    J.w0 = aalloc<uint32_t>(ctx, (size_t)J.n + 1); J.R = aalloc<uint32_t>(ctx, J.n); J.nl = aalloc<uint32_t>(ctx, J.n);
     J.adj_words = aalloc<uint32_t>(ctx, J.n); J.adj_off = aalloc<uint64_t>(ctx, (size_t)J.n + 1); J.best = aalloc<uint32_t>(ctx, J.n); J.giant = aalloc<uint32_t>(ctx, J.n); J.longest = aalloc<uint32_t>(ctx, 4 * (size_t)J.n);
     W.first = aalloc<int32_t>(ctx, E); W.job = aalloc<uint32_t>(ctx, E); W.len = aalloc<uint32_t>(ctx, E); W.src = aalloc<WordSrc>(ctx, E);
     W.off = aalloc<uint64_t>(ctx, (size_t)E + 1); W.is_leaf = aalloc<uint8_t>(ctx, E); W.leaf_word = aalloc<uint32_t>(ctx, E);
@@ -976,26 +980,25 @@ int run_consensus(mfk_ctx *ctx, const DevReads &R, const DevParams &P, Consensus
     W.leaf_list = aalloc<uint32_t>(ctx, E); W.rep_list = aalloc<uint32_t>(ctx, E); W.share = aalloc<uint32_t>(ctx, E); W.out_list = aalloc<uint32_t>(ctx, E);
     {
         FillGroup z(ctx, 0), f(ctx, 0xFF);
-        z.want(&wflag, E); z.want(&meta, 1); z.want(&W.nextra, E); z.want(&W.plen, E); z.want(&W.leaf_rank, E);
+        z.want(&meta, 1); z.want(&W.nextra, E); z.want(&W.plen, E); z.want(&W.leaf_rank, E);
         z.want(&W.has_match, E); z.want(&W.n_list, 4);
         f.want(&W.second, E); f.want(&W.label, E); f.want(&W.cover, E);
         if (!wid || !J.w0 || !J.R || !J.nl || !J.adj_words || !J.adj_off || !J.best || !J.giant || !J.longest || !W.first || !W.job || !W.len || !W.src || !W.off ||
-            !W.is_leaf || !W.leaf_word || !W.cl_count || !W.cl_len || !W.cl_key || !W.leaf_list || !W.rep_list || !W.share || !W.out_list || z.commit() || f.commit()) return 1;
+            !W.is_leaf || !W.leaf_word || !W.cl_count || !W.cl_len || !W.cl_key || !W.leaf_list || !W.rep_list || !W.share || !W.out_list || fill_commit2(z, f)) return 1;
     }
-    PROF_LAUNCH(k_word_flags, dim3(n_act), dim3(256), 0, st, io, wflag);
+    PROF_LAUNCH(k_job_meta, dim3(nblocks(J.n, 256)), dim3(256), 0, st, io, J, meta);
     KCHK();
-    if (int rc = dev_excl_scan32(ctx, wflag, wid, E)) return rc;
-    PROF_LAUNCH(k_job_meta, dim3(nblocks(J.n, 256)), dim3(256), 0, st, io, (const uint32_t *)wid, J, meta);
-    KCHK();
+    if (int rc = dev_excl_scan32(ctx, J.R, J.w0, J.n)) return rc;            // first word of every job; J.w0[J.n] = number of words
     if (int rc = dev_excl_scan64(ctx, J.adj_words, J.adj_off, J.n)) return rc;
-    PROF_LAUNCH(k_word_reads, dim3(n_act), dim3(256), 0, st, R, P, io, (const uint32_t *)wflag, (const uint32_t *)wid, W);
+    PROF_LAUNCH(k_word_reads, dim3(n_act), dim3(256), 0, st, R, P, io, (const uint32_t *)J.w0, wid, W);
     KCHK();
-    PROF_LAUNCH(k_word_len, dim3(nblocks(E, 256)), dim3(256), 0, st, R, W, (const uint32_t *)(wid + E), meta);
+    const uint32_t *n_words_p = J.w0 + J.n;
+    PROF_LAUNCH(k_word_len, dim3(nblocks(E, 256)), dim3(256), 0, st, R, W, n_words_p, meta);
     KCHK();
     if (int rc = dev_excl_scan64(ctx, W.plen, W.off, E)) return rc;   // plen is 0 beyond the last word: off[E] = all characters
     uint32_t Wn = 0; uint64_t adj_total = 0;
     CMeta hm; uint64_t total_chars = 0;
-    { ReadBatch rb(ctx); rb.add(wid + E, &Wn, 4); rb.add(J.adj_off + J.n, &adj_total, 8); rb.add(meta, &hm, sizeof hm); rb.add(W.off + E, &total_chars, 8); if (int rc = rb.flush()) return rc; }
+    { ReadBatch rb(ctx); rb.add(n_words_p, &Wn, 4); rb.add(J.adj_off + J.n, &adj_total, 8); rb.add(meta, &hm, sizeof hm); rb.add(W.off + E, &total_chars, 8); if (int rc = rb.flush()) return rc; }
     if (Wn == 0) return 0;
     W.n = Wn;
     const unsigned ww = nblocks(Wn, 4);

@@ -645,7 +645,7 @@ extern "C" int mfk_findflanks(mfk_ctx *ctx, const mfk_reads *reads, const mfk_pa
         FillGroup z(ctx, 0), f(ctx, 0xFF);
         z.want(&T.cnt2, 2 * (size_t)E); z.want(&T.sflags, E); z.want(&alive, E);
         f.want(&T.ev_mid, E);
-        if (!ev_info || !head || !head_scan || !T.gpos || !T.contig || !T.ev_begin || !T.ev_end || !T.st || !st2 || !ascan || z.commit() || f.commit()) return 1;
+        if (!ev_info || !head || !head_scan || !T.gpos || !T.contig || !T.ev_begin || !T.ev_end || !T.st || !st2 || !ascan || fill_commit2(z, f)) return 1;
         const unsigned eb = nblocks(E, 256);
         PROF_LAUNCH(k_event_info, dim3(eb), dim3(256), 0, st, R, P, (const uint64_t *)ev_sorted, E, ev_info, head);
         KCHK();
@@ -700,7 +700,7 @@ extern "C" int mfk_findflanks(mfk_ctx *ctx, const mfk_reads *reads, const mfk_pa
         }
         if (stop_after >= MFK_STAGE_CONSENSUS) {
             io.ev_keys = ev_sorted; io.ev_info = ev_info; io.n_events = E;
-            io.n_act = n_act; io.act_site = A.site; io.act_st = A.st;
+            io.n_act = n_act; io.act_site = A.site; io.act_st = A.st; io.act_cnt2 = A.cnt2;
             io.site_ev_begin = T.ev_begin; io.site_ev_mid = T.ev_mid; io.site_ev_end = T.ev_end;
             if (int rc = run_consensus(ctx, R, P, io)) return rc;
             PROF_LAUNCH(k_consensus_filters, dim3(ab), dim3(256), 0, st, A, n_act, (const uint32_t *)io.n_pass_len, (const uint32_t *)io.n_pass_both, d_stats);

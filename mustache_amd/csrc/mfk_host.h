@@ -97,6 +97,7 @@ struct FillGroup {
     template <typename T> void want(T **out, size_t n) { size_t b = ((n ? n : 1) * sizeof(T) + 255) & ~(size_t)255; reqs.push_back({(void **)out, b, total}); total += b; }
     int commit();    // allocates, assigns the pointers, queues the fill; non-zero on failure
 };
+int fill_commit2(FillGroup &zeros, FillGroup &ones);   // both groups (values 0 and 0xFF) with one allocation and one launch
 
 size_t upload_reads_pinned_bytes(int n_contigs);
 int upload_reads(mfk_ctx *ctx, const mfk_reads *reads, const mfk_params *params, DevReads *R, DevParams *P);
@@ -116,6 +117,7 @@ struct ConsensusIO {
     const uint64_t *ev_keys; const uint8_t *ev_info; uint32_t n_events;
     // active sites
     uint32_t n_act; const uint32_t *act_site; const uint32_t *act_st;     // st bits: 1 keep5, 2 keep3, 4 alive
+    const uint32_t *act_cnt2;                                              // distinct query names per active site and side
     const uint32_t *site_ev_begin, *site_ev_mid, *site_ev_end;             // indexed by site
     // outputs, indexed by job = 2*k + side (side 0 = 5p, 1 = 3p)
     int32_t *cons_count, *cons_len; uint32_t *n_pass_len, *n_pass_both;

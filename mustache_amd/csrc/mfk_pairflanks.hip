@@ -688,7 +688,7 @@ extern "C" int mfk_pairflanks(mfk_ctx *ctx, const mfk_reads *reads, const mfk_pa
         z.want(&d_pstats, MFK_N_STATS); z.want(&kv, nP); z.want(&jflag, nP); z.want(&dr, (size_t)nP * stride);
         f.want(&kk, nP);   // unused sort keys stay ~0 and sort behind the kept pairs
         if (!c5 || !c3 || !ir || !keys || !keys2 || !kk2 || !vals || !order || !best5 || !best3 || !used5 || !used3 || !state || !kflag || !kscan || !jscan ||
-            !kept || !spanning || !span_all || !fin || !fin_span || !meta || z.commit() || f.commit()) return 1;
+            !kept || !spanning || !span_all || !fin || !fin_span || !meta || fill_commit2(z, f)) return 1;
         const unsigned pb = nblocks(nP, 256);
         PROF_LAUNCH(k_pair_window<true>, dim3(fb), dim3(256), 0, st, F, P.maxdr, sorted, (uint32_t *)nullptr, (const uint32_t *)coff, c5, c3);
         KCHK();
