@@ -267,16 +267,19 @@ __global__ __launch_bounds__(256) void k_job_longest(Words W, Jobs J) {
 // is some other word an extension of a word (or an earlier copy)?  One wave per LF_WORDS consecutive words.  First
 // every word is tested against the N_LONGEST longest words of its job, all LF_WORDS x N_LONGEST tests at once (one lane
 // each, so the dependent loads job -> word range -> longest -> characters are paid once per wave, not once per word);
-// the words that settles (error-free reads) are done.  The others are scanned against every word of their job by the
-// whole wave.
+// the words that settles (error-free reads) are done.  The others differ from those longest words at some position p
+// (a sequencing error): a word that extends them must show the same character there, which nearly none does.  So the
+// scan of the job's words first looks at that one character of LF_BATCH x 64 candidates at once (their lengths, offsets
+// and characters are independent loads, all in flight together) and compares in full only the few that pass.
 // lf = words per wave (1..LF_WORDS): the host takes fewer when there are too few words to fill the GPU with waves.
 #define LF_WORDS 8
+#define LF_BATCH 8
 __global__ __launch_bounds__(256) void k_leaf_flags(Words W, Jobs J, int lf) {
     const int lane = threadIdx.x & 63;
     const uint32_t wbase = (blockIdx.x * 4 + (threadIdx.x >> 6)) * (uint32_t)lf;
     if (wbase >= W.n) return;
     uint32_t m_w0 = 0, m_R = 0, m_off = 0;
-    int m_la = 0;
+    int m_la = 0, m_lcp = 0;
     bool covered = false;
     {
         const uint32_t w = wbase + (uint32_t)lane / N_LONGEST;
@@ -287,27 +290,53 @@ __global__ __launch_bounds__(256) void k_leaf_flags(Words W, Jobs J, int lf) {
             if (j != 0xFFFFFFFFu) {
                 const uint32_t v = m_w0 + j;
                 const int lb = (int)W.len[v];
-                if (v != w && lb >= m_la && d_lcp(W.ch + m_off, m_la, W.ch + W.off[v], lb) >= m_la && (lb > m_la || v < w)) covered = true;
+                if (v != w) {
+                    m_lcp = d_lcp(W.ch + m_off, m_la, W.ch + W.off[v], lb);
+                    if (lb >= m_la && m_lcp >= m_la && (lb > m_la || v < w)) covered = true;
+                }
             }
         }
     }
     const unsigned long long cov = __ballot(covered);
+    // longest match of a word with one of the longest words: maximum over its N_LONGEST lanes
+    for (int o = 1; o < N_LONGEST; o <<= 1) { const int other = __shfl_xor(m_lcp, o, 64); if (other > m_lcp) m_lcp = other; }
     for (int i = 0; i < lf; i++) {   // wave-uniform
         const uint32_t w = wbase + (uint32_t)i;
         if (w >= W.n) break;
         if ((cov >> (i * N_LONGEST)) & ((1ull << N_LONGEST) - 1)) { if (lane == 0) W.is_leaf[w] = 0; continue; }
         const uint32_t w0 = __shfl(m_w0, i * N_LONGEST, 64), R = __shfl(m_R, i * N_LONGEST, 64);
         const int la = __shfl(m_la, i * N_LONGEST, 64);
+        if (la <= 0) { if (lane == 0) W.is_leaf[w] = R > 1 ? 0 : 1; continue; }   // an empty word is a prefix of everything (cannot happen: clips have >= 1 base)
         const uint8_t *a = W.ch + __shfl(m_off, i * N_LONGEST, 64);
-        bool c2 = false;
-        for (uint32_t j = lane; j < R && !c2; j += 64) {
-            const uint32_t v = w0 + j;
-            if (v == w) continue;
-            const int lb = (int)W.len[v];
-            if (lb < la) continue;
-            if (d_lcp(a, la, W.ch + W.off[v], lb) >= la && (lb > la || v < w)) c2 = true;
+        int p = __shfl(m_lcp, i * N_LONGEST, 64);
+        if (p > la - 1) p = la - 1;
+        const uint8_t ap = a[p];
+        unsigned long long any = 0;
+        for (uint32_t c0 = 0; c0 < R; c0 += 64 * LF_BATCH) {   // wave-uniform
+            int lens[LF_BATCH]; uint32_t offs[LF_BATCH]; bool ok[LF_BATCH]; uint8_t bp[LF_BATCH];
+#pragma unroll
+            for (int u = 0; u < LF_BATCH; u++) {
+                const uint32_t j = c0 + (uint32_t)u * 64 + lane;
+                ok[u] = j < R && w0 + j != w;
+                lens[u] = ok[u] ? (int)W.len[w0 + j] : 0;
+                offs[u] = ok[u] ? (uint32_t)W.off[w0 + j] : 0u;
+            }
+#pragma unroll
+            for (int u = 0; u < LF_BATCH; u++) {
+                ok[u] = ok[u] && lens[u] >= la;
+                bp[u] = ok[u] ? W.ch[(size_t)offs[u] + p] : (uint8_t)0xFE;
+            }
+            bool c2 = false;
+#pragma unroll
+            for (int u = 0; u < LF_BATCH; u++) {
+                if (ok[u] && bp[u] == ap) {
+                    const uint32_t v = w0 + c0 + (uint32_t)u * 64 + lane;
+                    if (d_lcp(a, la, W.ch + offs[u], lens[u]) >= la && (lens[u] > la || v < w)) c2 = true;
+                }
+            }
+            any = __ballot(c2);
+            if (any) break;
         }
-        const unsigned long long any = __ballot(c2);
         if (lane == 0) W.is_leaf[w] = any ? 0 : 1;
     }
 }

@@ -242,8 +242,12 @@ __global__ __launch_bounds__(BSORT_THREADS) void k_bucket_sort(const uint64_t *b
     __syncthreads();
     uint32_t base = 0;
     for (int w = 0; w < BSORT_THREADS / 64; w++) base += red[w];
-    for (uint32_t k = 2; k <= npad; k <<= 1)
-        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+    // Bitonic network.  A stage with distance j >= 128 pairs keys of different waves' pairs: block barrier per stage.  For
+    // j <= 64 the 64 consecutive pairs of a wave stay inside that wave's own 128 keys, so all remaining stages of a merge
+    // step run without block barriers (LDS operations of one wave execute in order): 21 barriers instead of 66 for 2048 keys.
+    for (uint32_t k = 2; k <= npad; k <<= 1) {
+        uint32_t j = k >> 1;
+        for (; j >= 128; j >>= 1) {
             for (uint32_t t = threadIdx.x; t < (npad >> 1); t += BSORT_THREADS) {
                 const uint32_t i = 2 * t - (t & (j - 1)), l = i + j;
                 const uint64_t x = keys[i], y = keys[l];
@@ -252,6 +256,16 @@ __global__ __launch_bounds__(BSORT_THREADS) void k_bucket_sort(const uint64_t *b
             }
             __syncthreads();
         }
+        for (uint32_t t = threadIdx.x; t < (npad >> 1); t += BSORT_THREADS)
+            for (uint32_t jj = j; jj > 0; jj >>= 1) {
+                const uint32_t i = 2 * t - (t & (jj - 1)), l = i + jj;
+                const uint64_t x = keys[i], y = keys[l];
+                const bool up = (i & k) == 0;
+                if ((x > y) == up) { keys[i] = y; keys[l] = x; }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");   // this wave's exchanges are complete before its next stage reads
+            }
+        __syncthreads();
+    }
     for (uint32_t i = threadIdx.x; i < n; i += BSORT_THREADS) out[base + i] = keys[i];
 }
 
