@@ -210,27 +210,62 @@ __device__ __forceinline__ void d_clip_char(const DevReads &R, uint64_t pool_off
     *q = R.pool_quals[k];
 }
 
-// one wave per word: mate merge by quality (combine_softclip_seq_quals_*, findflanks.py:932-1027)
+// mate merge by quality (combine_softclip_seq_quals_*, findflanks.py:932-1027): character p of a word, 0xFF / 0 padding
+__device__ __forceinline__ void d_word_char(const DevReads &R, const WordSrc &src, int side, int len, int p, uint8_t *c_out, uint8_t *q_out) {
+    uint8_t c = 0xFF, q = 0;
+    if (p < len) {
+        const int l1 = src.l1, l2 = src.l2;
+        uint8_t c1 = 0, qa = 0, c2 = 0, qb = 0;
+        if (p < l1) d_clip_char(R, src.o1, src.q1len, l1, side, p, &c1, &qa);
+        if (p < l2) d_clip_char(R, src.o2, src.q2len, l2, side, p, &c2, &qb);
+        if (p < l1 && p < l2) { if (qa >= qb) { c = c1; q = qa; } else { c = c2; q = qb; } }   // read1 = first in BAM order (Q4)
+        else if (p < l1) { c = c1; q = qa; }
+        else if (p < l2) { c = c2; q = qb; }
+    }
+    *c_out = c; *q_out = q;
+}
+
+// One wave per WF_WORDS consecutive words, lane = character.  A word is a few dozen characters: one word per wave would
+// leave the wave waiting on two dependent load round trips for 150 bytes of work.  So lane u resolves the header of the
+// wave's u-th word, and the first 128 characters of all WF_WORDS words are loaded before anything is stored.
+#define WF_WORDS 4
 __global__ __launch_bounds__(256) void k_word_fill(DevReads R, Words W) {
-    uint32_t w = blockIdx.x * 4 + (threadIdx.x >> 6);
-    int lane = threadIdx.x & 63;
-    if (w >= W.n) return;
-    const int side = (int)(W.job[w] & 1);
-    const WordSrc src = W.src[w];
-    const int l1 = src.l1, l2 = src.l2;
-    uint8_t *ch = W.ch + W.off[w], *qq = W.q + W.off[w];
-    const int len = (int)W.len[w], plen = (int)W.plen[w];
-    for (int p = lane; p < plen; p += 64) {
-        uint8_t c = 0xFF, q = 0;
-        if (p < len) {
-            uint8_t c1 = 0, qa = 0, c2 = 0, qb = 0;
-            if (p < l1) d_clip_char(R, src.o1, src.q1len, l1, side, p, &c1, &qa);
-            if (p < l2) d_clip_char(R, src.o2, src.q2len, l2, side, p, &c2, &qb);
-            if (p < l1 && p < l2) { if (qa >= qb) { c = c1; q = qa; } else { c = c2; q = qb; } }   // read1 = first in BAM order (Q4)
-            else if (p < l1) { c = c1; q = qa; }
-            else if (p < l2) { c = c2; q = qb; }
+    const uint32_t wbase = (blockIdx.x * 4 + (threadIdx.x >> 6)) * WF_WORDS;
+    const int lane = threadIdx.x & 63;
+    if (wbase >= W.n) return;
+    WordSrc m_src; m_src.o1 = 0; m_src.o2 = 0; m_src.l1 = 0; m_src.l2 = 0; m_src.q1len = 0; m_src.q2len = 0;
+    uint32_t m_off = 0, m_len = 0, m_plen = 0, m_side = 0;
+    if (lane < WF_WORDS && wbase + lane < W.n) {
+        const uint32_t w = wbase + lane;
+        m_src = W.src[w]; m_off = (uint32_t)W.off[w]; m_len = W.len[w]; m_plen = W.plen[w]; m_side = W.job[w] & 1u;
+    }
+    WordSrc src[WF_WORDS];
+    uint32_t off[WF_WORDS]; int len[WF_WORDS], plen[WF_WORDS], side[WF_WORDS];
+    uint8_t c[WF_WORDS][2], q[WF_WORDS][2];
+#pragma unroll
+    for (int u = 0; u < WF_WORDS; u++) {
+        src[u].o1 = ((uint64_t)__shfl((uint32_t)(m_src.o1 >> 32), u, 64) << 32) | (uint64_t)__shfl((uint32_t)m_src.o1, u, 64);
+        src[u].o2 = ((uint64_t)__shfl((uint32_t)(m_src.o2 >> 32), u, 64) << 32) | (uint64_t)__shfl((uint32_t)m_src.o2, u, 64);
+        const uint32_t ll = __shfl((uint32_t)m_src.l1 | ((uint32_t)m_src.l2 << 16), u, 64), qq = __shfl((uint32_t)m_src.q1len | ((uint32_t)m_src.q2len << 16), u, 64);
+        src[u].l1 = (uint16_t)ll; src[u].l2 = (uint16_t)(ll >> 16); src[u].q1len = (uint16_t)qq; src[u].q2len = (uint16_t)(qq >> 16);
+        off[u] = __shfl(m_off, u, 64); len[u] = (int)__shfl(m_len, u, 64); plen[u] = (int)__shfl(m_plen, u, 64); side[u] = (int)__shfl(m_side, u, 64);
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const int p = lane + 64 * h;
+            c[u][h] = 0xFF; q[u][h] = 0;
+            if (p < plen[u]) d_word_char(R, src[u], side[u], len[u], p, &c[u][h], &q[u][h]);
         }
-        ch[p] = c; qq[p] = q;
+    }
+#pragma unroll
+    for (int u = 0; u < WF_WORDS; u++) {
+        uint8_t *ch = W.ch + off[u], *qo = W.q + off[u];
+#pragma unroll
+        for (int h = 0; h < 2; h++) { const int p = lane + 64 * h; if (p < plen[u]) { ch[p] = c[u][h]; qo[p] = q[u][h]; } }
+        for (int p = lane + 128; p < plen[u]; p += 64) {   // clips longer than 128 bases
+            uint8_t cc, qv;
+            d_word_char(R, src[u], side[u], len[u], p, &cc, &qv);
+            ch[p] = cc; qo[p] = qv;
+        }
     }
 }
 
@@ -1030,7 +1065,7 @@ int run_consensus(mfk_ctx *ctx, const DevReads &R, const DevParams &P, Consensus
     { ReadBatch rb(ctx); rb.add(n_words_p, &Wn, 4); rb.add(J.adj_off + J.n, &adj_total, 8); rb.add(meta, &hm, sizeof hm); rb.add(W.off + E, &total_chars, 8); if (int rc = rb.flush()) return rc; }
     if (Wn == 0) return 0;
     W.n = Wn;
-    const unsigned ww = nblocks(Wn, 4);
+    const unsigned ww = nblocks(Wn, 4 * WF_WORDS);
     if (hm.err & ERR_READ_NUMBER) { snprintf(ctx->err, sizeof ctx->err, "READ NUMBER ERROR - ZERO OR MORE THAN TWO READS ASSOCIATED WITH QUERY NAME"); return 3; }
     if (hm.err & ERR_NO_SEQUENCE) { snprintf(ctx->err, sizeof ctx->err, "a clipped read at a surviving site has no sequence in the pool (pack with pool='clipped')"); return 2; }
     if (hm.err & ERR_WORD_TOO_LONG) { snprintf(ctx->err, sizeof ctx->err, "soft clip longer than %d bases: not supported by this build", MAX_WORD_LEN); return 6; }
