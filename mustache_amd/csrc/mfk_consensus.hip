@@ -28,7 +28,11 @@ struct CMeta {          // small device struct the host reads back once
     uint32_t err, max_len, max_R, pad;
 };
 
-struct NodeSum { uint32_t q, c, e; };   // quality sum, #words through the node, #words ending on it
+// per trie node: quality sum (low 40 bits) and #words through the node (high 24 bits) in ONE 64-bit word, so that a node
+// costs one global atomic instead of two (the flush of k_node_sums is bound by the L2's atomic rate); #words ending on it
+struct NodeSum { unsigned long long qc; uint32_t e; };   // register view; in memory two arrays (agg_qc, agg_e): 12 bytes per node, 8-byte aligned atomics
+#define NS_C_SHIFT 40
+#define NS_Q_MASK ((1ull << NS_C_SHIFT) - 1ull)
 
 struct WordSrc {        // where a word's characters come from: pool offsets and clip lengths of its one or two reads
     uint64_t o1, o2;
@@ -47,7 +51,8 @@ struct Words {
     uint8_t *ch, *q;                  // characters (4-bit codes, one per byte) and qualities
     uint32_t *npos;                   // per character d of a leaf a: its trie node = position of character d of word t(a[:d+1])
     uint32_t *cover;                  // per word: a leaf (local leaf index) the word is a prefix of
-    NodeSum *agg;                     // per character position = trie node
+    unsigned long long *agg_qc;       // per character position = trie node: quality sum | #words << 40
+    uint32_t *agg_e;                  // #words ending on the node
     uint32_t *share;                  // per leaf slot: longest prefix shared with an earlier leaf of its cluster
     uint8_t *is_leaf;
     uint32_t *leaf_word;              // slot w0+k -> local word index of the k-th leaf (word order)
@@ -812,8 +817,8 @@ __global__ __launch_bounds__(1024) void k_node_sums(Words W, Jobs J, uint32_t ma
                 atomicAdd(&tq[i2], qv); atomicAdd(&tc[i2], 1u);
                 if (d == len - 1) atomicAdd(&te[i2], 1u);
             } else {
-                atomicAdd(&W.agg[pos].q, qv); atomicAdd(&W.agg[pos].c, 1u);
-                if (d == len - 1) atomicAdd(&W.agg[pos].e, 1u);
+                atomicAdd(&W.agg_qc[pos], (unsigned long long)qv | (1ull << NS_C_SHIFT));
+                if (d == len - 1) atomicAdd(&W.agg_e[pos], 1u);
             }
         }
     }
@@ -821,8 +826,8 @@ __global__ __launch_bounds__(1024) void k_node_sums(Words W, Jobs J, uint32_t ma
     for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
         const uint32_t pos = tk[i];
         if (pos == 0xFFFFFFFFu) continue;
-        atomicAdd(&W.agg[pos].q, tq[i]); atomicAdd(&W.agg[pos].c, tc[i]);
-        if (te[i]) atomicAdd(&W.agg[pos].e, te[i]);
+        atomicAdd(&W.agg_qc[pos], (unsigned long long)tq[i] | ((unsigned long long)tc[i] << NS_C_SHIFT));
+        if (te[i]) atomicAdd(&W.agg_e[pos], te[i]);
     }
 }
 
@@ -909,20 +914,21 @@ __global__ __launch_bounds__(CV_THREADS) void k_cluster_vote(DevParams P, Words 
                 if (ok[u]) { np[u] = W.npos[(size_t)o[u] + d[u]]; code[u] = W.ch[(size_t)o[u] + d[u]] & 15; }
             }
 #pragma unroll
-            for (int u = 0; u < CV_BATCH; u++) { ns[u].q = 0; ns[u].c = 0; ns[u].e = 0; if (ok[u]) ns[u] = W.agg[np[u]]; }
+            for (int u = 0; u < CV_BATCH; u++) { ns[u].qc = 0; ns[u].e = 0; if (ok[u]) { ns[u].qc = W.agg_qc[np[u]]; ns[u].e = W.agg_e[np[u]]; } }
 #pragma unroll
             for (int u = 0; u < CV_BATCH; u++) if (ok[u]) {
-                atomicAdd(&hq[d[u] * 16 + code[u]], ns[u].q);
-                atomicAdd(&hc[d[u] * 16 + code[u]], ns[u].c);
+                atomicAdd(&hq[d[u] * 16 + code[u]], (uint32_t)(ns[u].qc & NS_Q_MASK));
+                atomicAdd(&hc[d[u] * 16 + code[u]], (uint32_t)(ns[u].qc >> NS_C_SHIFT));
                 words += ns[u].e;                            // words ending here: prefixes of a leaf of the cluster
             }
 #pragma unroll
             for (int u = 0; u < CV_BATCH; u++)               // a path longer than 64 below its shared depth
                 for (int dd = d[u] + 64; dd < len[u]; dd += 64) {
-                    const NodeSum n2 = W.agg[W.npos[(size_t)o[u] + dd]];
+                    const uint32_t np2 = W.npos[(size_t)o[u] + dd];
+                    NodeSum n2; n2.qc = W.agg_qc[np2]; n2.e = W.agg_e[np2];
                     const uint32_t c2 = W.ch[(size_t)o[u] + dd] & 15;
-                    atomicAdd(&hq[dd * 16 + c2], n2.q);
-                    atomicAdd(&hc[dd * 16 + c2], n2.c);
+                    atomicAdd(&hq[dd * 16 + c2], (uint32_t)(n2.qc & NS_Q_MASK));
+                    atomicAdd(&hc[dd * 16 + c2], (uint32_t)(n2.qc >> NS_C_SHIFT));
                     words += n2.e;
                 }
         }
@@ -1071,7 +1077,7 @@ int run_consensus(mfk_ctx *ctx, const DevReads &R, const DevParams &P, Consensus
     if (hm.err & ERR_WORD_TOO_LONG) { snprintf(ctx->err, sizeof ctx->err, "soft clip longer than %d bases: not supported by this build", MAX_WORD_LEN); return 6; }
     {
         FillGroup z(ctx, 0);
-        z.want(&J.adj, (size_t)adj_total); z.want(&W.agg, (size_t)total_chars + 8);
+        z.want(&J.adj, (size_t)adj_total); z.want(&W.agg_qc, (size_t)total_chars + 8); z.want(&W.agg_e, (size_t)total_chars + 8);
         if (z.commit()) return 1;
     }
     W.ch = aalloc<uint8_t>(ctx, (size_t)total_chars + 64); W.q = aalloc<uint8_t>(ctx, (size_t)total_chars + 64);
