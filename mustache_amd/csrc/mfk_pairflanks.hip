@@ -440,6 +440,7 @@ __global__ void k_pair_final(const uint32_t *kept, const uint32_t *n_kept, const
 // ---- get_direct_repeats ---------------------------------------------------------------------------------------------------
 #define DR_WIN 50
 #define DR_SEGS 1536
+#define DR_FLIGHT 4   // eight in flight were no faster at C2 and slower with a thousand pairs
 // per candidate pair c: dr_out[c*stride ...] = reference repeat, dr_out[c*stride + half ...] = reads consensus.
 // One block per CANDIDATE pair (like k_spanning, on the side stream next to the inverted-repeat alignment); the host
 // takes the rows of the final pairs.
@@ -525,10 +526,10 @@ __global__ __launch_bounds__(1024) void k_direct_repeats(DevReads R, FlankDev F,
         const uint32_t ns = nseg < DR_SEGS ? nseg : DR_SEGS;
         const int lane = threadIdx.x & 63;
         const uint32_t nw = blockDim.x >> 6;
-        for (uint32_t sgi = threadIdx.x >> 6; sgi < ns; sgi += 4 * nw) {   // four segments in flight per wave
-            uint32_t code[4], qv[4], rr[4]; int col[4]; bool on[4];
+        for (uint32_t sgi = threadIdx.x >> 6; sgi < ns; sgi += DR_FLIGHT * nw) {   // DR_FLIGHT segments in flight per wave
+            uint32_t code[DR_FLIGHT], qv[DR_FLIGHT], rr[DR_FLIGHT]; int col[DR_FLIGHT]; bool on[DR_FLIGHT];
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
+            for (int u = 0; u < DR_FLIGHT; u++) {
                 const uint32_t sg = sgi + u * nw;
                 on[u] = false;
                 if (sg < ns) {
@@ -540,7 +541,7 @@ __global__ __launch_bounds__(1024) void k_direct_repeats(DevReads R, FlankDev F,
                 }
             }
 #pragma unroll
-            for (int u = 0; u < 4; u++)
+            for (int u = 0; u < DR_FLIGHT; u++)
                 if (on[u]) { atomicAdd(&sum[col[u]][code[u]], qv[u]); atomicMin(&firstr[col[u]][code[u]], rr[u]); }
         }
         __syncthreads();
