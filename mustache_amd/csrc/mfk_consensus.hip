@@ -64,7 +64,8 @@ struct Words {
     // device-side work lists (order arbitrary): the kernels that work per leaf / per cluster run a fixed grid over them
     uint32_t *leaf_list, *rep_list;   // slots of the leaves / of the cluster representatives
     uint32_t *out_list;               // slots of the leaves outside their job's giant component after the pivot pass
-    uint32_t *n_list;                 // [0] = number of leaves, [1] = number of representatives, [2] = number of outsiders
+    uint32_t *my_list;                // pivot-pass work items of k_leaf_myers: job << 8 | pivot << 4 | partner chunk
+    uint32_t *n_list;                 // [1] = representatives, [2] = outsiders; [4] = leaves and [5] = pivot-pass work items (one 64-bit counter)
 };
 
 struct Jobs {
@@ -381,8 +382,10 @@ __global__ __launch_bounds__(256) void k_leaf_flags(Words W, Jobs J, int lf) {
     }
 }
 
+#define N_PIVOTS 4   // pivot leaves of the first edit-distance pass (k_leaf_myers)
+
 // one block per job: ordered list of its leaves
-__global__ __launch_bounds__(256) void k_leaf_compact(Words W, Jobs J) {
+__global__ __launch_bounds__(256) void k_leaf_compact(Words W, Jobs J, uint32_t n_chunks) {
     __shared__ uint32_t sh[8];
     uint32_t job = blockIdx.x;
     if (job >= J.n) return;
@@ -396,10 +399,23 @@ __global__ __launch_bounds__(256) void k_leaf_compact(Words W, Jobs J) {
         if (f) { W.leaf_word[w0 + running + off] = i; W.label[w0 + running + off] = running + off; }
         running += tot;
     }
-    __shared__ uint32_t s_base;
-    if (threadIdx.x == 0) { J.nl[job] = running; s_base = atomicAdd(&W.n_list[0], running); }
+    // pivot-pass work items of this job (k_leaf_myers mode 0): (pivot, chunk of 64 partners) pairs that have a partner.
+    // A compact list lets that kernel give every item its own wave on its own SIMD; enumerating all (job slot, pivot,
+    // chunk) triples leaves three of four waves without work and the busy ones bunched on the same SIMDs.
+    // Room in the leaf list and in the item list is reserved with ONE 64-bit atomic per job (leaves low, items high):
+    // tens of thousands of jobs on one counter serialise in the L2, so a second counter would double that time.
+    __shared__ uint32_t s_base, s_ibase;
+    const uint32_t ka = threadIdx.x >> 4, chunk = threadIdx.x & 15;
+    const bool valid = W.my_list && threadIdx.x < 64 && ka < N_PIVOTS && chunk < n_chunks && running >= 2 && ka + 1 + 64 * chunk < running;
+    const unsigned long long m = __ballot(valid);   // wave 0 holds all candidates
+    if (threadIdx.x == 0) {
+        J.nl[job] = running;
+        const unsigned long long old = atomicAdd(reinterpret_cast<unsigned long long *>(W.n_list + 4), (unsigned long long)running | ((unsigned long long)__popcll(m) << 32));
+        s_base = (uint32_t)old; s_ibase = (uint32_t)(old >> 32);
+    }
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < running; i += blockDim.x) W.leaf_list[s_base + i] = w0 + i;
+    if (valid) W.my_list[s_ibase + (uint32_t)__popcll(m & ((1ull << threadIdx.x) - 1ull))] = (job << 8) | (ka << 4) | chunk;
 }
 
 // one wave per leaf slot: t(a[:d+1]) = first word sharing d+1 characters with the leaf, for every depth d.
@@ -409,7 +425,7 @@ __global__ __launch_bounds__(256) void k_leaf_compact(Words W, Jobs J) {
 __global__ __launch_bounds__(64) void k_leaf_first(Words W, Jobs J, uint16_t *lcpm) {
     __shared__ uint32_t tmin[MAX_WORD_LEN];
     const int lane = threadIdx.x;
-    const uint32_t n_leaf = W.n_list[0];
+    const uint32_t n_leaf = W.n_list[4];
     for (uint64_t it0 = blockIdx.x; it0 < n_leaf; it0 += (uint64_t)gridDim.x * 64) {
     uint32_t m_slot = 0, m_w0 = 0, m_R = 0, m_off = 0, m_la = 0;
     unsigned long long m_adj = 0;
@@ -522,13 +538,12 @@ __device__ __forceinline__ int d_myers(const uint64_t *peq, const uint8_t *text,
     return score;
 }
 
-#define N_PIVOTS 4
 
 // DFS order of the leaves (traverse_seqs, flanktrie.py:157-170): at the first differing depth the branch whose first word
 // came earlier is visited first.  One block per leaf slot a, threads over the later leaves b; rank = #leaves before.
 __global__ __launch_bounds__(256) void k_leaf_rank(Words W, Jobs J) {
     __shared__ uint32_t s_rank;
-    const uint32_t n_leaf = W.n_list[0];
+    const uint32_t n_leaf = W.n_list[4];
     for (uint32_t it = blockIdx.x; it < n_leaf; it += gridDim.x) {
         __syncthreads();
         if (threadIdx.x == 0) s_rank = 0;
@@ -561,7 +576,7 @@ __global__ __launch_bounds__(256) void k_leaf_rank(Words W, Jobs J) {
 __global__ __launch_bounds__(256) void k_leaf_rank_wave(Words W, Jobs J) {
     const int lane = threadIdx.x & 63;
     const uint32_t wave = blockIdx.x * 4 + (threadIdx.x >> 6), n_waves = gridDim.x * 4;
-    const uint32_t n_leaf = W.n_list[0];
+    const uint32_t n_leaf = W.n_list[4];
     for (uint64_t it0 = wave; it0 < n_leaf; it0 += (uint64_t)n_waves * 64) {
         uint32_t m_slot = 0, m_w0 = 0, m_nl = 0, m_off = 0, m_la = 0;
         {
@@ -638,11 +653,14 @@ __global__ __launch_bounds__(256) void k_leaf_myers(Words W, Jobs J, int mode, u
     __shared__ uint64_t s_peq[4][8 * 16];   // per wave: Eq[limb][code] of its current pattern leaf
     const int lane = threadIdx.x & 63;
     uint64_t *peq = s_peq[threadIdx.x >> 6];
-    const uint32_t wave = blockIdx.x * 4 + (threadIdx.x >> 6), n_waves = gridDim.x * 4;
-    const uint32_t n_items = (mode == 0 ? J.n * N_PIVOTS : W.n_list[2]) * n_chunks;
+    const uint32_t wpb = blockDim.x >> 6;   // waves per block: 1 in the pivot pass (every item on its own SIMD), 4 otherwise
+    const uint32_t wave = blockIdx.x * wpb + (threadIdx.x >> 6), n_waves = gridDim.x * wpb;
+    const bool listed = mode == 0 && W.my_list != nullptr;
+    const uint32_t n_items = listed ? W.n_list[5] : (mode == 0 ? J.n * N_PIVOTS : W.n_list[2]) * n_chunks;
     for (uint32_t it = wave; it < n_items; it += n_waves) {   // wave-uniform
         uint32_t job, ka, slot, chunk;
-        if (mode == 0) { chunk = it / (J.n * N_PIVOTS); const uint32_t r = it % (J.n * N_PIVOTS); job = r / N_PIVOTS; ka = r % N_PIVOTS; slot = J.w0[job] + ka; }
+        if (listed) { const uint32_t item = W.my_list[it]; job = item >> 8; ka = (item >> 4) & 15; chunk = item & 15; slot = J.w0[job] + ka; }
+        else if (mode == 0) { chunk = it / (J.n * N_PIVOTS); const uint32_t r = it % (J.n * N_PIVOTS); job = r / N_PIVOTS; ka = r % N_PIVOTS; slot = J.w0[job] + ka; }
         else { chunk = it % n_chunks; slot = W.out_list[it / n_chunks]; job = W.job[slot]; ka = slot - J.w0[job]; }
         const uint32_t w0 = J.w0[job], R = J.R[job], nl = J.nl[job];
         if (ka >= nl || nl < 2) continue;
@@ -836,7 +854,7 @@ __global__ __launch_bounds__(1024) void k_node_sums(Words W, Jobs J, uint32_t ma
 // of its path above that depth are counted by that earlier leaf.
 __global__ __launch_bounds__(256) void k_leaf_share(Words W, Jobs J, const uint16_t *lcpm) {
     const int lane = threadIdx.x & 63;
-    const uint32_t n_leaf = W.n_list[0];
+    const uint32_t n_leaf = W.n_list[4];
     for (uint32_t it = blockIdx.x * 4 + (threadIdx.x >> 6); it < n_leaf; it += gridDim.x * 4) {
         const uint32_t slot = W.leaf_list[it];
         const uint32_t job = W.job[slot], w0 = J.w0[job], R = J.R[job], kl = slot - w0;
@@ -1051,7 +1069,7 @@ int run_consensus(mfk_ctx *ctx, const DevReads &R, const DevParams &P, Consensus
     {
         FillGroup z(ctx, 0), f(ctx, 0xFF);
         z.want(&meta, 1); z.want(&W.nextra, E); z.want(&W.plen, E); z.want(&W.leaf_rank, E);
-        z.want(&W.has_match, E); z.want(&W.n_list, 4);
+        z.want(&W.has_match, E); z.want(&W.n_list, 8);
         f.want(&W.second, E); f.want(&W.label, E); f.want(&W.cover, E);
         if (!wid || !J.w0 || !J.R || !J.nl || !J.adj_words || !J.adj_off || !J.best || !J.giant || !J.longest || !W.first || !W.job || !W.len || !W.src || !W.off ||
             !W.is_leaf || !W.leaf_word || !W.cl_count || !W.cl_len || !W.cl_key || !W.leaf_list || !W.rep_list || !W.share || !W.out_list || fill_commit2(z, f)) return 1;
@@ -1091,7 +1109,13 @@ int run_consensus(mfk_ctx *ctx, const DevReads &R, const DevParams &P, Consensus
     const int lf = Wn >= (1u << 18) ? LF_WORDS : (Wn >= (1u << 17) ? 4 : (Wn >= (1u << 16) ? 2 : 1));
     PROF_LAUNCH(k_leaf_flags, dim3(nblocks(Wn, 4 * (size_t)lf)), dim3(256), 0, st, W, J, lf);
     KCHK();
-    PROF_LAUNCH(k_leaf_compact, dim3(J.n), dim3(256), 0, st, W, J);
+    // partner chunks per pattern leaf: enough 64-lane chunks for the largest job, at most 16 (larger jobs stride)
+    uint32_t n_chunks = (hm.max_R + 63) / 64;
+    if (n_chunks < 1) n_chunks = 1;
+    if (n_chunks > 16) n_chunks = 16;
+    const uint64_t my_items = (uint64_t)J.n * N_PIVOTS * n_chunks;
+    if (J.n < (1u << 24)) { W.my_list = aalloc<uint32_t>(ctx, (size_t)my_items); if (!W.my_list) return 1; }   // else: k_leaf_myers enumerates the triples
+    PROF_LAUNCH(k_leaf_compact, dim3(J.n), dim3(256), 0, st, W, J, n_chunks);
     KCHK();
     uint16_t *lcpm = aalloc<uint16_t>(ctx, (size_t)adj_total * 32);
     if (!lcpm) return 1;
@@ -1104,14 +1128,14 @@ int run_consensus(mfk_ctx *ctx, const DevReads &R, const DevParams &P, Consensus
     hipStream_t sb = ctx->stream2;
     HIPCHK(hipEventRecord(ctx->ev_fork, st));
     HIPCHK(hipStreamWaitEvent(sb, ctx->ev_fork, 0));
-    // partner chunks per pattern leaf: enough 64-lane chunks for the largest job, at most 16 (larger jobs stride)
-    uint32_t n_chunks = (hm.max_R + 63) / 64;
-    if (n_chunks < 1) n_chunks = 1;
-    if (n_chunks > 16) n_chunks = 16;
-    const uint64_t my_items = (uint64_t)J.n * N_PIVOTS * n_chunks;
-    const unsigned g_my0 = (unsigned)(my_items / 4 + 1 < 8192 ? my_items / 4 + 1 : 8192);
     // chain (B)
-    PROF_LAUNCH(k_leaf_myers, dim3(g_my0), dim3(256), 0, sb, W, J, 0, n_chunks);
+    if (W.my_list) {   // one wave per block: consecutive work items land on different CUs
+        const unsigned g_my0 = (unsigned)(my_items < 8192 ? (my_items ? my_items : 1) : 8192);
+        PROF_LAUNCH(k_leaf_myers, dim3(g_my0), dim3(64), 0, sb, W, J, 0, n_chunks);
+    } else {
+        const unsigned g_my0 = (unsigned)(my_items / 4 + 1 < 8192 ? my_items / 4 + 1 : 8192);
+        PROF_LAUNCH(k_leaf_myers, dim3(g_my0), dim3(256), 0, sb, W, J, 0, n_chunks);
+    }
     KCHK();
     PROF_LAUNCH(k_components, dim3(J.n), dim3(256), 0, sb, W, J, 0);
     KCHK();
