@@ -541,7 +541,7 @@ __device__ __forceinline__ int d_myers(const uint64_t *peq, const uint8_t *text,
 
 // DFS order of the leaves (traverse_seqs, flanktrie.py:157-170): at the first differing depth the branch whose first word
 // came earlier is visited first.  One block per leaf slot a, threads over the later leaves b; rank = #leaves before.
-__global__ __launch_bounds__(256) void k_leaf_rank(Words W, Jobs J) {
+__global__ __launch_bounds__(256) void k_leaf_rank(Words W, Jobs J, const uint16_t *lcpm) {
     __shared__ uint32_t s_rank;
     const uint32_t n_leaf = W.n_list[4];
     for (uint32_t it = blockIdx.x; it < n_leaf; it += gridDim.x) {
@@ -549,19 +549,19 @@ __global__ __launch_bounds__(256) void k_leaf_rank(Words W, Jobs J) {
         if (threadIdx.x == 0) s_rank = 0;
         __syncthreads();
         const uint32_t slot = W.leaf_list[it];
-        const uint32_t job = W.job[slot], w0 = J.w0[job], nl = J.nl[job];
+        const uint32_t job = W.job[slot], w0 = J.w0[job], nl = J.nl[job], R = J.R[job];
         const uint32_t ka = slot - w0;
         const uint32_t wa = w0 + W.leaf_word[slot];
-        const uint8_t *a = W.ch + W.off[wa];
         const int la = (int)W.len[wa];
         const uint32_t *ta = W.npos + W.off[wa];
+        const uint16_t *mrow = lcpm + J.adj_off[job] * 32 + (size_t)ka * ((R + 31) >> 5) * 32;   // LCP(leaf a, word j) from k_leaf_first
         uint32_t before = 0;   // leaves visited before a: every leaf counts its own predecessors, nobody writes to another leaf
         for (uint32_t kb = threadIdx.x; kb < nl; kb += blockDim.x) {
             if (kb == ka) continue;
-            const uint32_t wb = w0 + W.leaf_word[w0 + kb];
+            const uint32_t jb = W.leaf_word[w0 + kb], wb = w0 + jb;
             const int lb = (int)W.len[wb];
             const int m = la < lb ? la : lb;
-            const int k = d_lcp(a, la, W.ch + W.off[wb], lb);
+            const int k = (int)mrow[jb];
             if (k < m && W.npos[W.off[wb] + k] < ta[k]) before++;   // same depth: positions order like first-word indices
         }
         for (int o = 32; o > 0; o >>= 1) before += __shfl_xor(before, o, 64);
@@ -573,18 +573,19 @@ __global__ __launch_bounds__(256) void k_leaf_rank(Words W, Jobs J) {
 
 // k_leaf_rank for jobs with few leaves (a 100-200x site has a few dozen): one wave per leaf, no LDS, no barrier, and the
 // dependent loads that describe a leaf are resolved for 64 leaves at a time (lane k: the wave's k-th next leaf).
-__global__ __launch_bounds__(256) void k_leaf_rank_wave(Words W, Jobs J) {
+__global__ __launch_bounds__(256) void k_leaf_rank_wave(Words W, Jobs J, const uint16_t *lcpm) {
     const int lane = threadIdx.x & 63;
     const uint32_t wave = blockIdx.x * 4 + (threadIdx.x >> 6), n_waves = gridDim.x * 4;
     const uint32_t n_leaf = W.n_list[4];
     for (uint64_t it0 = wave; it0 < n_leaf; it0 += (uint64_t)n_waves * 64) {
-        uint32_t m_slot = 0, m_w0 = 0, m_nl = 0, m_off = 0, m_la = 0;
+        uint32_t m_slot = 0, m_w0 = 0, m_nl = 0, m_off = 0, m_la = 0, m_rw = 0;
+        unsigned long long m_adj = 0;
         {
             const uint64_t it = it0 + (uint64_t)lane * n_waves;
             if (it < n_leaf) {
                 m_slot = W.leaf_list[it];
                 const uint32_t job = W.job[m_slot];
-                m_w0 = J.w0[job]; m_nl = J.nl[job];
+                m_w0 = J.w0[job]; m_nl = J.nl[job]; m_rw = (J.R[job] + 31) >> 5; m_adj = J.adj_off[job];
                 const uint32_t wa = m_w0 + W.leaf_word[m_slot];
                 m_off = (uint32_t)W.off[wa]; m_la = W.len[wa];
             }
@@ -594,16 +595,16 @@ __global__ __launch_bounds__(256) void k_leaf_rank_wave(Words W, Jobs J) {
             const uint32_t off_a = __shfl(m_off, kk, 64);
             const int la = (int)__shfl(m_la, kk, 64);
             const uint32_t ka = slot - w0;
-            const uint8_t *a = W.ch + off_a;
             const uint32_t *ta = W.npos + off_a;
+            const uint16_t *mrow = lcpm + __shfl(m_adj, kk, 64) * 32 + (size_t)ka * __shfl(m_rw, kk, 64) * 32;   // LCP(leaf, word j) from k_leaf_first
             uint32_t before = 0;
             for (uint32_t kb = lane; kb < nl; kb += 64) {
                 if (kb == ka) continue;
-                const uint32_t wb = w0 + W.leaf_word[w0 + kb];
+                const uint32_t jb = W.leaf_word[w0 + kb], wb = w0 + jb;
                 const int lb = (int)W.len[wb];
                 const uint64_t off_b = W.off[wb];
                 const int m = la < lb ? la : lb;
-                const int k = d_lcp(a, la, W.ch + off_b, lb);
+                const int k = (int)mrow[jb];
                 if (k < m && W.npos[off_b + k] < ta[k]) before++;
             }
             for (int o = 32; o > 0; o >>= 1) before += __shfl_xor(before, o, 64);
@@ -1152,8 +1153,8 @@ int run_consensus(mfk_ctx *ctx, const DevReads &R, const DevParams &P, Consensus
         PROF_LAUNCH(k_node_sums, dim3(nblocks(Wn, NS_WORDS)), dim3(1024), ns_lds, st, W, J, max_len);
         KCHK();
     }
-    if (hm.max_R <= 256) { PROF_LAUNCH(k_leaf_rank_wave, dim3(g_leaf4), dim3(256), 0, st, W, J); }
-    else { PROF_LAUNCH(k_leaf_rank, dim3(g_leaf4), dim3(256), 0, st, W, J); }
+    if (hm.max_R <= 256) { PROF_LAUNCH(k_leaf_rank_wave, dim3(g_leaf4), dim3(256), 0, st, W, J, (const uint16_t *)lcpm); }
+    else { PROF_LAUNCH(k_leaf_rank, dim3(g_leaf4), dim3(256), 0, st, W, J, (const uint16_t *)lcpm); }
     KCHK();
     HIPCHK(hipEventRecord(ctx->ev_join, sb));
     HIPCHK(hipStreamWaitEvent(st, ctx->ev_join, 0));
