@@ -15,6 +15,7 @@ mfk_ctx *mfk_create(int device_id) {
     ctx->pinned = nullptr;
     ctx->pinned_cap = 0;
     ctx->gather_count = nullptr;
+    ctx->hdr_dev = nullptr; ctx->hdr_cap = 0;
     ctx->gather_flag = nullptr; ctx->gather_flag_dev = nullptr;
     ctx->gather_seq = 0;
     ctx->err[0] = 0;
@@ -45,6 +46,7 @@ void mfk_destroy(mfk_ctx *ctx) {
     for (auto &c : ctx->chunks) (void)hipFree(c.p);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     if (ctx->gather_count) (void)hipFree(ctx->gather_count);
+    if (ctx->hdr_dev) (void)hipFree(ctx->hdr_dev);
     if (ctx->gather_flag) (void)hipHostFree(ctx->gather_flag);
     for (auto e : ctx->prof_events) (void)hipEventDestroy(e);
     (void)hipEventDestroy(ctx->ev0);
@@ -337,10 +339,24 @@ int upload_reads(mfk_ctx *ctx, const mfk_reads *in, const mfk_params *pr, DevRea
     if (base >= ((int64_t)1 << 32)) { snprintf(ctx->err, sizeof ctx->err, "total reference length %lld does not fit the 32-bit site axis", (long long)base); return 1; }
     for (int c = 0; c <= nc; c++) h_rs[c] = in->h_contig_read_start[c];
     R->gpos_span = (uint32_t)base;
-    char *d_hdr = aalloc<char>(ctx, bytes);
-    if (!d_hdr) return 1;
-    HIPCHK(hipMemcpyAsync(d_hdr, h, bytes, hipMemcpyHostToDevice, ctx->stream));
-    // no synchronisation: later read-backs into the same pinned bytes are ordered behind this copy on the stream
+    // The header lives in an allocation of its own and is uploaded only when its bytes change: findflanks, pairflanks
+    // and recall on the same reads (and every step of a loop over resident reads) reuse it, which saves a copy and the
+    // gap behind it at the head of every call.
+    const size_t used = (size_t)((char *)(h_base + nc) - h);
+    if (bytes > ctx->hdr_cap) {
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        if (ctx->hdr_dev) (void)hipFree(ctx->hdr_dev);
+        ctx->hdr_dev = nullptr; ctx->hdr_cap = 0; ctx->hdr_last.clear();
+        HIPCHK(hipMalloc((void **)&ctx->hdr_dev, bytes * 2));
+        ctx->hdr_cap = bytes * 2;
+    }
+    char *d_hdr = ctx->hdr_dev;
+    if (ctx->hdr_last.size() != used || memcmp(ctx->hdr_last.data(), h, used) != 0) {
+        ctx->hdr_last.clear();   // stays empty if the copy fails
+        HIPCHK(hipMemcpyAsync(d_hdr, h, bytes, hipMemcpyHostToDevice, ctx->stream));
+        // no synchronisation: later read-backs into the same pinned bytes are ordered behind this copy on the stream
+        ctx->hdr_last.assign(h, h + used);
+    }
     int64_t *d_rs = (int64_t *)d_hdr; int32_t *d_len = (int32_t *)(d_rs + nc + 1); uint32_t *d_base = (uint32_t *)(d_len + nc);
     R->contig_len = d_len; R->contig_rs = d_rs; R->contig_base = d_base;
     P->minlen = pr->min_softclip_length; P->mincount = pr->min_softclip_count; P->minq = pr->min_alignment_quality;

@@ -24,6 +24,8 @@ struct mfk_ctx {
     double last_ms;
     std::vector<Chunk> chunks;      // device arena
     void *pinned; size_t pinned_cap;
+    char *hdr_dev; size_t hdr_cap;   // contig header on the device (own allocation, survives arena resets) ...
+    std::vector<char> hdr_last;      // ... and the bytes it holds: an unchanged header is not uploaded again
     uint32_t *gather_count;         // device word: blocks of the current gather that have finished (the last one resets it)
     uint32_t *gather_flag, *gather_flag_dev;   // pinned word of its own (host / device address) the sequence number lands in
     uint32_t gather_seq;            // sequence number the gather kernel publishes behind its data; the host polls for it
