@@ -181,6 +181,18 @@ __device__ inline void d_fetch_range_wave(const DevReads &R, int32_t contig, int
     *lo_out = a;
     *hi_out = d_wave_lower_bound<int32_t, int32_t>(R.ref_start, a, r1, end);
 }
+// d_fetch_range by the first TWO waves of a workgroup, one bound each (the bounds do not depend on each other: the array
+// is sorted, so the upper bound may search the whole contig): five dependent loads instead of ten.  Call with
+// threadIdx.x < 128; range[0], range[1] (LDS) are valid after the next barrier.  An empty interval gives 0, 0.
+__device__ inline void d_fetch_range_2waves(const DevReads &R, int32_t contig, int32_t start, int32_t end, int64_t *range) {
+    const int w = threadIdx.x >> 6;
+    int64_t v = 0;
+    if (start < end) {
+        const int64_t r0 = R.contig_rs[contig], r1 = R.contig_rs[contig + 1];
+        v = d_wave_lower_bound<int32_t, int32_t>(R.ref_start, r0, r1, w == 0 ? start - R.max_span : end);
+    }
+    if ((threadIdx.x & 63) == 0) range[w] = v;
+}
 __device__ inline int64_t d_pool_index_wave(const DevReads &R, int64_t r) {
     const int64_t lo = d_wave_lower_bound<uint32_t, int64_t>(R.pool_read, 0, R.n_pool, r);
     if (lo >= R.n_pool || (int64_t)R.pool_read[lo] != r) return -1;

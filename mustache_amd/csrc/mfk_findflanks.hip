@@ -456,11 +456,7 @@ __device__ __forceinline__ void d_site_tally(const DevReads &R, const DevParams 
     if (start < 0) start = 0;
     if (end > clen) end = clen;
     if (threadIdx.x < NSETS) cnt[threadIdx.x] = 0;
-    if (threadIdx.x < 64) {   // first wave: cooperative search of the read range
-        int64_t a = 0, b = 0;
-        if (start < end) d_fetch_range_wave(R, contig, start, end, &a, &b);
-        if (threadIdx.x == 0) { range[0] = a; range[1] = b; }
-    }
+    if (threadIdx.x < 128) d_fetch_range_2waves(R, contig, start, end, range);   // first two waves: one bound of the read range each
     __syncthreads();
     const int64_t lo = range[0], hi = range[1];
     uint32_t mine[NSETS];   // per-thread tallies: one LDS atomic per set and wave at the end

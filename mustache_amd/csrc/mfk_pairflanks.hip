@@ -386,11 +386,8 @@ __global__ __launch_bounds__(1024) void k_spanning(DevReads R, DevParams P, Flan
     int32_t start = pos3 - 1, end = pos5 + 2;
     if (start < 0) start = 0;
     if (end > clen) end = clen;
-    if (threadIdx.x < 64) {   // first wave: cooperative search of the read range
-        int64_t a = 0, b = 0;
-        if (start < end) d_fetch_range_wave(R, contig, start, end, &a, &b);
-        if (threadIdx.x == 0) { cnt = 0; range[0] = a; range[1] = b; }
-    }
+    if (threadIdx.x == 0) cnt = 0;
+    if (threadIdx.x < 128) d_fetch_range_2waves(R, contig, start, end, range);   // first two waves: one bound each
     __syncthreads();
     uint32_t mine = 0;
     for (int64_t r = range[0] + threadIdx.x; r < range[1]; r += blockDim.x) {
@@ -473,13 +470,15 @@ __global__ __launch_bounds__(1024) void k_direct_repeats(DevReads R, FlankDev F,
         int64_t idx = threadIdx.x;
         refch[threadIdx.x] = idx < add_start_n ? (uint8_t)'N' : ((es + idx - add_start_n) < glen ? g[es + idx - add_start_n] : (uint8_t)'N');
     }
-    if (threadIdx.x < 64) {   // first wave: cooperative searches
-        int64_t a = 0, b = 0;
-        if (W > 0) d_fetch_range_wave(R, contig, (int32_t)es, (int32_t)ee, &a, &b);
-        // pooled reads of that read range: the per-read lookups below search only this slice of pool_read
-        const int64_t pa = d_wave_lower_bound<uint32_t, int64_t>(R.pool_read, 0, R.n_pool, a);
-        const int64_t pb = d_wave_lower_bound<uint32_t, int64_t>(R.pool_read, pa, R.n_pool, b);
-        if (threadIdx.x == 0) { err = 0; range[0] = a; range[1] = b; prange[0] = pa; prange[1] = pb; }
+    // cooperative searches, two at a time (first two waves, one bound each): the read range of the window, then the
+    // pooled reads of that read range (the per-read lookups below search only this slice of pool_read)
+    if (threadIdx.x == 0) err = 0;
+    if (threadIdx.x < 128) d_fetch_range_2waves(R, contig, W > 0 ? (int32_t)es : 0, W > 0 ? (int32_t)ee : 0, range);
+    __syncthreads();
+    if (threadIdx.x < 128) {
+        const int w = threadIdx.x >> 6;
+        const int64_t pv = d_wave_lower_bound<uint32_t, int64_t>(R.pool_read, 0, R.n_pool, range[w]);
+        if ((threadIdx.x & 63) == 0) prange[w] = pv;
     }
     __syncthreads();
     // reads of bam.fetch(contig, expanded_start, expanded_end): no read filter here (pairflanks.py:311).
