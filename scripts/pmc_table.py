@@ -14,7 +14,7 @@ import sys
 from collections import defaultdict
 
 WIDE_LOAD_KERNELS = ("k_scan_clips",)
-MODELLED = ("k_scan_clips", "k_clip_events_bkt", "k_clip_events", "k_bucket_sort", "k_event_info", "k_classify")
+MODELLED = ("k_scan_clips", "k_clip_events_bkt", "k_clip_events", "k_bucket_sort", "k_event_info", "k_classify", "k_direct_repeats")
 
 
 def short(name):
