@@ -18,9 +18,11 @@
 #include "mfk_host.h"
 
 #include <algorithm>
+#include <stdlib.h>
 
 #define IR_MAXLEN 100      // 40 + 20 + 40 (truncated_flank_length, pairflanks.py:78, 183-186)
 #define IR_MAXREP 8
+#define PW_HOST_MAX 256    // up to this many flanks the candidate pairs are listed on the host (mfk_pairflanks)
 
 struct FlankDev {
     uint32_t n;
@@ -634,8 +636,22 @@ extern "C" int mfk_pairflanks(mfk_ctx *ctx, const mfk_reads *reads, const mfk_pa
         if (f.seq_off + f.seq_len > seq_total) seq_total = f.seq_off + f.seq_len;
         if (i && (flanks[i - 1].contig_id > f.contig_id || (flanks[i - 1].contig_id == f.contig_id && flanks[i - 1].pos > f.pos))) sorted = 0;
     }
+    // Few flanks (a single isolate has a few dozen): pair_all_nearby_flanks runs right here on the host table (same
+    // order as k_pair_window: 5p rows in file order, their 3p partners in file order) and the candidate list travels with
+    // the flank table.  That takes two kernels, a scan and a read-back of the candidate count off the head of the call.
+    std::vector<uint32_t> host_c5, host_c3;
+    const char *nh_env = getenv("MFK_NO_HOST_PAIRS");   // tests: force the device path for small tables too
+    const bool host_pairs = nF <= PW_HOST_MAX && !(nh_env && *nh_env && *nh_env != '0');
+    if (host_pairs)
+        for (uint32_t a = 0; a < nF; a++) {
+            if (flanks[a].orient != 5) continue;
+            const int64_t min_pos = (int64_t)flanks[a].pos - params->max_direct_repeat_length - 1;
+            for (uint32_t b = 0; b < nF; b++)
+                if (flanks[b].orient == 3 && flanks[b].contig_id == flanks[a].contig_id && (int64_t)flanks[b].pos >= min_pos && flanks[b].pos < flanks[a].pos) { host_c5.push_back(a); host_c3.push_back(b); }
+        }
     const size_t o_soff = 0, o_goff = o_soff + (size_t)nF * 8, o_tab = o_goff + ((size_t)nc + 1) * 8, o_rank = o_tab + 6 * (size_t)nF * 4;
-    const size_t o_seqs = o_rank + (size_t)nc * 4, up_bytes = ((o_seqs + (size_t)seq_total + 1) + 255) & ~(size_t)255;
+    const size_t o_c5 = o_rank + (size_t)nc * 4, o_c3 = o_c5 + host_c5.size() * 4;
+    const size_t o_seqs = o_c3 + host_c3.size() * 4, up_bytes = ((o_seqs + (size_t)seq_total + 1) + 255) & ~(size_t)255;
     char *hp = (char *)pinned_buf(ctx, pin_off + up_bytes);
     char *d_up = aalloc<char>(ctx, up_bytes);
     if (!hp || !d_up) return 1;
@@ -650,6 +666,7 @@ extern "C" int mfk_pairflanks(mfk_ctx *ctx, const mfk_reads *reads, const mfk_pa
         memcpy(hp + o_goff, h_genome_off, ((size_t)nc + 1) * 8);
         memcpy(hp + o_rank, h_contig_rank, (size_t)nc * 4);
         if (seq_total) memcpy(hp + o_seqs, flank_seqs, (size_t)seq_total);
+        if (!host_c5.empty()) { memcpy(hp + o_c5, host_c5.data(), host_c5.size() * 4); memcpy(hp + o_c3, host_c3.data(), host_c3.size() * 4); }
     }
     HIPCHK(hipMemcpyAsync(d_up, hp, up_bytes, hipMemcpyHostToDevice, st));   // pinned bytes stay untouched until the final read-back, which is ordered behind this copy
     int32_t *d_tab = (int32_t *)(d_up + o_tab); int64_t *d_soff = (int64_t *)(d_up + o_soff); char *d_seqs = d_up + o_seqs;
@@ -659,20 +676,24 @@ extern "C" int mfk_pairflanks(mfk_ctx *ctx, const mfk_reads *reads, const mfk_pa
     F.total = d_tab + 4 * (size_t)nF; F.seq_len = d_tab + 5 * (size_t)nF; F.seq_off = d_soff; F.seqs = d_seqs;
     // ---- candidate pairs ----------------------------------------------------------------------------------------------
     const unsigned fb = nblocks(nF, 256);
-    uint32_t *cnt = aalloc<uint32_t>(ctx, nF), *coff = aalloc<uint32_t>(ctx, (size_t)nF + 1);
-    if (!cnt || !coff) return 1;
-    PROF_LAUNCH(k_pair_window<false>, dim3(fb), dim3(256), 0, st, F, P.maxdr, sorted, cnt, (const uint32_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr);
-    KCHK();
-    if (int rc = dev_excl_scan32(ctx, cnt, coff, nF)) return rc;
+    uint32_t *cnt = nullptr, *coff = nullptr;
     uint32_t nP = 0;
-    if (int rc = read_back(ctx, coff + nF, &nP, 4)) return rc;
+    if (host_pairs) nP = (uint32_t)host_c5.size();
+    else {
+        cnt = aalloc<uint32_t>(ctx, nF); coff = aalloc<uint32_t>(ctx, (size_t)nF + 1);
+        if (!cnt || !coff) return 1;
+        PROF_LAUNCH(k_pair_window<false>, dim3(fb), dim3(256), 0, st, F, P.maxdr, sorted, cnt, (const uint32_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr);
+        KCHK();
+        if (int rc = dev_excl_scan32(ctx, cnt, coff, nF)) return rc;
+        if (int rc = read_back(ctx, coff + nF, &nP, 4)) return rc;
+    }
     ctx->pstats[0] = nP;
     uint32_t nK = 0, nFin = 0;
     uint32_t h_ps[MFK_N_STATS]; memset(h_ps, 0, sizeof h_ps);
     std::vector<uint32_t> h_fin, h_span, h_c5, h_c3; std::vector<int32_t> h_ir, h_meta; std::vector<char> h_dr; uint32_t stride = 0;
     if (nP > 0) {
         // everything downstream is sized by the candidate count; the kept / final counts stay on the device
-        uint32_t *c5 = aalloc<uint32_t>(ctx, nP), *c3 = aalloc<uint32_t>(ctx, nP);
+        uint32_t *c5 = host_pairs ? (uint32_t *)(d_up + o_c5) : aalloc<uint32_t>(ctx, nP), *c3 = host_pairs ? (uint32_t *)(d_up + o_c3) : aalloc<uint32_t>(ctx, nP);
         int32_t *ir = aalloc<int32_t>(ctx, 6 * (size_t)nP);
         uint64_t *keys = aalloc<uint64_t>(ctx, nP), *keys2 = aalloc<uint64_t>(ctx, nP), *kk2 = aalloc<uint64_t>(ctx, nP), *kk = nullptr;
         uint32_t *vals = aalloc<uint32_t>(ctx, nP), *order = aalloc<uint32_t>(ctx, nP);
@@ -690,8 +711,10 @@ extern "C" int mfk_pairflanks(mfk_ctx *ctx, const mfk_reads *reads, const mfk_pa
         if (!c5 || !c3 || !ir || !keys || !keys2 || !kk2 || !vals || !order || !best5 || !best3 || !used5 || !used3 || !state || !kflag || !kscan || !jscan ||
             !kept || !spanning || !span_all || !fin || !fin_span || !meta || fill_commit2(z, f)) return 1;
         const unsigned pb = nblocks(nP, 256);
-        PROF_LAUNCH(k_pair_window<true>, dim3(fb), dim3(256), 0, st, F, P.maxdr, sorted, (uint32_t *)nullptr, (const uint32_t *)coff, c5, c3);
-        KCHK();
+        if (!host_pairs) {
+            PROF_LAUNCH(k_pair_window<true>, dim3(fb), dim3(256), 0, st, F, P.maxdr, sorted, (uint32_t *)nullptr, (const uint32_t *)coff, c5, c3);
+            KCHK();
+        }
         // Side streams: direct repeats and spanning reads of every candidate (they depend on the positions only), each on
         // its own stream.  Main stream: inverted repeats -> assign_pairs.  (Timing events of a launch go to the stream of that launch.)
         hipStream_t sb = ctx->stream2, sc = ctx->stream3;

@@ -174,3 +174,24 @@ def test_flankpairs_one_call_equals_two(hip, name):
     assert list(ff2["stats"]) == list(ff["stats"])
     assert pf2["pairs"].tobytes() == pf["pairs"].tobytes() and pf2["strs"] == pf["strs"] and list(pf2["stats"]) == list(pf["stats"])
     assert len(pf["pairs"]) > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["sim_b", "quirks"])
+def test_pair_window_device_path(hip, name, monkeypatch):
+    """Small flank tables list their candidate pairs on the host; MFK_NO_HOST_PAIRS forces the kernels that large tables
+    use (k_pair_window + scan + rocPRIM sorts need > 256 flanks otherwise).  Same pairs table either way."""
+    import torch
+    case = util.load_json(name)
+    rs = util.case_readset(case)
+    packed = pack_reads(rs.contigs, rs, pool="all")
+    R = device_reads(hip, packed, "cuda:0")
+    params = lib.make_params(**dict(case["findflanks_params"], **case["pairflanks_params"]))
+    g, goff = pfh.genome_arrays(case["genome"], packed.contig_names)
+    gd = torch.from_numpy(g).to("cuda:0")
+    ranks = pfh.contig_ranks(packed.contig_names)
+    ff, pf = hip.run_flankpairs(R, params, ranks, gd, goff)
+    monkeypatch.setenv("MFK_NO_HOST_PAIRS", "1")
+    ff2, pf2 = hip.run_flankpairs(R, params, ranks, gd, goff)
+    assert pf2["pairs"].tobytes() == pf["pairs"].tobytes() and pf2["strs"] == pf["strs"] and list(pf2["stats"]) == list(pf["stats"])
+    assert len(pf["pairs"]) > 0
