@@ -113,6 +113,37 @@ __global__ void k_job_meta(ConsensusIO io, Jobs J, CMeta *meta) {
     if (R) atomicMax(&meta->max_R, R);
 }
 
+// k_job_meta and the two scans over the job slots (first word, first adjacency word) in ONE launch of one workgroup: up to
+// JM_ONE_MAX job slots (a few thousand sites) three launches cost more than the work
+#define JM_ONE_MAX 16384
+__global__ __launch_bounds__(1024) void k_job_meta_scan(ConsensusIO io, Jobs J, CMeta *meta) {
+    __shared__ uint32_t sh[16];
+    __shared__ unsigned long long sh64[16];
+    uint32_t run32 = 0, maxR = 0;
+    unsigned long long run64 = 0;
+    for (uint32_t base = 0; base < J.n; base += blockDim.x) {   // block-uniform
+        const uint32_t j = base + threadIdx.x;
+        uint32_t R = 0;
+        if (j < J.n) {
+            const uint32_t k = j >> 1, side = j & 1, st = io.act_st[k];
+            if ((st & 4) && (st & (1u << side))) R = io.act_cnt2[j];
+        }
+        const uint32_t aw = R * ((R + 31) >> 5);
+        uint32_t tot32; unsigned long long tot64;
+        const uint32_t o32 = block_excl_scan(R, sh, &tot32);
+        const unsigned long long o64 = block_excl_scan64((unsigned long long)aw, sh64, &tot64);
+        if (j < J.n) {
+            J.R[j] = R; J.nl[j] = 0; J.best[j] = 0xFFFFFFFFu; J.adj_words[j] = aw;
+            J.w0[j] = run32 + o32; J.adj_off[j] = run64 + o64;
+            if (R > maxR) maxR = R;
+        }
+        run32 += tot32; run64 += tot64;
+        __syncthreads();
+    }
+    if (maxR) atomicMax(&meta->max_R, maxR);
+    if (threadIdx.x == 0) { J.w0[J.n] = run32; J.adj_off[J.n] = run64; }
+}
+
 // first / second read of every word (combine_softclip_seq_quals_*: one or two reads per name, findflanks.py:932-1027);
 // one block per active site.  Phase 1 numbers the word-starting events of each kept side (block scan over the side's
 // events, offset by the job's first word) into wid[]; phase 2 fills the word table and attaches the second reads.
@@ -1075,10 +1106,15 @@ int run_consensus(mfk_ctx *ctx, const DevReads &R, const DevParams &P, Consensus
         if (!wid || !J.w0 || !J.R || !J.nl || !J.adj_words || !J.adj_off || !J.best || !J.giant || !J.longest || !W.first || !W.job || !W.len || !W.src || !W.off ||
             !W.is_leaf || !W.leaf_word || !W.cl_count || !W.cl_len || !W.cl_key || !W.leaf_list || !W.rep_list || !W.share || !W.out_list || fill_commit2(z, f)) return 1;
     }
-    PROF_LAUNCH(k_job_meta, dim3(nblocks(J.n, 256)), dim3(256), 0, st, io, J, meta);
-    KCHK();
-    if (int rc = dev_excl_scan32(ctx, J.R, J.w0, J.n)) return rc;            // first word of every job; J.w0[J.n] = number of words
-    if (int rc = dev_excl_scan64(ctx, J.adj_words, J.adj_off, J.n)) return rc;
+    if (J.n <= JM_ONE_MAX) {
+        PROF_LAUNCH(k_job_meta_scan, dim3(1), dim3(1024), 0, st, io, J, meta);
+        KCHK();
+    } else {
+        PROF_LAUNCH(k_job_meta, dim3(nblocks(J.n, 256)), dim3(256), 0, st, io, J, meta);
+        KCHK();
+        if (int rc = dev_excl_scan32(ctx, J.R, J.w0, J.n)) return rc;            // first word of every job; J.w0[J.n] = number of words
+        if (int rc = dev_excl_scan64(ctx, J.adj_words, J.adj_off, J.n)) return rc;
+    }
     PROF_LAUNCH(k_word_reads, dim3(n_act), dim3(256), 0, st, R, P, io, (const uint32_t *)J.w0, wid, W);
     KCHK();
     const uint32_t *n_words_p = J.w0 + J.n;

@@ -233,3 +233,18 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t *sh, ui
     *total = tot;
     return base + inc - v;
 }
+
+// 64-bit variant (sh = 16 x uint64 of LDS for up to 1024 threads)
+__device__ __forceinline__ unsigned long long block_excl_scan64(unsigned long long v, unsigned long long *sh, unsigned long long *total) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    unsigned long long inc = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const unsigned long long t = __shfl_up(inc, d, 64); if (lane >= d) inc += t; }
+    __syncthreads();
+    if (lane == 63) sh[w] = inc;
+    __syncthreads();
+    unsigned long long base = 0, tot = 0;
+    for (int i = 0; i < nw; i++) { const unsigned long long s = sh[i]; if (i < w) base += s; tot += s; }
+    *total = tot;
+    return base + inc - v;
+}

@@ -543,6 +543,55 @@ __global__ void k_ratio_filter(ActTab A, uint32_t n_act, double minratio, double
     if (threadIdx.x == 0 && c) atomicAdd(stat, (uint32_t)c);
 }
 
+// the min-distance stencil of k_mindistance on a status array in LDS (one workgroup, n <= blockDim.x): thread i's new status
+__device__ __forceinline__ uint32_t d_mindistance_lds(const uint32_t *gpos, const uint32_t *cnt2, const uint32_t *st_lds, uint32_t i, uint32_t n, int mindist) {
+    uint32_t s = st_lds[i];
+    if (!(s & 4)) return s;
+    const uint32_t g = gpos[i], md = mindist < 0 ? 0u : (uint32_t)mindist;
+    if (cnt2[2 * i] > 0) {
+        bool found = false;
+        if (mindist >= 1)
+            for (int64_t j = (int64_t)i - 1; j >= 0 && g - gpos[j] <= md; j--)
+                if ((st_lds[j] & 4) && cnt2[2 * j + 1] > 0) { found = true; break; }
+        if (!found) s &= ~1u;
+    }
+    if (cnt2[2 * i + 1] > 0) {
+        bool found = false;
+        if (mindist >= 1)
+            for (uint32_t j = i + 1; j < n && gpos[j] - g <= md; j++)
+                if ((st_lds[j] & 4) && cnt2[2 * j] > 0) { found = true; break; }
+        if (!found) s &= ~2u;
+    }
+    if (!(s & 3)) s &= ~4u;
+    return s;
+}
+
+// k_ratio_filter followed by k_mindistance for up to 1024 active sites: one workgroup, one launch
+__global__ __launch_bounds__(1024) void k_ratio_mindist(ActTab A, uint32_t n_act, double minratio, double maxir, int mindist, uint32_t *st_out, uint32_t *stat_ratio, uint32_t *stat_dist) {
+    __shared__ uint32_t st_lds[1024];
+    const uint32_t k = threadIdx.x;
+    uint32_t s = 0;
+    if (k < n_act) {
+        s = A.st[k];
+        if (s & 4) {
+            const uint32_t *c = A.counts + 8 * k;
+            uint32_t sc5 = A.cnt2[2 * k], sc3 = A.cnt2[2 * k + 1];
+            uint32_t run = c[0], si5 = c[1], si3 = c[2], li5 = c[3], li3 = c[4], del = c[5], up = c[6], down = c[7];
+            double tot = (double)(sc5 + sc3 + run + si5 + si3 + li5 + li3 + del);     // get_total_count 789-795 (Q7)
+            if (s & 1) { if ((double)(sc5 + li5 + li3) / tot < minratio || (double)(si5 + del) / tot > maxir) s &= ~1u; }
+            if (s & 2) { if ((double)(sc3 + li5 + li3) / tot < minratio || (double)(si3 + del) / tot > maxir) s &= ~2u; }
+            if (s & 3) { if ((double)down / tot > maxir || (double)up / tot > maxir) s &= ~3u; }
+            if (!(s & 3)) s &= ~4u;
+        }
+    }
+    st_lds[k] = s;
+    const int c1 = __syncthreads_count((int)((s >> 2) & 1));
+    uint32_t s2 = 0;
+    if (k < n_act) { s2 = d_mindistance_lds(A.gpos, A.cnt2, st_lds, k, n_act, mindist); st_out[k] = s2; }
+    const int c2 = __syncthreads_count((int)((s2 >> 2) & 1));
+    if (threadIdx.x == 0) { if (c1) atomicAdd(stat_ratio, (uint32_t)c1); if (c2) atomicAdd(stat_dist, (uint32_t)c2); }
+}
+
 // ---- consensus filters findflanks.py:241-342 -----------------------------------------------------------------------
 __global__ void k_consensus_filters(ActTab A, uint32_t n_act, const uint32_t *n_pass_len, const uint32_t *n_pass_both, uint32_t *stats) {
     uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
@@ -560,6 +609,33 @@ __global__ void k_consensus_filters(ActTab A, uint32_t n_act, const uint32_t *n_
     atomicAdd(&stats[7], n7);
     atomicAdd(&stats[8], n8);   // filter_multiple_consensus_sequences keeps one per remaining side
     A.st[k] = s;
+}
+
+// k_consensus_filters followed by the last k_mindistance for up to 1024 active sites: one workgroup, one launch
+__global__ __launch_bounds__(1024) void k_consfilters_mindist(ActTab A, uint32_t n_act, const uint32_t *n_pass_len, const uint32_t *n_pass_both, int mindist, uint32_t *st_out, uint32_t *stats) {
+    __shared__ uint32_t st_lds[1024];
+    const uint32_t k = threadIdx.x;
+    uint32_t s = 0;
+    if (k < n_act) {
+        s = A.st[k];
+        if (s & 4) {
+            uint32_t n6 = 0, n7 = 0, n8 = 0;
+            for (int side = 0; side < 2; side++) if (s & (1u << side)) { uint32_t c = n_pass_len[2 * k + side]; if (!c) s &= ~(1u << side); else n6 += c; }
+            if (!(s & 3)) s &= ~4u;
+            else {
+                atomicAdd(&stats[6], n6);
+                for (int side = 0; side < 2; side++) if (s & (1u << side)) { uint32_t c = n_pass_both[2 * k + side]; if (!c) s &= ~(1u << side); else { n7 += c; n8 += 1; } }
+                if (!(s & 3)) s &= ~4u;
+                else { atomicAdd(&stats[7], n7); atomicAdd(&stats[8], n8); }
+            }
+        }
+    }
+    st_lds[k] = s;
+    __syncthreads();
+    uint32_t s2 = 0;
+    if (k < n_act) { s2 = d_mindistance_lds(A.gpos, A.cnt2, st_lds, k, n_act, mindist); st_out[k] = s2; }
+    const int c2 = __syncthreads_count((int)((s2 >> 2) & 1));
+    if (threadIdx.x == 0 && c2) atomicAdd(&stats[9], (uint32_t)c2);
 }
 
 // =====================================================================================================================
@@ -699,6 +775,12 @@ extern "C" int mfk_findflanks(mfk_ctx *ctx, const mfk_reads *reads, const mfk_pa
             PROF_LAUNCH(k_classify, dim3(n_act), dim3(n_act >= 2048 ? 256 : 1024), 0, st, R, P, A, n_act);
             KCHK();
         }
+        const bool one_wg = n_act <= 1024;   // a few hundred sites: filter pairs in one launch of one workgroup
+        if (one_wg && stop_after >= MFK_STAGE_MINDIST2) {
+            PROF_LAUNCH(k_ratio_mindist, dim3(1), dim3(1024), 0, st, A, n_act, P.minratio, P.maxir, P.mindist, st2, d_stats + 4, d_stats + 5);
+            KCHK();
+            uint32_t *t = A.st; A.st = st2; st2 = t;
+        } else {
         if (stop_after >= MFK_STAGE_RATIOS) {
             PROF_LAUNCH(k_ratio_filter, dim3(ab), dim3(256), 0, st, A, n_act, P.minratio, P.maxir, d_stats + 4);
             KCHK();
@@ -708,15 +790,22 @@ extern "C" int mfk_findflanks(mfk_ctx *ctx, const mfk_reads *reads, const mfk_pa
             KCHK();
             uint32_t *t = A.st; A.st = st2; st2 = t;
         }
+        }
         if (stop_after >= MFK_STAGE_CONSENSUS) {
             io.ev_keys = ev_sorted; io.ev_info = ev_info; io.n_events = E;
             io.n_act = n_act; io.act_site = A.site; io.act_st = A.st; io.act_cnt2 = A.cnt2;
             io.site_ev_begin = T.ev_begin; io.site_ev_mid = T.ev_mid; io.site_ev_end = T.ev_end;
             if (int rc = run_consensus(ctx, R, P, io)) return rc;
-            PROF_LAUNCH(k_consensus_filters, dim3(ab), dim3(256), 0, st, A, n_act, (const uint32_t *)io.n_pass_len, (const uint32_t *)io.n_pass_both, d_stats);
-            KCHK();
+            if (one_wg && stop_after >= MFK_STAGE_ALL) {
+                PROF_LAUNCH(k_consfilters_mindist, dim3(1), dim3(1024), 0, st, A, n_act, (const uint32_t *)io.n_pass_len, (const uint32_t *)io.n_pass_both, P.mindist, st2, d_stats);
+                KCHK();
+                uint32_t *t = A.st; A.st = st2; st2 = t;
+            } else {
+                PROF_LAUNCH(k_consensus_filters, dim3(ab), dim3(256), 0, st, A, n_act, (const uint32_t *)io.n_pass_len, (const uint32_t *)io.n_pass_both, d_stats);
+                KCHK();
+            }
         }
-        if (stop_after >= MFK_STAGE_ALL) {
+        if (stop_after >= MFK_STAGE_ALL && !one_wg) {
             PROF_LAUNCH(k_mindistance, dim3(ab), dim3(256), 0, st, (const uint32_t *)A.gpos, (const uint32_t *)A.cnt2, (const uint32_t *)A.st, st2, (const uint32_t *)nullptr, n_act, P.mindist, d_stats + 9, (uint32_t *)nullptr);
             KCHK();
             uint32_t *t = A.st; A.st = st2; st2 = t;
