@@ -194,7 +194,12 @@ __global__ __launch_bounds__(256) void k_gather(GatherArgs g, uint8_t *dst, uint
         const uint8_t *src = g.src[i];
         uint8_t *out = dst + g.off[i];
         const uint32_t nb = g.bytes[i];
-        if ((((uintptr_t)src | (uintptr_t)out) & 3) == 0) {
+        if ((((uintptr_t)src | (uintptr_t)out) & 15) == 0) {   // 16 bytes per lane: stores to host memory are few and wide
+            const uint32_t nq = nb >> 4;
+            for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < nq; k += gridDim.x * blockDim.x)
+                reinterpret_cast<uint4 *>(out)[k] = reinterpret_cast<const uint4 *>(src)[k];
+            for (uint32_t k = (nq << 4) + blockIdx.x * blockDim.x + threadIdx.x; k < nb; k += gridDim.x * blockDim.x) out[k] = src[k];
+        } else if ((((uintptr_t)src | (uintptr_t)out) & 3) == 0) {
             const uint32_t nw = nb >> 2;
             for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < nw; k += gridDim.x * blockDim.x)
                 reinterpret_cast<uint32_t *>(out)[k] = reinterpret_cast<const uint32_t *>(src)[k];
@@ -213,6 +218,25 @@ __global__ __launch_bounds__(256) void k_gather(GatherArgs g, uint8_t *dst, uint
     }
 }
 
+// host -> device for the small staging blocks (contig header, flank table): a kernel that reads the pinned bytes through
+// their device address; launching it costs the host less than a hipMemcpyAsync and the stream no copy-engine hand-over
+__global__ __launch_bounds__(256) void k_upload(const uint4 *src, uint4 *dst, size_t n16) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+int upload_pinned(mfk_ctx *ctx, void *dev, const void *pinned_host, size_t bytes) {
+    void *dsrc = nullptr;
+    if ((bytes & 15) == 0 && (((uintptr_t)dev | (uintptr_t)pinned_host) & 15) == 0 && bytes <= ((size_t)1 << 22) &&
+        hipHostGetDevicePointer(&dsrc, const_cast<void *>(pinned_host), 0) == hipSuccess) {
+        const size_t n16 = bytes / 16;
+        size_t blocks = (n16 + 255) / 256; if (blocks < 1) blocks = 1; if (blocks > 256) blocks = 256;
+        hipLaunchKernelGGL(k_upload, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, (const uint4 *)dsrc, (uint4 *)dev, n16);
+        KCHK();
+        return 0;
+    }
+    HIPCHK(hipMemcpyAsync(dev, pinned_host, bytes, hipMemcpyHostToDevice, ctx->stream));
+    return 0;
+}
+
 int ReadBatch::flush() {
     if (items.empty()) return 0;
     char *pin = (char *)pinned_buf(ctx, total);
@@ -224,7 +248,7 @@ int ReadBatch::flush() {
         GatherArgs g; g.n = (int)items.size();
         size_t biggest = 0;
         for (int i = 0; i < g.n; i++) { g.src[i] = (const uint8_t *)items[i].dev; g.bytes[i] = (uint32_t)items[i].bytes; g.off[i] = (uint32_t)items[i].off; if (items[i].bytes > biggest) biggest = items[i].bytes; }
-        unsigned bx = (unsigned)((biggest / 4 + 255) / 256); if (bx < 1) bx = 1; if (bx > 64) bx = 64;
+        unsigned bx = (unsigned)((biggest / 16 + 255) / 256); if (bx < 1) bx = 1; if (bx > 64) bx = 64;
         uint32_t seq = ++ctx->gather_seq;
         if (seq == 0) seq = ++ctx->gather_seq;
         volatile uint32_t *hflag = ctx->gather_flag;   // sequence numbers only grow: no reset needed between gathers
@@ -353,7 +377,7 @@ int upload_reads(mfk_ctx *ctx, const mfk_reads *in, const mfk_params *pr, DevRea
     char *d_hdr = ctx->hdr_dev;
     if (ctx->hdr_last.size() != used || memcmp(ctx->hdr_last.data(), h, used) != 0) {
         ctx->hdr_last.clear();   // stays empty if the copy fails
-        HIPCHK(hipMemcpyAsync(d_hdr, h, bytes, hipMemcpyHostToDevice, ctx->stream));
+        if (int rc = upload_pinned(ctx, d_hdr, h, bytes)) return rc;
         // no synchronisation: later read-backs into the same pinned bytes are ordered behind this copy on the stream
         ctx->hdr_last.assign(h, h + used);
     }

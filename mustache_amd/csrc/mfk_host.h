@@ -79,6 +79,7 @@ void prof_collect(mfk_ctx *ctx);               // call after the stream has been
 void arena_reset(mfk_ctx *ctx);                       // frees nothing on the fast path; merges chunks after growth
 void *arena_alloc(mfk_ctx *ctx, size_t bytes);        // 256-byte aligned device memory valid until the next reset
 template <typename T> static inline T *aalloc(mfk_ctx *ctx, size_t n) { return (T *)arena_alloc(ctx, (n ? n : 1) * sizeof(T)); }
+int upload_pinned(mfk_ctx *ctx, void *dev, const void *pinned_host, size_t bytes);   // small host -> device copy of pinned_buf bytes by a kernel
 void *pinned_buf(mfk_ctx *ctx, size_t bytes);      // grows (after draining the stream) and returns the staging buffer
 
 // device -> host read-backs: one stream synchronisation per batch

@@ -668,7 +668,7 @@ extern "C" int mfk_pairflanks(mfk_ctx *ctx, const mfk_reads *reads, const mfk_pa
         if (seq_total) memcpy(hp + o_seqs, flank_seqs, (size_t)seq_total);
         if (!host_c5.empty()) { memcpy(hp + o_c5, host_c5.data(), host_c5.size() * 4); memcpy(hp + o_c3, host_c3.data(), host_c3.size() * 4); }
     }
-    HIPCHK(hipMemcpyAsync(d_up, hp, up_bytes, hipMemcpyHostToDevice, st));   // pinned bytes stay untouched until the final read-back, which is ordered behind this copy
+    if (int rc = upload_pinned(ctx, d_up, hp, up_bytes)) return rc;   // pinned bytes stay untouched until the final read-back, which is ordered behind this copy
     int32_t *d_tab = (int32_t *)(d_up + o_tab); int64_t *d_soff = (int64_t *)(d_up + o_soff); char *d_seqs = d_up + o_seqs;
     int32_t *d_rank = (int32_t *)(d_up + o_rank); int64_t *d_goff = (int64_t *)(d_up + o_goff);
     HIPCHK(hipEventRecord(ctx->ev0, st));
