@@ -22,6 +22,7 @@
 
 #define IR_MAXLEN 100      // 40 + 20 + 40 (truncated_flank_length, pairflanks.py:78, 183-186)
 #define IR_MAXREP 8
+#define IR_CM 168          // padded row of column codes: a lane reaches index 63 + 99 + 1
 #define PW_HOST_MAX 256    // up to this many flanks the candidate pairs are listed on the host (mfk_pairflanks)
 
 struct FlankDev {
@@ -77,36 +78,34 @@ __device__ void d_ir_detect(const uint8_t *code, int L, int16_t *S, uint8_t *mas
     // still written to LDS, but only the traceback reads it; the column characters are fetched one diagonal ahead, so a
     // diagonal is a short chain of VALU instructions instead of three LDS round trips and a barrier.
     const int iA = lane, iB = lane + 64;
-    uint8_t *cm = mask + IR_MAXLEN + 4;   // code | masked << 3, rebuilt every pass (the caller's mask array has room for it)
+    uint8_t *cm = mask + IR_MAXLEN + 4;   // code | masked << 3, rebuilt every pass (the caller's mask array has room for IR_CM entries)
+    // Row A's part of a diagonal is branch-free: cm is padded with "masked N" up to the largest index a lane can reach, so a
+    // cell beyond the matrix scores 0 like any masked cell, its store lands in the unused lower triangle of S (row A never
+    // leaves the array), and the best cell of a row is kept as (score, diagonal) instead of a packed key per cell.
+    for (int i = L + lane; i < IR_CM; i += 64) cm[i] = 12;
     while (nrep < IR_MAXREP) {
         for (int i = lane; i < L; i += 64) { S[i * L + i] = 0; cm[i] = (uint8_t)(code[i] | (mask[i] ? 8 : 0)); }
         __syncthreads();
-        const int cA = iA < L ? cm[iA] : 12, cB = iB < L ? cm[iB] : 12;
-        int cjA = iA + 1 < L ? cm[iA + 1] : 12, cjB = iB + 1 < L ? cm[iB + 1] : 12;
+        const int cA = cm[iA], cB = iB < L ? cm[iB] : 12;
+        const int wantA = cA < 4 ? 3 - cA : 16;   // the code that pairs with row A's base (none for N)
+        int cjA = cm[iA + 1], cjB = iB + 1 < L ? cm[iB + 1] : 12;
         unsigned pA = 0, pB = 0;               // S(i, i+d-1) | S(i, i+d-2) << 16
-        unsigned bestkey = 0;   // score << 16 | (255 - j) << 8 | i : highest score, then smallest j, then largest i
+        int bestvA = 0, bestdA = 0;            // row A: highest score and the first diagonal that reached it (= smallest j)
+        unsigned bestkey = 0;   // row B: score << 16 | (255 - j) << 8 | i : highest score, then smallest j, then largest i
         const int nB = L - 64;  // row B has cells only on diagonals d < L - 64
+        int16_t *sA = S + iA * L + iA;         // S(iA, iA + d) = sA[d]
         for (int d = 1; d < L; d++) {
             unsigned nA = (unsigned)__builtin_amdgcn_update_dpp(0, (int)pA, 0x130 /* wave_shl:1: lane i <- lane i+1 */, 0xF, 0xF, false);
             const unsigned fromB = (unsigned)__builtin_amdgcn_readfirstlane((int)pB);
             if (lane == 63) nA = fromB;
-            // next diagonal's column characters: issued now, used in the next iteration
-            const int ncjA = iA + d + 1 < L ? cm[iA + d + 1] : 12;
-            int vA = 0;
-            const int jA = iA + d;
-            if (jA < L) {
-                if (!((cA | cjA) & 8)) {
-                    const int m = (cA < 4 && cjA < 4 && cA + cjA == 3) ? MATCH : MISMATCH;
-                    vA = (d >= 2 ? (int)(nA >> 16) : 0) + m;
-                    const int up = (int)(nA & 0xFFFF) - GAP, left = (int)(pA & 0xFFFF) - GAP;
-                    if (up > vA) vA = up;
-                    if (left > vA) vA = left;
-                    if (vA < 0) vA = 0;
-                }
-                S[iA * L + jA] = (int16_t)vA;
-                const unsigned key = ((unsigned)vA << 16) | ((unsigned)(255 - jA) << 8) | (unsigned)iA;
-                if (vA > 0 && key > bestkey) bestkey = key;
-            }
+            const int ncjA = cm[iA + d + 1];   // next diagonal's column character: issued now, used in the next iteration
+            const int m = cjA == wantA ? MATCH : MISMATCH;   // a masked column (bit 3) never equals wantA
+            int vA = (int)(nA >> 16) + m;                    // S(i+1, j-1) is 0 on the first two diagonals by construction
+            const int up = (int)(nA & 0xFFFF) - GAP, left = (int)(pA & 0xFFFF) - GAP;
+            vA = max(max(vA, up), max(left, 0));
+            if ((cA | cjA) & 8) vA = 0;
+            sA[d] = (int16_t)vA;
+            if (vA > bestvA) { bestvA = vA; bestdA = d; }
             pA = (pA << 16) | (unsigned)vA;
             cjA = ncjA;
             if (d < nB) {   // wave-uniform
@@ -116,11 +115,11 @@ __device__ void d_ir_detect(const uint8_t *code, int L, int16_t *S, uint8_t *mas
                 const int jB = iB + d;
                 if (jB < L) {
                     if (!((cB | cjB) & 8)) {
-                        const int m = (cB < 4 && cjB < 4 && cB + cjB == 3) ? MATCH : MISMATCH;
-                        vB = (d >= 2 ? (int)(nBv >> 16) : 0) + m;
-                        const int up = (int)(nBv & 0xFFFF) - GAP, left = (int)(pB & 0xFFFF) - GAP;
-                        if (up > vB) vB = up;
-                        if (left > vB) vB = left;
+                        const int mb = (cB < 4 && cjB < 4 && cB + cjB == 3) ? MATCH : MISMATCH;
+                        vB = (d >= 2 ? (int)(nBv >> 16) : 0) + mb;
+                        const int upb = (int)(nBv & 0xFFFF) - GAP, leftb = (int)(pB & 0xFFFF) - GAP;
+                        if (upb > vB) vB = upb;
+                        if (leftb > vB) vB = leftb;
                         if (vB < 0) vB = 0;
                     }
                     S[iB * L + jB] = (int16_t)vB;
@@ -130,6 +129,10 @@ __device__ void d_ir_detect(const uint8_t *code, int L, int16_t *S, uint8_t *mas
                 pB = (pB << 16) | (unsigned)vB;
                 cjB = ncjB;
             }
+        }
+        if (bestvA > 0) {
+            const unsigned keyA = ((unsigned)bestvA << 16) | ((unsigned)(255 - (iA + bestdA)) << 8) | (unsigned)iA;
+            if (keyA > bestkey) bestkey = keyA;
         }
         __syncthreads();
         for (int o = 32; o > 0; o >>= 1) { unsigned other = __shfl_xor(bestkey, o, 64); if (other > bestkey) bestkey = other; }
@@ -178,7 +181,7 @@ __device__ void d_ir_detect(const uint8_t *code, int L, int16_t *S, uint8_t *mas
 // generic entry: sequences given explicitly (mfk_ir_detect)
 __global__ __launch_bounds__(64) void k_ir_seqs(const char *seqs, const int64_t *off, uint32_t n, int32_t *out) {
     __shared__ int16_t S[IR_MAXLEN * IR_MAXLEN];
-    __shared__ uint8_t code[IR_MAXLEN + 4], mask[2 * (IR_MAXLEN + 4)];   // mask | cm (d_ir_detect)
+    __shared__ uint8_t code[IR_MAXLEN + 4], mask[IR_MAXLEN + 4 + IR_CM];   // mask | cm (d_ir_detect)
     __shared__ int32_t rep[4 * IR_MAXREP + 8];
     uint32_t k = blockIdx.x;
     if (k >= n) return;
@@ -201,7 +204,7 @@ __device__ __forceinline__ uint64_t d_assign_key(const FlankDev &F, uint32_t a, 
 // also writes the candidate's sort key for assign_pairs (stable order by IR_length desc, diffcount asc, difflength asc)
 __global__ __launch_bounds__(64) void k_inverted_repeat(FlankDev F, const uint32_t *c5, const uint32_t *c3, uint32_t n, int32_t *out, uint64_t *keys, uint32_t *vals) {
     __shared__ int16_t S[IR_MAXLEN * IR_MAXLEN];
-    __shared__ uint8_t code[IR_MAXLEN + 4], mask[2 * (IR_MAXLEN + 4)];   // mask | cm (d_ir_detect)
+    __shared__ uint8_t code[IR_MAXLEN + 4], mask[IR_MAXLEN + 4 + IR_CM];   // mask | cm (d_ir_detect)
     __shared__ int32_t rep[4 * IR_MAXREP + 8];
     uint32_t k = blockIdx.x;
     if (k >= n) return;
