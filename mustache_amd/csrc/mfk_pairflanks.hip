@@ -446,8 +446,15 @@ __global__ void k_pair_final(const uint32_t *kept, const uint32_t *n_kept, const
 // per candidate pair c: dr_out[c*stride ...] = reference repeat, dr_out[c*stride + half ...] = reads consensus.
 // One block per CANDIDATE pair (like k_spanning, on the side stream next to the inverted-repeat alignment); the host
 // takes the rows of the final pairs.
+// MODE 0: all of it in one workgroup per pair.  A deep isolate has a few dozen pairs with more than a thousand reads over
+// each window, i.e. a few dozen workgroups each walking a long chain: then the reads of a pair are split over gridDim.y
+// workgroups (MODE 1: pile-up of a share of the reads, flushed into per-pair accumulators in HBM by atomics) and a
+// second launch (MODE 2) reads the accumulators and writes the repeats.
+#define DR_ACC (DR_WIN * 17)
+template <int MODE>
 __global__ __launch_bounds__(1024) void k_direct_repeats(DevReads R, FlankDev F, uint32_t n_cand, const uint32_t *c5, const uint32_t *c3,
-                                                        const uint8_t *genome, const int64_t *goff, char *dr_out, uint32_t stride, int32_t *dr_meta /* 3 per pair: ref_len, reads_len, err */) {
+                                                        const uint8_t *genome, const int64_t *goff, char *dr_out, uint32_t stride, int32_t *dr_meta /* 3 per pair: ref_len, reads_len, err */,
+                                                        uint32_t *g_sum, uint32_t *g_first, uint32_t *g_err) {
     __shared__ uint32_t sum[DR_WIN][17];
     __shared__ uint32_t firstr[DR_WIN][17];
     __shared__ uint8_t refch[DR_WIN];
@@ -478,23 +485,33 @@ __global__ __launch_bounds__(1024) void k_direct_repeats(DevReads R, FlankDev F,
     // cooperative searches, two at a time (first two waves, one bound each): the read range of the window, then the
     // pooled reads of that read range (the per-read lookups below search only this slice of pool_read)
     if (threadIdx.x == 0) err = 0;
-    if (threadIdx.x < 128) d_fetch_range_2waves(R, contig, W > 0 ? (int32_t)es : 0, W > 0 ? (int32_t)ee : 0, range);
+    if (MODE != 2 && threadIdx.x < 128) d_fetch_range_2waves(R, contig, W > 0 ? (int32_t)es : 0, W > 0 ? (int32_t)ee : 0, range);
     __syncthreads();
-    if (threadIdx.x < 128) {
+    if (MODE != 2 && threadIdx.x < 128) {
         const int w = threadIdx.x >> 6;
         const int64_t pv = d_wave_lower_bound<uint32_t, int64_t>(R.pool_read, 0, R.n_pool, range[w]);
         if ((threadIdx.x & 63) == 0) prange[w] = pv;
     }
     __syncthreads();
+    // this workgroup's share of the read range (MODE 1: contiguous shares, one per blockIdx.y)
+    int64_t r_begin = 0, r_end = 0;
+    if (MODE != 2) {
+        r_begin = range[0]; r_end = range[1];
+        if (MODE == 1) {
+            const int64_t share = (r_end - r_begin + gridDim.y - 1) / gridDim.y;
+            r_begin += (int64_t)blockIdx.y * share;
+            if (r_begin + share < r_end) r_end = r_begin + share;
+        }
+    }
     // reads of bam.fetch(contig, expanded_start, expanded_end): no read filter here (pairflanks.py:311).
     // Two phases per chunk of reads so that the LDS atomics of one wave instruction go to 50 different columns instead
     // of 64 reads hammering the same column: (1) one thread per read resolves its pool offset and aligned blocks into
     // window-clipped segments in LDS; (2) one wave per segment, lane = window position.
-    for (int64_t rbase = range[0]; rbase < range[1]; rbase += blockDim.x) {
+    for (int64_t rbase = r_begin; rbase < r_end; rbase += blockDim.x) {
         if (threadIdx.x == 0) nseg = 0;
         __syncthreads();
         const int64_t r = rbase + threadIdx.x;
-        if (r < range[1] && d_overlaps(R, r, (int32_t)es) && R.qlen[r] != 0) {
+        if (r < r_end && d_overlaps(R, r, (int32_t)es) && R.qlen[r] != 0) {
             const uint8_t f = R.flags[r];
             int64_t pi = -1;
             {   // the pool usually holds every read of the window: then read r sits at a fixed offset from the range start
@@ -548,6 +565,20 @@ __global__ __launch_bounds__(1024) void k_direct_repeats(DevReads R, FlankDev F,
             for (int u = 0; u < DR_FLIGHT; u++)
                 if (on[u]) { atomicAdd(&sum[col[u]][code[u]], qv[u]); atomicMin(&firstr[col[u]][code[u]], rr[u]); }
         }
+        __syncthreads();
+    }
+    if (MODE == 1) {   // this share's sums into the pair's accumulators; MODE 2 takes it from there
+        for (int i = threadIdx.x; i < DR_ACC; i += blockDim.x) {
+            const uint32_t v = (&sum[0][0])[i], fr = (&firstr[0][0])[i];
+            if (v) atomicAdd(&g_sum[(size_t)c * DR_ACC + i], v);
+            if (fr != 0xFFFFFFFFu) atomicMin(&g_first[(size_t)c * DR_ACC + i], fr);
+        }
+        if (threadIdx.x == 0 && err) atomicOr(&g_err[c], 1u);
+        return;
+    }
+    if (MODE == 2) {
+        for (int i = threadIdx.x; i < DR_ACC; i += blockDim.x) { (&sum[0][0])[i] = g_sum[(size_t)c * DR_ACC + i]; (&firstr[0][0])[i] = g_first[(size_t)c * DR_ACC + i]; }
+        if (threadIdx.x == 0) err = (int)g_err[c];
         __syncthreads();
     }
     int32_t *meta = dr_meta + 3 * (size_t)k;
@@ -708,9 +739,22 @@ extern "C" int mfk_pairflanks(mfk_ctx *ctx, const mfk_reads *reads, const mfk_pa
         int32_t *meta = aalloc<int32_t>(ctx, 3 * (size_t)nP);
         stride = 2 * (((uint32_t)P.maxdr + 1 + 15) & ~15u);
         uint32_t *d_pstats = nullptr, *kv = nullptr, *jflag = nullptr; char *dr = nullptr;
+        // few pairs under deep coverage: the reads over a pair's direct-repeat window (about coverage x (150 + 50) / 150 of
+        // them) are split over several workgroups
+        uint32_t dr_split = 1;
+        uint32_t *g_sum = nullptr, *g_first = nullptr, *g_err = nullptr;
+        if (nP <= 128) {
+            int64_t ref_total = 0;
+            for (int c = 0; c < nc; c++) ref_total += reads->h_contig_len[c];
+            const double per_window = ref_total > 0 ? (double)reads->n_reads * (200.0 + R.max_span) / (double)ref_total : 0.0;
+            dr_split = (uint32_t)(per_window / 192.0);
+            if (dr_split > 8) dr_split = 8;
+            if (dr_split < 1) dr_split = 1;
+        }
         FillGroup z(ctx, 0), f(ctx, 0xFF);
         z.want(&d_pstats, MFK_N_STATS); z.want(&kv, nP); z.want(&jflag, nP); z.want(&dr, (size_t)nP * stride);
         f.want(&kk, nP);   // unused sort keys stay ~0 and sort behind the kept pairs
+        if (dr_split > 1) { z.want(&g_sum, (size_t)nP * DR_ACC); z.want(&g_err, nP); f.want(&g_first, (size_t)nP * DR_ACC); }
         if (!c5 || !c3 || !ir || !keys || !keys2 || !kk2 || !vals || !order || !best5 || !best3 || !used5 || !used3 || !state || !kflag || !kscan || !jscan ||
             !kept || !spanning || !span_all || !fin || !fin_span || !meta || fill_commit2(z, f)) return 1;
         const unsigned pb = nblocks(nP, 256);
@@ -724,9 +768,18 @@ extern "C" int mfk_pairflanks(mfk_ctx *ctx, const mfk_reads *reads, const mfk_pa
         HIPCHK(hipEventRecord(ctx->ev_fork, st));
         HIPCHK(hipStreamWaitEvent(sb, ctx->ev_fork, 0));
         HIPCHK(hipStreamWaitEvent(sc, ctx->ev_fork, 0));
-        PROF_LAUNCH(k_direct_repeats, dim3(nP), dim3(nP >= 2048 ? 256 : 1024), 0, sb, R, F, nP, (const uint32_t *)c5, (const uint32_t *)c3,
-                    genome, (const int64_t *)d_goff, dr, stride, meta);
-        KCHK();
+        if (dr_split > 1) {
+            PROF_LAUNCH(k_direct_repeats<1>, dim3(nP, dr_split), dim3(1024), 0, sb, R, F, nP, (const uint32_t *)c5, (const uint32_t *)c3,
+                        genome, (const int64_t *)d_goff, dr, stride, meta, g_sum, g_first, g_err);
+            KCHK();
+            PROF_LAUNCH(k_direct_repeats<2>, dim3(nP), dim3(64), 0, sb, R, F, nP, (const uint32_t *)c5, (const uint32_t *)c3,
+                        genome, (const int64_t *)d_goff, dr, stride, meta, g_sum, g_first, g_err);
+            KCHK();
+        } else {
+            PROF_LAUNCH(k_direct_repeats<0>, dim3(nP), dim3(nP >= 2048 ? 256 : 1024), 0, sb, R, F, nP, (const uint32_t *)c5, (const uint32_t *)c3,
+                        genome, (const int64_t *)d_goff, dr, stride, meta, (uint32_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr);
+            KCHK();
+        }
         HIPCHK(hipEventRecord(ctx->ev_join, sb));
         PROF_LAUNCH(k_spanning, dim3(nP), dim3(nP >= 2048 ? 256 : 1024), 0, sc, R, P, F, (const uint32_t *)c5, (const uint32_t *)c3, nP, span_all);
         KCHK();
