@@ -208,7 +208,6 @@ __global__ __launch_bounds__(256) void k_word_reads(DevReads R, DevParams P, Con
 
 // one thread per word: length, and where its characters are (a binary search of the pool per read: thousands of
 // independent searches in flight instead of one latency chain per wave in k_word_fill)
-template <bool WIDE>
 __global__ void k_word_len(DevReads R, Words W, const uint32_t *n_words, CMeta *meta) {
     uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
     if (w >= *n_words) return;
@@ -217,7 +216,7 @@ __global__ void k_word_len(DevReads R, Words W, const uint32_t *n_words, CMeta *
     if (W.nextra[w] > 1) atomicOr(&meta->err, ERR_READ_NUMBER);      // findflanks.py:976-978 / 1025-1027
     uint8_t f1 = R.flags[r1];
     int l1 = side == 0 ? d_rlen(R, r1, f1) : d_llen(R, r1, f1), l2 = 0;
-    const int64_t p1 = WIDE ? d_pool_index16(R, r1) : d_pool_index(R, r1);
+    const int64_t p1 = d_pool_index(R, r1);
     int64_t p2 = -1;
     WordSrc src;
     src.o1 = p1 >= 0 ? R.pool_off[p1] : 0; src.o2 = 0;
@@ -225,7 +224,7 @@ __global__ void k_word_len(DevReads R, Words W, const uint32_t *n_words, CMeta *
     if (r2 >= 0) {
         uint8_t f2 = R.flags[r2];
         l2 = side == 0 ? d_rlen(R, r2, f2) : d_llen(R, r2, f2);
-        p2 = WIDE ? d_pool_index16(R, r2) : d_pool_index(R, r2);
+        p2 = d_pool_index(R, r2);
         src.o2 = p2 >= 0 ? R.pool_off[p2] : 0;
         src.q2len = R.qlen[r2];
     }
@@ -1119,9 +1118,7 @@ int run_consensus(mfk_ctx *ctx, const DevReads &R, const DevParams &P, Consensus
     PROF_LAUNCH(k_word_reads, dim3(n_act), dim3(256), 0, st, R, P, io, (const uint32_t *)J.w0, wid, W);
     KCHK();
     const uint32_t *n_words_p = J.w0 + J.n;
-    // 16-ary pool lookups (five load round trips instead of eighteen, 16 x the loads) while the events are few
-    if (E <= (1u << 20)) { PROF_LAUNCH(k_word_len<true>, dim3(nblocks(E, 256)), dim3(256), 0, st, R, W, n_words_p, meta); }
-    else { PROF_LAUNCH(k_word_len<false>, dim3(nblocks(E, 256)), dim3(256), 0, st, R, W, n_words_p, meta); }
+    PROF_LAUNCH(k_word_len, dim3(nblocks(E, 256)), dim3(256), 0, st, R, W, n_words_p, meta);
     KCHK();
     if (int rc = dev_excl_scan64(ctx, W.plen, W.off, E)) return rc;   // plen is 0 beyond the last word: off[E] = all characters
     uint32_t Wn = 0; uint64_t adj_total = 0;

@@ -212,27 +212,6 @@ __device__ inline int64_t d_pool_index(const DevReads &R, int64_t r) {
     if (lo >= R.n_pool || (int64_t)R.pool_read[lo] != r) return -1;
     return lo;
 }
-// d_pool_index with 16-ary steps: the 15 pivots of a step are independent loads, so a lookup among 2^18 pooled reads is
-// five load round trips instead of eighteen (16 x the loads: for workloads of up to a few hundred thousand lookups)
-__device__ inline int64_t d_pool_index16(const DevReads &R, int64_t r) {
-    int64_t lo = 0, hi = R.n_pool;   // first entry >= r lies in [lo, hi]
-    while (hi - lo > 16) {
-        const int64_t step = (hi - lo + 15) >> 4;
-        int c = 0;
-#pragma unroll
-        for (int i = 1; i < 16; i++) { const int64_t p = lo + i * step - 1; c += (p < hi && (int64_t)R.pool_read[p] < r) ? 1 : 0; }   // sorted: the first c pivots are smaller
-        const int64_t nlo = lo + c * step;
-        int64_t nhi = c < 15 ? nlo + step - 1 : hi;   // the (c+1)-th pivot is >= r; behind the last pivot nothing was tested
-        if (nhi > hi) nhi = hi;
-        lo = nlo < hi ? nlo : hi; hi = nhi;
-    }
-    int c = 0;
-#pragma unroll
-    for (int i = 0; i < 16; i++) c += (lo + i < hi && (int64_t)R.pool_read[lo + i] < r) ? 1 : 0;
-    lo += c;
-    if (lo >= R.n_pool || (int64_t)R.pool_read[lo] != r) return -1;
-    return lo;
-}
 __device__ __forceinline__ uint8_t d_pool_base(const DevReads &R, uint64_t k) { return (R.pool_bases[k >> 1] >> ((~k & 1) << 2)) & 15; }
 
 // ---- block-wide helpers (256 threads = 4 waves) -----------------------------------------------------------------
