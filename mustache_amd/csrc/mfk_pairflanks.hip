@@ -22,7 +22,8 @@
 
 #define IR_MAXLEN 100      // 40 + 20 + 40 (truncated_flank_length, pairflanks.py:78, 183-186)
 #define IR_MAXREP 8
-#define IR_CM 168          // padded row of column codes: a lane reaches index 63 + 99 + 1
+#define IR_CM 168          // padded row of column codes: a lane reaches index 127 + 35 + 1
+#define IR_S (128 * IR_MAXLEN + 128 + 64)   // score matrix + room for the rows 64..127 of lanes beyond the matrix
 #define PW_HOST_MAX 256    // up to this many flanks the candidate pairs are listed on the host (mfk_pairflanks)
 
 struct FlankDev {
@@ -86,14 +87,14 @@ __device__ void d_ir_detect(const uint8_t *code, int L, int16_t *S, uint8_t *mas
     while (nrep < IR_MAXREP) {
         for (int i = lane; i < L; i += 64) { S[i * L + i] = 0; cm[i] = (uint8_t)(code[i] | (mask[i] ? 8 : 0)); }
         __syncthreads();
-        const int cA = cm[iA], cB = iB < L ? cm[iB] : 12;
-        const int wantA = cA < 4 ? 3 - cA : 16;   // the code that pairs with row A's base (none for N)
-        int cjA = cm[iA + 1], cjB = iB + 1 < L ? cm[iB + 1] : 12;
+        const int cA = cm[iA], cB = cm[iB];
+        const int wantA = cA < 4 ? 3 - cA : 16, wantB = cB < 4 ? 3 - cB : 16;   // the code that pairs with the row's base (none for N)
+        int cjA = cm[iA + 1], cjB = cm[iB + 1];
         unsigned pA = 0, pB = 0;               // S(i, i+d-1) | S(i, i+d-2) << 16
-        int bestvA = 0, bestdA = 0;            // row A: highest score and the first diagonal that reached it (= smallest j)
-        unsigned bestkey = 0;   // row B: score << 16 | (255 - j) << 8 | i : highest score, then smallest j, then largest i
+        int bestvA = 0, bestdA = 0, bestvB = 0, bestdB = 0;   // per row: highest score and the first diagonal that reached it (= smallest j)
         const int nB = L - 64;  // row B has cells only on diagonals d < L - 64
         int16_t *sA = S + iA * L + iA;         // S(iA, iA + d) = sA[d]
+        int16_t *sB = S + iB * L + iB;         // rows beyond the matrix write behind it: S has IR_S entries
         for (int d = 1; d < L; d++) {
             unsigned nA = (unsigned)__builtin_amdgcn_update_dpp(0, (int)pA, 0x130 /* wave_shl:1: lane i <- lane i+1 */, 0xF, 0xF, false);
             const unsigned fromB = (unsigned)__builtin_amdgcn_readfirstlane((int)pB);
@@ -108,28 +109,22 @@ __device__ void d_ir_detect(const uint8_t *code, int L, int16_t *S, uint8_t *mas
             if (vA > bestvA) { bestvA = vA; bestdA = d; }
             pA = (pA << 16) | (unsigned)vA;
             cjA = ncjA;
-            if (d < nB) {   // wave-uniform
+            if (d < nB) {   // wave-uniform: rows 64.. have cells only on the first L - 64 diagonals; same branch-free step
                 const unsigned nBv = (unsigned)__builtin_amdgcn_update_dpp(0, (int)pB, 0x130, 0xF, 0xF, false);
-                const int ncjB = iB + d + 1 < L ? cm[iB + d + 1] : 12;
-                int vB = 0;
-                const int jB = iB + d;
-                if (jB < L) {
-                    if (!((cB | cjB) & 8)) {
-                        const int mb = (cB < 4 && cjB < 4 && cB + cjB == 3) ? MATCH : MISMATCH;
-                        vB = (d >= 2 ? (int)(nBv >> 16) : 0) + mb;
-                        const int upb = (int)(nBv & 0xFFFF) - GAP, leftb = (int)(pB & 0xFFFF) - GAP;
-                        if (upb > vB) vB = upb;
-                        if (leftb > vB) vB = leftb;
-                        if (vB < 0) vB = 0;
-                    }
-                    S[iB * L + jB] = (int16_t)vB;
-                    const unsigned key = ((unsigned)vB << 16) | ((unsigned)(255 - jB) << 8) | (unsigned)iB;
-                    if (vB > 0 && key > bestkey) bestkey = key;
-                }
+                const int ncjB = cm[iB + d + 1];
+                const int mb = cjB == wantB ? MATCH : MISMATCH;
+                int vB = (int)(nBv >> 16) + mb;
+                const int upb = (int)(nBv & 0xFFFF) - GAP, leftb = (int)(pB & 0xFFFF) - GAP;
+                vB = max(max(vB, upb), max(leftb, 0));
+                if ((cB | cjB) & 8) vB = 0;
+                sB[d] = (int16_t)vB;
+                if (vB > bestvB) { bestvB = vB; bestdB = d; }
                 pB = (pB << 16) | (unsigned)vB;
                 cjB = ncjB;
             }
         }
+        unsigned bestkey = 0;   // score << 16 | (255 - j) << 8 | i : highest score, then smallest j, then largest i
+        if (bestvB > 0) bestkey = ((unsigned)bestvB << 16) | ((unsigned)(255 - (iB + bestdB)) << 8) | (unsigned)iB;
         if (bestvA > 0) {
             const unsigned keyA = ((unsigned)bestvA << 16) | ((unsigned)(255 - (iA + bestdA)) << 8) | (unsigned)iA;
             if (keyA > bestkey) bestkey = keyA;
@@ -180,7 +175,7 @@ __device__ void d_ir_detect(const uint8_t *code, int L, int16_t *S, uint8_t *mas
 
 // generic entry: sequences given explicitly (mfk_ir_detect)
 __global__ __launch_bounds__(64) void k_ir_seqs(const char *seqs, const int64_t *off, uint32_t n, int32_t *out) {
-    __shared__ int16_t S[IR_MAXLEN * IR_MAXLEN];
+    __shared__ int16_t S[IR_S];
     __shared__ uint8_t code[IR_MAXLEN + 4], mask[IR_MAXLEN + 4 + IR_CM];   // mask | cm (d_ir_detect)
     __shared__ int32_t rep[4 * IR_MAXREP + 8];
     uint32_t k = blockIdx.x;
@@ -203,7 +198,7 @@ __device__ __forceinline__ uint64_t d_assign_key(const FlankDev &F, uint32_t a, 
 
 // also writes the candidate's sort key for assign_pairs (stable order by IR_length desc, diffcount asc, difflength asc)
 __global__ __launch_bounds__(64) void k_inverted_repeat(FlankDev F, const uint32_t *c5, const uint32_t *c3, uint32_t n, int32_t *out, uint64_t *keys, uint32_t *vals) {
-    __shared__ int16_t S[IR_MAXLEN * IR_MAXLEN];
+    __shared__ int16_t S[IR_S];
     __shared__ uint8_t code[IR_MAXLEN + 4], mask[IR_MAXLEN + 4 + IR_CM];   // mask | cm (d_ir_detect)
     __shared__ int32_t rep[4 * IR_MAXREP + 8];
     uint32_t k = blockIdx.x;
