@@ -33,7 +33,8 @@ mfk_ctx *mfk_create(int device_id) {
     if (hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&ctx->ev_join3, hipEventDisableTiming) != hipSuccess) { delete ctx; return nullptr; }
+        hipEventCreateWithFlags(&ctx->ev_join3, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_fork3, hipEventDisableTiming) != hipSuccess) { delete ctx; return nullptr; }
     return ctx;
 }
 
@@ -54,6 +55,7 @@ void mfk_destroy(mfk_ctx *ctx) {
     (void)hipEventDestroy(ctx->ev_fork);
     (void)hipEventDestroy(ctx->ev_join);
     (void)hipEventDestroy(ctx->ev_join3);
+    (void)hipEventDestroy(ctx->ev_fork3);
     (void)hipStreamDestroy(ctx->stream3);
     (void)hipStreamDestroy(ctx->stream2);
     (void)hipStreamDestroy(ctx->stream);

@@ -1183,17 +1183,23 @@ int run_consensus(mfk_ctx *ctx, const DevReads &R, const DevParams &P, Consensus
     // chain (A)
     PROF_LAUNCH(k_leaf_first, dim3(g_leaf1), dim3(64), 0, st, W, J, lcpm);
     KCHK();
+    // the DFS ranks need only what k_leaf_first wrote (LCP rows, trie nodes), not the node sums: third stream
+    hipStream_t sc = ctx->stream3;
+    HIPCHK(hipEventRecord(ctx->ev_fork3, st));
+    HIPCHK(hipStreamWaitEvent(sc, ctx->ev_fork3, 0));
+    if (hm.max_R <= 256) { PROF_LAUNCH(k_leaf_rank_wave, dim3(g_leaf4), dim3(256), 0, sc, W, J, (const uint16_t *)lcpm); }
+    else { PROF_LAUNCH(k_leaf_rank, dim3(g_leaf4), dim3(256), 0, sc, W, J, (const uint16_t *)lcpm); }
+    KCHK();
+    HIPCHK(hipEventRecord(ctx->ev_join3, sc));
     const uint32_t max_len = hm.max_len ? hm.max_len : 1;
     {
         const size_t ns_lds = (size_t)max_len * NS_SLOTS * 16;   // <= 64 KB with MAX_WORD_LEN 512
         PROF_LAUNCH(k_node_sums, dim3(nblocks(Wn, NS_WORDS)), dim3(1024), ns_lds, st, W, J, max_len);
         KCHK();
     }
-    if (hm.max_R <= 256) { PROF_LAUNCH(k_leaf_rank_wave, dim3(g_leaf4), dim3(256), 0, st, W, J, (const uint16_t *)lcpm); }
-    else { PROF_LAUNCH(k_leaf_rank, dim3(g_leaf4), dim3(256), 0, st, W, J, (const uint16_t *)lcpm); }
-    KCHK();
     HIPCHK(hipEventRecord(ctx->ev_join, sb));
     HIPCHK(hipStreamWaitEvent(st, ctx->ev_join, 0));
+    HIPCHK(hipStreamWaitEvent(st, ctx->ev_join3, 0));
     size_t lds = (size_t)max_len * 16 * 8;
     if (lds > 64 * 1024) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_cluster_vote), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     io.cons_stride = (max_len + 7) & ~7u;

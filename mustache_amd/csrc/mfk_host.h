@@ -20,7 +20,7 @@ struct mfk_ctx {
     hipStream_t stream2;            // side stream for kernel chains that do not depend on each other (consensus stage)
     hipEvent_t ev0, ev1;
     hipStream_t stream3;            // second side stream (pairflanks: spanning reads next to the direct repeats)
-    hipEvent_t ev_fork, ev_join, ev_join3;
+    hipEvent_t ev_fork, ev_join, ev_join3, ev_fork3;
     double last_ms;
     std::vector<Chunk> chunks;      // device arena
     void *pinned; size_t pinned_cap;
