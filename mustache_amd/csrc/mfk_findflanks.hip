@@ -224,13 +224,22 @@ __global__ __launch_bounds__(256) void k_clip_events_bkt(DevReads R, DevParams P
 }
 
 // one workgroup per bucket: output offset = sum of the counts before it, bitonic sort in LDS, coalesced write
-#define BSORT_THREADS 1024
-__global__ __launch_bounds__(BSORT_THREADS) void k_bucket_sort(const uint64_t *bkt, const uint32_t *bkt_count, uint32_t B, uint64_t *out) {
+// Deep buckets (a 1000x site puts a few thousand keys into one) take several times as long as the others and set the
+// kernel's duration when they are dispatched late: the host, which has read the counts anyway, lists the first
+// DEEP_MAX of them (ascending) and the first workgroups of the grid take those; the workgroup that owns a listed bucket
+// by position leaves it alone.
+#define DEEP_MIN 512u
+#define DEEP_MAX 60
+struct DeepBuckets { uint16_t n, last; uint16_t id[DEEP_MAX]; };
+#define BSORT_THREADS 512
+__global__ __launch_bounds__(BSORT_THREADS) void k_bucket_sort(const uint64_t *bkt, const uint32_t *bkt_count, uint32_t B, uint64_t *out, DeepBuckets D) {
     __shared__ uint64_t keys[BKT_CAP];
     __shared__ uint32_t red[BSORT_THREADS / 64];
-    const uint32_t b = blockIdx.x;
+    const bool listed = blockIdx.x < D.n;
+    const uint32_t b = listed ? D.id[blockIdx.x] : blockIdx.x - D.n;
     const uint32_t n = bkt_count[b];
     if (n == 0 || n > BKT_CAP) return;   // block-uniform (an overflow never gets here: the host checks the counts first)
+    if (!listed && D.n && n > DEEP_MIN && b <= D.last) return;   // taken by one of the first workgroups
     uint32_t part = 0;
     for (uint32_t j = threadIdx.x; j < b; j += BSORT_THREADS) part += bkt_count[j];
     for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
@@ -686,7 +695,8 @@ extern "C" int mfk_findflanks(mfk_ctx *ctx, const mfk_reads *reads, const mfk_pa
         PROF_LAUNCH(k_scan_clips, dim3(nblk), dim3(SCAN_THREADS), 0, st, R, list, ev_count + SEG_PAD, (uint32_t)seg_cap);
         KCHK();
         if (bucketed) {
-            PROF_LAUNCH(k_clip_events_bkt, dim3(32, LIST_SEGS), dim3(256), 0, st, R, P, (const uint64_t *)list, (const uint32_t *)(ev_count + SEG_PAD), (uint32_t)seg_cap, bkt, bkt_count, B);
+            static const unsigned ceb_x = getenv("MFK_CEB_X") ? (unsigned)atoi(getenv("MFK_CEB_X")) : 32u;
+            PROF_LAUNCH(k_clip_events_bkt, dim3(ceb_x, LIST_SEGS), dim3(256), 0, st, R, P, (const uint64_t *)list, (const uint32_t *)(ev_count + SEG_PAD), (uint32_t)seg_cap, bkt, bkt_count, B);
         } else {
             PROF_LAUNCH(k_clip_events, dim3(8, LIST_SEGS), dim3(256), 0, st, R, P, (const uint64_t *)list, (const uint32_t *)(ev_count + SEG_PAD), (uint32_t)seg_cap, ev, ev_count, (uint32_t)cap64);
         }
@@ -719,7 +729,9 @@ extern "C" int mfk_findflanks(mfk_ctx *ctx, const mfk_reads *reads, const mfk_pa
         ev_sorted = aalloc<uint64_t>(ctx, E);
         if (!ev_sorted) return 1;
         if (bucketed) {
-            PROF_LAUNCH(k_bucket_sort, dim3(B), dim3(BSORT_THREADS), 0, st, (const uint64_t *)bkt, (const uint32_t *)bkt_count, B, ev_sorted);
+            DeepBuckets D; D.n = 0; D.last = 0;
+            for (uint32_t b = 0; b < B && D.n < DEEP_MAX; b++) if (h_bkt[b] > DEEP_MIN) { D.id[D.n++] = (uint16_t)b; D.last = (uint16_t)b; }
+            PROF_LAUNCH(k_bucket_sort, dim3(B + D.n), dim3(BSORT_THREADS), 0, st, (const uint64_t *)bkt, (const uint32_t *)bkt_count, B, ev_sorted, D);
             KCHK();
         } else if (int rc = dev_sort_keys64(ctx, ev, ev_sorted, E, 0, 64)) return rc;
         ev_info = aalloc<uint8_t>(ctx, E);
