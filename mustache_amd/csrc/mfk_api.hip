@@ -5,6 +5,7 @@
 
 extern "C" {
 
+#define SCAN_CHAIN_TILES 256   // k_scan_chain: at most this many 8192-element tiles (2 M elements), rocPRIM beyond
 mfk_ctx *mfk_create(int device_id) {
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device_id < 0 || device_id >= ndev) return nullptr;
@@ -18,6 +19,7 @@ mfk_ctx *mfk_create(int device_id) {
     ctx->hdr_dev = nullptr; ctx->hdr_cap = 0;
     ctx->gather_flag = nullptr; ctx->gather_flag_dev = nullptr;
     ctx->gather_seq = 0;
+    ctx->scan_state = nullptr; ctx->scan_epoch = 0;
     ctx->err[0] = 0;
     ctx->prof_on = false;
     ctx->prof_skip = false;
@@ -25,6 +27,7 @@ mfk_ctx *mfk_create(int device_id) {
     memset(ctx->stats, 0, sizeof ctx->stats);
     memset(ctx->pstats, 0, sizeof ctx->pstats);
     if (hipMalloc((void **)&ctx->gather_count, 256) != hipSuccess || hipMemset(ctx->gather_count, 0, 256) != hipSuccess) { delete ctx; return nullptr; }
+    if (hipMalloc((void **)&ctx->scan_state, SCAN_CHAIN_TILES * 8) != hipSuccess || hipMemset(ctx->scan_state, 0, SCAN_CHAIN_TILES * 8) != hipSuccess) { delete ctx; return nullptr; }
     if (hipHostMalloc((void **)&ctx->gather_flag, 256, hipHostMallocMapped) != hipSuccess || hipHostGetDevicePointer((void **)&ctx->gather_flag_dev, ctx->gather_flag, 0) != hipSuccess) { delete ctx; return nullptr; }
     ctx->gather_flag[0] = 0;
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return nullptr; }
@@ -48,6 +51,7 @@ void mfk_destroy(mfk_ctx *ctx) {
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     if (ctx->gather_count) (void)hipFree(ctx->gather_count);
     if (ctx->hdr_dev) (void)hipFree(ctx->hdr_dev);
+    if (ctx->scan_state) (void)hipFree(ctx->scan_state);
     if (ctx->gather_flag) (void)hipHostFree(ctx->gather_flag);
     for (auto e : ctx->prof_events) (void)hipEventDestroy(e);
     (void)hipEventDestroy(ctx->ev0);
@@ -453,6 +457,64 @@ __global__ __launch_bounds__(1024) void k_scan_small(const uint32_t *in, TOut *o
     (void)carry_s;
 }
 
+// SCAN_SMALL < n <= SCAN_CHAIN_TILES tiles: one launch, one 8192-element tile per workgroup.  A workgroup publishes its
+// tile's sum (epoch << 48 | sum, one 64-bit store) as soon as it has it, then its first wave reads the entries of all
+// tiles before it, 64 at a time, waiting for those not yet tagged with this call's epoch.  A workgroup only waits for
+// lower-numbered ones, which are dispatched before it.  The epoch changes with every call, so the state array is never
+// cleared (the host clears it when the 16-bit epoch wraps).  Sums stay below 2^48 (inputs are 32-bit, n <= 2^21).
+template <typename TOut>
+__global__ __launch_bounds__(1024) void k_scan_chain(const uint32_t *in, TOut *out, uint32_t n, unsigned long long *state, uint32_t epoch) {
+    __shared__ unsigned long long wsum[16];
+    __shared__ unsigned long long s_prefix;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t tile = blockIdx.x;
+    const uint32_t i0 = tile * (1024 * SCAN_ITEMS) + threadIdx.x * SCAN_ITEMS;
+    uint32_t v[SCAN_ITEMS];
+    if (i0 + SCAN_ITEMS <= n && ((uintptr_t)in & 15) == 0) {
+        const uint4 a = *reinterpret_cast<const uint4 *>(in + i0), b = *reinterpret_cast<const uint4 *>(in + i0 + 4);
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+    } else {
+#pragma unroll
+        for (int k = 0; k < SCAN_ITEMS; k++) v[k] = i0 + k < n ? in[i0 + k] : 0u;
+    }
+    unsigned long long tsum = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; k++) tsum += v[k];
+    unsigned long long inc = tsum;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { unsigned long long t = __shfl_up(inc, d, 64); if (lane >= d) inc += t; }
+    if (lane == 63) wsum[wave] = inc;
+    __syncthreads();
+    unsigned long long wbase = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < 16; w++) { unsigned long long s = wsum[w]; if (w < wave) wbase += s; tot += s; }
+    if (wave == 0) {
+        if (lane == 0) __hip_atomic_store(&state[tile], ((unsigned long long)epoch << 48) | tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned long long acc = 0;
+        for (uint32_t p0 = 0; p0 < tile; p0 += 64) {
+            const uint32_t p = p0 + lane;
+            if (p < tile) {
+                unsigned long long e;
+                uint32_t spins = 0;
+                do {
+                    e = __hip_atomic_load(&state[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                } while ((uint32_t)(e >> 48) != epoch && ++spins < (1u << 24));
+                if ((uint32_t)(e >> 48) != epoch) __builtin_trap();   // a predecessor never ran: fail loudly, never hang
+                acc += e & 0xFFFFFFFFFFFFull;
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+        if (lane == 0) s_prefix = acc;
+    }
+    __syncthreads();
+    const unsigned long long before = s_prefix;
+    unsigned long long run = before + wbase + inc - tsum;
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; k++) { if (i0 + k < n) out[i0 + k] = (TOut)run; run += v[k]; }
+    if (tile == gridDim.x - 1 && threadIdx.x == 0) out[n] = (TOut)(before + tot);
+}
+
 template <typename TOut>
 struct PaddedIn {
     const uint32_t *in; size_t n;
@@ -465,6 +527,19 @@ static int dev_excl_scan(mfk_ctx *ctx, const uint32_t *in, TOut *out, size_t n) 
     if (n <= SCAN_SMALL) {
         prof_begin(ctx, "k_scan_small");
         hipLaunchKernelGGL(k_scan_small<TOut>, dim3(1), dim3(1024), 0, ctx->stream, in, out, (uint32_t)n);
+        prof_end(ctx);
+        KCHK();
+        return 0;
+    }
+    static const bool no_chain = getenv("MFK_NO_SCAN_CHAIN") && atoi(getenv("MFK_NO_SCAN_CHAIN"));
+    if (n <= (size_t)SCAN_CHAIN_TILES * 1024 * SCAN_ITEMS && !no_chain) {
+        if (++ctx->scan_epoch >= 0xFFFFu) {   // the tag wraps: entries of 65534 calls ago must not pass for this call's
+            HIPCHK(hipMemsetAsync(ctx->scan_state, 0, SCAN_CHAIN_TILES * 8, ctx->stream));
+            ctx->scan_epoch = 1;
+        }
+        const unsigned tiles = (unsigned)((n + 1024 * SCAN_ITEMS - 1) / (1024 * SCAN_ITEMS));
+        prof_begin(ctx, "k_scan_chain");
+        hipLaunchKernelGGL(k_scan_chain<TOut>, dim3(tiles), dim3(1024), 0, ctx->stream, in, out, (uint32_t)n, ctx->scan_state, ctx->scan_epoch);
         prof_end(ctx);
         KCHK();
         return 0;

@@ -21,6 +21,7 @@ struct mfk_ctx {
     hipEvent_t ev0, ev1;
     hipStream_t stream3;            // second side stream (pairflanks: spanning reads next to the direct repeats)
     hipEvent_t ev_fork, ev_join, ev_join3, ev_fork3;
+    unsigned long long *scan_state; uint32_t scan_epoch;   // tile aggregates of k_scan_chain, tagged with the call's epoch (never cleared between calls)
     double last_ms;
     std::vector<Chunk> chunks;      // device arena
     void *pinned; size_t pinned_cap;
