@@ -20,6 +20,7 @@ mfk_ctx *mfk_create(int device_id) {
     ctx->gather_flag = nullptr; ctx->gather_flag_dev = nullptr;
     ctx->gather_seq = 0;
     ctx->scan_state = nullptr; ctx->scan_epoch = 0;
+    ctx->fill_stream = nullptr;
     ctx->err[0] = 0;
     ctx->prof_on = false;
     ctx->prof_skip = false;
@@ -37,7 +38,8 @@ mfk_ctx *mfk_create(int device_id) {
         hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_join3, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&ctx->ev_fork3, hipEventDisableTiming) != hipSuccess) { delete ctx; return nullptr; }
+        hipEventCreateWithFlags(&ctx->ev_fork3, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_fill, hipEventDisableTiming) != hipSuccess) { delete ctx; return nullptr; }
     return ctx;
 }
 
@@ -60,6 +62,7 @@ void mfk_destroy(mfk_ctx *ctx) {
     (void)hipEventDestroy(ctx->ev_join);
     (void)hipEventDestroy(ctx->ev_join3);
     (void)hipEventDestroy(ctx->ev_fork3);
+    (void)hipEventDestroy(ctx->ev_fill);
     (void)hipStreamDestroy(ctx->stream3);
     (void)hipStreamDestroy(ctx->stream2);
     (void)hipStreamDestroy(ctx->stream);
@@ -288,7 +291,7 @@ static int fill_launch(mfk_ctx *ctx, char *p, size_t zero_bytes, size_t one_byte
     if (!n_total) return 0;
     size_t blocks = (n_total + 255) / 256;
     if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(k_fill2, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, (uint4 *)p, n_zero, n_total);
+    hipLaunchKernelGGL(k_fill2, dim3((unsigned)blocks), dim3(256), 0, ctx->fill_stream ? ctx->fill_stream : ctx->stream, (uint4 *)p, n_zero, n_total);
     KCHK();
     return 0;
 }
@@ -300,7 +303,7 @@ int FillGroup::commit() {
     for (auto &r : reqs) *r.out = p + r.off;
     if (value == 0) return fill_launch(ctx, p, total, 0);
     if (value == 0xFF) return fill_launch(ctx, p, 0, total);
-    HIPCHK(hipMemsetAsync(p, value, total, ctx->stream));
+    HIPCHK(hipMemsetAsync(p, value, total, ctx->fill_stream ? ctx->fill_stream : ctx->stream));
     return 0;
 }
 

@@ -1133,7 +1133,12 @@ int run_consensus(mfk_ctx *ctx, const DevReads &R, const DevParams &P, Consensus
     {
         FillGroup z(ctx, 0);
         z.want(&J.adj, (size_t)adj_total); z.want(&W.agg_qc, (size_t)total_chars + 8); z.want(&W.agg_e, (size_t)total_chars + 8);
-        if (z.commit()) return 1;
+        // first touched by k_leaf_compact and later: the fill runs on the third stream next to the three kernels before it
+        ctx->fill_stream = ctx->stream3;
+        const int fill_rc = z.commit();
+        ctx->fill_stream = nullptr;
+        if (fill_rc) return 1;
+        HIPCHK(hipEventRecord(ctx->ev_fill, ctx->stream3));
     }
     W.ch = aalloc<uint8_t>(ctx, (size_t)total_chars + 64); W.q = aalloc<uint8_t>(ctx, (size_t)total_chars + 64);
     if (total_chars >= 0xFFFFFFF0ull) { snprintf(ctx->err, sizeof ctx->err, "more than 2^32 clipped bases at the surviving sites of one call"); return 1; }
@@ -1152,6 +1157,7 @@ int run_consensus(mfk_ctx *ctx, const DevReads &R, const DevParams &P, Consensus
     if (n_chunks > 16) n_chunks = 16;
     const uint64_t my_items = (uint64_t)J.n * N_PIVOTS * n_chunks;
     if (J.n < (1u << 24)) { W.my_list = aalloc<uint32_t>(ctx, (size_t)my_items); if (!W.my_list) return 1; }   // else: k_leaf_myers enumerates the triples
+    HIPCHK(hipStreamWaitEvent(st, ctx->ev_fill, 0));
     PROF_LAUNCH(k_leaf_compact, dim3(J.n), dim3(256), 0, st, W, J, n_chunks);
     KCHK();
     uint16_t *lcpm = aalloc<uint16_t>(ctx, (size_t)adj_total * 32);

@@ -727,28 +727,35 @@ extern "C" int mfk_findflanks(mfk_ctx *ctx, const mfk_reads *reads, const mfk_pa
     uint32_t *ascan = nullptr; const uint32_t *n_sites_p = nullptr;
     if (E > 0) {
         ev_sorted = aalloc<uint64_t>(ctx, E);
-        if (!ev_sorted) return 1;
-        if (bucketed) {
-            DeepBuckets D; D.n = 0; D.last = 0;
-            for (uint32_t b = 0; b < B && D.n < DEEP_MAX; b++) if (h_bkt[b] > DEEP_MIN) { D.id[D.n++] = (uint16_t)b; D.last = (uint16_t)b; }
-            PROF_LAUNCH(k_bucket_sort, dim3(B + D.n), dim3(BSORT_THREADS), 0, st, (const uint64_t *)bkt, (const uint32_t *)bkt_count, B, ev_sorted, D);
-            KCHK();
-        } else if (int rc = dev_sort_keys64(ctx, ev, ev_sorted, E, 0, 64)) return rc;
         ev_info = aalloc<uint8_t>(ctx, E);
         uint32_t *head = aalloc<uint32_t>(ctx, E), *head_scan = aalloc<uint32_t>(ctx, (size_t)E + 1);
         T.gpos = aalloc<uint32_t>(ctx, E); T.contig = aalloc<int32_t>(ctx, E);
         T.ev_begin = aalloc<uint32_t>(ctx, E); T.ev_end = aalloc<uint32_t>(ctx, E); T.st = aalloc<uint32_t>(ctx, E);
         uint32_t *st2 = aalloc<uint32_t>(ctx, E), *alive = nullptr;
         ascan = aalloc<uint32_t>(ctx, (size_t)E + 1);
+        // the site arrays are first touched by k_site_accumulate: their fill runs on the third stream, next to the sort, the
+        // event pass and the scan
         FillGroup z(ctx, 0), f(ctx, 0xFF);
         z.want(&T.cnt2, 2 * (size_t)E); z.want(&T.sflags, E); z.want(&alive, E);
         f.want(&T.ev_mid, E);
-        if (!ev_info || !head || !head_scan || !T.gpos || !T.contig || !T.ev_begin || !T.ev_end || !T.st || !st2 || !ascan || fill_commit2(z, f)) return 1;
+        if (!ev_info || !head || !head_scan || !T.gpos || !T.contig || !T.ev_begin || !T.ev_end || !T.st || !st2 || !ascan || !ev_sorted) return 1;
+        ctx->fill_stream = ctx->stream3;
+        const int fill_rc = fill_commit2(z, f);
+        ctx->fill_stream = nullptr;
+        if (fill_rc) return 1;
+        HIPCHK(hipEventRecord(ctx->ev_fill, ctx->stream3));
+        if (bucketed) {
+            DeepBuckets D; D.n = 0; D.last = 0;
+            for (uint32_t b = 0; b < B && D.n < DEEP_MAX; b++) if (h_bkt[b] > DEEP_MIN) { D.id[D.n++] = (uint16_t)b; D.last = (uint16_t)b; }
+            PROF_LAUNCH(k_bucket_sort, dim3(B + D.n), dim3(BSORT_THREADS), 0, st, (const uint64_t *)bkt, (const uint32_t *)bkt_count, B, ev_sorted, D);
+            KCHK();
+        } else if (int rc = dev_sort_keys64(ctx, ev, ev_sorted, E, 0, 64)) return rc;
         const unsigned eb = nblocks(E, 256);
         PROF_LAUNCH(k_event_info, dim3(eb), dim3(256), 0, st, R, P, (const uint64_t *)ev_sorted, E, ev_info, head);
         KCHK();
         if (int rc = dev_excl_scan32(ctx, head, head_scan, E)) return rc;
         n_sites_p = head_scan + E;
+        HIPCHK(hipStreamWaitEvent(st, ctx->ev_fill, 0));
         PROF_LAUNCH(k_site_accumulate, dim3(eb), dim3(256), 0, st, R, (const uint64_t *)ev_sorted, (const uint8_t *)ev_info, (const uint32_t *)head_scan, E, T);
         KCHK();
         const int upto = stop_after >= MFK_STAGE_MINCOUNT ? 2 : (stop_after >= MFK_STAGE_MINLENGTH ? 1 : 0);

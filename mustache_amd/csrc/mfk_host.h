@@ -20,7 +20,8 @@ struct mfk_ctx {
     hipStream_t stream2;            // side stream for kernel chains that do not depend on each other (consensus stage)
     hipEvent_t ev0, ev1;
     hipStream_t stream3;            // second side stream (pairflanks: spanning reads next to the direct repeats)
-    hipEvent_t ev_fork, ev_join, ev_join3, ev_fork3;
+    hipEvent_t ev_fork, ev_join, ev_join3, ev_fork3, ev_fill;
+    hipStream_t fill_stream;   // while set, FillGroup launches go to this stream instead of `stream` (fills that overlap the kernels before their first consumer)
     unsigned long long *scan_state; uint32_t scan_epoch;   // tile aggregates of k_scan_chain, tagged with the call's epoch (never cleared between calls)
     double last_ms;
     std::vector<Chunk> chunks;      // device arena
