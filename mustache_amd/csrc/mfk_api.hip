@@ -19,7 +19,8 @@ mfk_ctx *mfk_create(int device_id) {
     ctx->hdr_dev = nullptr; ctx->hdr_cap = 0;
     ctx->gather_flag = nullptr; ctx->gather_flag_dev = nullptr;
     ctx->gather_seq = 0;
-    ctx->scan_state = nullptr; ctx->scan_epoch = 0;
+    ctx->scan_state = nullptr;
+    { const char *e0 = getenv("MFK_SCAN_EPOCH0"); ctx->scan_epoch = e0 ? (uint32_t)atoi(e0) & 0xFFFFu : 0u; }   // test hook: start near the wrap
     ctx->fill_stream = nullptr;
     ctx->err[0] = 0;
     ctx->prof_on = false;

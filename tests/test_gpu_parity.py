@@ -195,3 +195,32 @@ def test_pair_window_device_path(hip, name, monkeypatch):
     ff2, pf2 = hip.run_flankpairs(R, params, ranks, gd, goff)
     assert pf2["pairs"].tobytes() == pf["pairs"].tobytes() and pf2["strs"] == pf["strs"] and list(pf2["stats"]) == list(pf["stats"])
     assert len(pf["pairs"]) > 0
+
+
+@pytest.mark.gpu
+def test_chained_scan_epoch_wrap(hip, oracle, monkeypatch):
+    """More than 16 k events: the prefix sums go through k_scan_chain, whose tile entries are tagged with a 16-bit call
+    counter.  A ctx that starts just below the wrap (test hook MFK_SCAN_EPOCH0) crosses it within three calls; every call
+    must give the oracle's tables."""
+    import torch
+    from mustache_amd.synth import synth_packed
+    packed, genome, _ = synth_packed(contig_lens=(2_400_000,), coverage=150, n_insertions=6, seed=77)
+    params = lib.make_params()
+    g, goff = pfh.genome_arrays(genome, packed.contig_names)
+    ranks = pfh.contig_ranks(packed.contig_names)
+    Ro = oracle.reads(packed)
+    want = oracle.run_findflanks(Ro, params)
+    wantp = oracle.run_pairflanks(Ro, params, want["flanks"], want["seqs"], ranks, g, goff)
+    monkeypatch.setenv("MFK_SCAN_EPOCH0", str(0xFFFF - 5))
+    own = lib.Binding(lib.LIB_PATH, "mfk_", 0)
+    try:
+        R = device_reads(own, packed, "cuda:0")
+        gd = torch.from_numpy(g).to("cuda:0")
+        for _ in range(4):
+            ff, pf = own.run_flankpairs(R, params, ranks, gd, goff)
+            assert int(ff["stats"][10]) > 16 * 1024          # events: beyond the one-workgroup scan
+            assert ff["flanks"].tobytes() == want["flanks"].tobytes() and ff["seqs"] == want["seqs"]
+            assert pf["pairs"].tobytes() == wantp["pairs"].tobytes() and pf["strs"] == wantp["strs"]
+        assert len(want["flanks"]) >= 10
+    finally:
+        own.close()
