@@ -695,8 +695,7 @@ extern "C" int mfk_findflanks(mfk_ctx *ctx, const mfk_reads *reads, const mfk_pa
         PROF_LAUNCH(k_scan_clips, dim3(nblk), dim3(SCAN_THREADS), 0, st, R, list, ev_count + SEG_PAD, (uint32_t)seg_cap);
         KCHK();
         if (bucketed) {
-            static const unsigned ceb_x = getenv("MFK_CEB_X") ? (unsigned)atoi(getenv("MFK_CEB_X")) : 32u;
-            PROF_LAUNCH(k_clip_events_bkt, dim3(ceb_x, LIST_SEGS), dim3(256), 0, st, R, P, (const uint64_t *)list, (const uint32_t *)(ev_count + SEG_PAD), (uint32_t)seg_cap, bkt, bkt_count, B);
+            PROF_LAUNCH(k_clip_events_bkt, dim3(32, LIST_SEGS), dim3(256), 0, st, R, P, (const uint64_t *)list, (const uint32_t *)(ev_count + SEG_PAD), (uint32_t)seg_cap, bkt, bkt_count, B);
         } else {
             PROF_LAUNCH(k_clip_events, dim3(8, LIST_SEGS), dim3(256), 0, st, R, P, (const uint64_t *)list, (const uint32_t *)(ev_count + SEG_PAD), (uint32_t)seg_cap, ev, ev_count, (uint32_t)cap64);
         }
