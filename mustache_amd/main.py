@@ -1,11 +1,12 @@
-"""Command line: ``mustache findflanks`` / ``mustache pairflanks`` / ``mustache recall`` with the reference's flags, short flags and defaults
-(reference mustache/main.py:66-117; the CLI defaults are authoritative, not the class defaults or the help texts).
+"""Command line with the reference's flags, short flags and defaults (reference mustache/main.py:66-117 for the two hot-path
+commands; the CLI defaults are authoritative, not the class defaults or the help texts).
 
     python -m mustache_amd.main findflanks BAM -o out.findflanks.tsv
     python -m mustache_amd.main pairflanks FLANKS BAM GENOME -o out.pairflanks.tsv
 
 The Snakemake workflow of the reference calls exactly these two commands (workflow/Snakefile:82-87, 105-109); every flag
-it passes is accepted here.  Only these two sub-commands exist: the rest of the toolbox is outside the hot path.
+it passes is accepted here.  Beside them the SURVEY.md section 8(f) "next" rows are registered: ``recall`` (main.py:272-284),
+``inferseq-overlap`` (167-182), ``inferseq-reference`` (143-164).  The rest of the toolbox is outside the hot path.
 """
 from __future__ import annotations
 
