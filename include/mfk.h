@@ -198,6 +198,16 @@ int mfk_ir_detect(mfk_ctx *ctx, const char *seqs, const int64_t *off, int64_t n,
 int mfk_recall(mfk_ctx *ctx, const mfk_reads *reads, const mfk_params *params, const int32_t *h_contig_id, const int32_t *h_pos,
                int64_t n_sites, int32_t *h_counts_out);
 
+/* mfk_recall for callers that cannot allocate: code under HIP graph capture, tight serving loops, harnesses that forbid
+ * hipMalloc.  NO COUNTERPART IN THE REFERENCE (which has no device memory to manage); same arguments, meaning and results
+ * as mfk_recall.  The call allocates nothing on the device or the host (no hipMalloc / hipFree / hipHostMalloc, no arena
+ * growth): the contig header, the staged site list and the device-side counts live in a fixed array in the library's
+ * code object (852,224 bytes per GPU, held until the process ends), the pinned staging block is allocated by mfk_create.
+ * Limits: n_sites <= 16384 and reads->n_contigs <= 4096 per call, otherwise return code 9 with a message.  All calls
+ * on one GPU share that array, whatever ctx they use: calls that overlap on one GPU race; serialise them. */
+int mfk_recall_noalloc(mfk_ctx *ctx, const mfk_reads *reads, const mfk_params *params, const int32_t *h_contig_id, const int32_t *h_pos,
+                       int64_t n_sites, int32_t *h_counts_out);
+
 /* inferseq-overlap: best ungapped sliding overlap of the end of the 5p flank with the start of the 3p flank (replaces
  * get_best_sliding_alignment, inferseqoverlap.py:94-164, called from find_overlap 73-91).  seqs5 / seqs3: HOST
  * concatenated sequences with n+1 offsets each (bytes are compared as they are).  out: n x 6 int32 = best_score,

@@ -22,6 +22,7 @@ mfk_ctx *mfk_create(int device_id) {
     ctx->scan_state = nullptr;
     { const char *e0 = getenv("MFK_SCAN_EPOCH0"); ctx->scan_epoch = e0 ? (uint32_t)atoi(e0) & 0xFFFFu : 0u; }   // test hook: start near the wrap
     ctx->fill_stream = nullptr;
+    ctx->na_pinned = nullptr;
     ctx->err[0] = 0;
     ctx->prof_on = false;
     ctx->prof_skip = false;
@@ -41,6 +42,7 @@ mfk_ctx *mfk_create(int device_id) {
         hipEventCreateWithFlags(&ctx->ev_join3, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_fork3, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_fill, hipEventDisableTiming) != hipSuccess) { delete ctx; return nullptr; }
+    if (noalloc_setup(ctx) != 0) { mfk_destroy(ctx); return nullptr; }
     return ctx;
 }
 
@@ -56,6 +58,7 @@ void mfk_destroy(mfk_ctx *ctx) {
     if (ctx->hdr_dev) (void)hipFree(ctx->hdr_dev);
     if (ctx->scan_state) (void)hipFree(ctx->scan_state);
     if (ctx->gather_flag) (void)hipHostFree(ctx->gather_flag);
+    noalloc_teardown(ctx);
     for (auto e : ctx->prof_events) (void)hipEventDestroy(e);
     (void)hipEventDestroy(ctx->ev0);
     (void)hipEventDestroy(ctx->ev1);
@@ -338,7 +341,9 @@ void *pinned_buf(mfk_ctx *ctx, size_t bytes) {
 // contigs and no neighbour search can cross a contig boundary.
 size_t upload_reads_pinned_bytes(int nc) { return (((size_t)(nc + 1) * 8 + (size_t)nc * 8) + 255) & ~(size_t)255; }
 
-int upload_reads(mfk_ctx *ctx, const mfk_reads *in, const mfk_params *pr, DevReads *R, DevParams *P) {
+// validation + everything of R / P that is not a device address of the header; the header bytes [read starts i64 x (nc+1) |
+// lengths i32 x nc | bases u32 x nc] go to `h` (upload_reads_pinned_bytes(nc) bytes); *used = bytes of it that carry data
+int prepare_reads(mfk_ctx *ctx, const mfk_reads *in, const mfk_params *pr, DevReads *R, DevParams *P, char *h, size_t *used) {
     if (in->n_reads < 0 || in->n_reads >= ((int64_t)1 << 31)) { snprintf(ctx->err, sizeof ctx->err, "n_reads %lld out of range (max 2^31-1 per call)", (long long)in->n_reads); return 1; }
     if (in->n_contigs <= 0 || in->n_contigs > 65535) { snprintf(ctx->err, sizeof ctx->err, "n_contigs %d out of range", in->n_contigs); return 1; }
     if (in->n_reads > 0 && (!in->ref_start || !in->ref_end || !in->link || !in->contig_id || !in->qlen || !in->first_op_len || !in->last_op_len || !in->mapq || !in->flags)) {
@@ -355,13 +360,9 @@ int upload_reads(mfk_ctx *ctx, const mfk_reads *in, const mfk_params *pr, DevRea
     R->blk_start = in->blk_start; R->blk_end = in->blk_end; R->blk_ins = in->blk_ins;
     R->n_pool = in->n_pool; R->pool_read = in->pool_read; R->pool_off = in->pool_off;
     R->pool_bases = in->pool_bases; R->pool_quals = in->pool_quals;
-    int nc = in->n_contigs;
+    const int nc = in->n_contigs;
     int64_t pad = (int64_t)pr->min_distance_to_mate + pr->max_direct_repeat_length + 64;
     if (pad < 64) pad = 64;
-    // header arrays: [read starts i64 x (nc+1) | lengths i32 x nc | bases u32 x nc] staged in pinned memory, one copy
-    const size_t bytes = upload_reads_pinned_bytes(nc);
-    char *h = (char *)pinned_buf(ctx, bytes);
-    if (!h) { snprintf(ctx->err, sizeof ctx->err, "pinned allocation failed"); return 1; }
     int64_t *h_rs = (int64_t *)h; int32_t *h_len = (int32_t *)(h_rs + nc + 1); uint32_t *h_base = (uint32_t *)(h_len + nc);
     int64_t base = 0;
     for (int c = 0; c < nc; c++) {
@@ -373,10 +374,32 @@ int upload_reads(mfk_ctx *ctx, const mfk_reads *in, const mfk_params *pr, DevRea
     if (base >= ((int64_t)1 << 32)) { snprintf(ctx->err, sizeof ctx->err, "total reference length %lld does not fit the 32-bit site axis", (long long)base); return 1; }
     for (int c = 0; c <= nc; c++) h_rs[c] = in->h_contig_read_start[c];
     R->gpos_span = (uint32_t)base;
+    *used = (size_t)((char *)(h_base + nc) - h);
+    P->minlen = pr->min_softclip_length; P->mincount = pr->min_softclip_count; P->minq = pr->min_alignment_quality;
+    P->minial = pr->min_alignment_inner_length; P->mindist = pr->min_distance_to_mate; P->lins = pr->large_insertion_cutoff;
+    P->mcc = pr->min_count_consensus; P->maxdr = pr->max_direct_repeat_length;
+    P->minratio = pr->min_softclip_ratio; P->maxir = pr->max_indel_ratio; P->maxjsp = pr->max_junction_spanning_prop;
+    return 0;
+}
+
+// the header arrays live at `d_hdr` on the device, laid out as prepare_reads wrote them
+void set_header_ptrs(DevReads *R, char *d_hdr) {
+    const int nc = R->n_contigs;
+    int64_t *d_rs = (int64_t *)d_hdr; int32_t *d_len = (int32_t *)(d_rs + nc + 1); uint32_t *d_base = (uint32_t *)(d_len + nc);
+    R->contig_len = d_len; R->contig_rs = d_rs; R->contig_base = d_base;
+}
+
+int upload_reads(mfk_ctx *ctx, const mfk_reads *in, const mfk_params *pr, DevReads *R, DevParams *P) {
+    if (in->n_contigs <= 0 || in->n_contigs > 65535) { snprintf(ctx->err, sizeof ctx->err, "n_contigs %d out of range", in->n_contigs); return 1; }
+    // header arrays staged in pinned memory, one copy
+    const size_t bytes = upload_reads_pinned_bytes(in->n_contigs);
+    char *h = (char *)pinned_buf(ctx, bytes);
+    if (!h) { snprintf(ctx->err, sizeof ctx->err, "pinned allocation failed"); return 1; }
+    size_t used = 0;
+    if (int rc = prepare_reads(ctx, in, pr, R, P, h, &used)) return rc;
     // The header lives in an allocation of its own and is uploaded only when its bytes change: findflanks, pairflanks
     // and recall on the same reads (and every step of a loop over resident reads) reuse it, which saves a copy and the
     // gap behind it at the head of every call.
-    const size_t used = (size_t)((char *)(h_base + nc) - h);
     if (bytes > ctx->hdr_cap) {
         HIPCHK(hipStreamSynchronize(ctx->stream));
         if (ctx->hdr_dev) (void)hipFree(ctx->hdr_dev);
@@ -391,12 +414,7 @@ int upload_reads(mfk_ctx *ctx, const mfk_reads *in, const mfk_params *pr, DevRea
         // no synchronisation: later read-backs into the same pinned bytes are ordered behind this copy on the stream
         ctx->hdr_last.assign(h, h + used);
     }
-    int64_t *d_rs = (int64_t *)d_hdr; int32_t *d_len = (int32_t *)(d_rs + nc + 1); uint32_t *d_base = (uint32_t *)(d_len + nc);
-    R->contig_len = d_len; R->contig_rs = d_rs; R->contig_base = d_base;
-    P->minlen = pr->min_softclip_length; P->mincount = pr->min_softclip_count; P->minq = pr->min_alignment_quality;
-    P->minial = pr->min_alignment_inner_length; P->mindist = pr->min_distance_to_mate; P->lins = pr->large_insertion_cutoff;
-    P->mcc = pr->min_count_consensus; P->maxdr = pr->max_direct_repeat_length;
-    P->minratio = pr->min_softclip_ratio; P->maxir = pr->max_indel_ratio; P->maxjsp = pr->max_junction_spanning_prop;
+    set_header_ptrs(R, d_hdr);
     return 0;
 }
 

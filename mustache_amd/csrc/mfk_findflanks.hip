@@ -942,3 +942,79 @@ extern "C" int mfk_recall(mfk_ctx *ctx, const mfk_reads *reads, const mfk_params
     if (hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1) == hipSuccess) ctx->last_ms = ms;
     return 0;
 }
+
+// ---- recall without any allocation ------------------------------------------------------------------------------------
+// mfk_recall_noalloc: mfk_recall for callers that cannot allocate (HIP graph capture around them, serving loops, harnesses
+// that forbid hipMalloc).  What mfk_recall takes from the arena and the growable pinned buffer -- the contig header, the
+// staged site list and the device-side counts -- lives in ONE file-scope device array of fixed size instead.  Every GPU
+// holds its own copy of that array at its own address: the address is looked up once per device (noalloc_setup, called by
+// mfk_create with the device current) and only that pointer is ever handed to kernels and copies.  The pinned staging
+// block on the host side is allocated by mfk_create as well.  All calls on one GPU share the array (and keep the last
+// call's bytes in it): calls that overlap on one GPU race, whatever ctx they use.  Nothing in it has to start at zero:
+// k_recall writes all ten counts of every site it is given and reads nothing it has not been sent in this call.
+#define NA_MAX_SITES 16384
+#define NA_MAX_CONTIGS 4096
+#define NA_HDR_BYTES ((((size_t)(NA_MAX_CONTIGS + 1) * 8 + (size_t)NA_MAX_CONTIGS * 8) + 255) & ~(size_t)255)   // = upload_reads_pinned_bytes(NA_MAX_CONTIGS)
+#define NA_SITES_BYTES ((size_t)NA_MAX_SITES * 8)
+#define NA_COUNTS_BYTES ((size_t)NA_MAX_SITES * 40)
+#define NA_BYTES (NA_HDR_BYTES + NA_SITES_BYTES + NA_COUNTS_BYTES)   // 852,224 bytes per GPU
+static __device__ __align__(256) unsigned char scratch[NA_BYTES];
+#define NA_MAX_DEVICES 64
+static unsigned char *g_na_ptr[NA_MAX_DEVICES];   // device address of `scratch` on each GPU (the array's name is no device address in host code)
+
+int noalloc_setup(mfk_ctx *ctx) {
+    if (ctx->device < 0 || ctx->device >= NA_MAX_DEVICES) return 0;   // such a device simply has no no-allocation entry point
+    HIPCHK(hipSetDevice(ctx->device));
+    if (!g_na_ptr[ctx->device]) {
+        unsigned char *p = nullptr;
+        HIPCHK(hipGetSymbolAddress((void **)&p, HIP_SYMBOL(scratch)));
+        if (!p || ((uintptr_t)p & 255) != 0) { snprintf(ctx->err, sizeof ctx->err, "no-allocation scratch array has no usable device address"); return 1; }
+        g_na_ptr[ctx->device] = p;
+    }
+    HIPCHK(hipHostMalloc((void **)&ctx->na_pinned, NA_BYTES, hipHostMallocDefault));
+    return 0;
+}
+
+void noalloc_teardown(mfk_ctx *ctx) {
+    if (ctx->na_pinned) (void)hipHostFree(ctx->na_pinned);
+    ctx->na_pinned = nullptr;
+}
+
+extern "C" int mfk_recall_noalloc(mfk_ctx *ctx, const mfk_reads *reads, const mfk_params *params, const int32_t *h_contig_id, const int32_t *h_pos,
+                                  int64_t n_sites, int32_t *h_counts) {
+    if (!ctx || !reads || !params || n_sites < 0 || (n_sites > 0 && (!h_contig_id || !h_pos || !h_counts))) return 1;
+    HIPCHK(hipSetDevice(ctx->device));
+    ctx->err[0] = 0;
+    if (n_sites == 0) return 0;
+    if (n_sites > NA_MAX_SITES) { snprintf(ctx->err, sizeof ctx->err, "mfk_recall_noalloc takes at most %d sites per call (got %lld): split the list or use mfk_recall", NA_MAX_SITES, (long long)n_sites); return 9; }
+    if (reads->n_contigs <= 0 || reads->n_contigs > NA_MAX_CONTIGS) { snprintf(ctx->err, sizeof ctx->err, "mfk_recall_noalloc takes at most %d contigs (got %d): use mfk_recall", NA_MAX_CONTIGS, reads->n_contigs); return 9; }
+    unsigned char *dev = (ctx->device >= 0 && ctx->device < NA_MAX_DEVICES) ? g_na_ptr[ctx->device] : nullptr;
+    if (!dev || !ctx->na_pinned) { snprintf(ctx->err, sizeof ctx->err, "the no-allocation scratch was not set up for device %d", ctx->device); return 1; }
+    for (int64_t i = 0; i < n_sites; i++) {
+        if (h_contig_id[i] < 0 || h_contig_id[i] >= reads->n_contigs) { snprintf(ctx->err, sizeof ctx->err, "site %lld: contig id %d out of range", (long long)i, h_contig_id[i]); return 1; }
+        if (h_pos[i] < -1 || h_pos[i] > reads->h_contig_len[h_contig_id[i]]) { snprintf(ctx->err, sizeof ctx->err, "site %lld: position %d outside contig", (long long)i, h_pos[i]); return 1; }
+    }
+    hipStream_t st = ctx->stream;
+    // the pinned block may still be the source / target of the previous call's copies only if that call failed half-way
+    HIPCHK(hipStreamSynchronize(st));
+    DevReads R; DevParams P;
+    char *h_hdr = ctx->na_pinned;
+    int32_t *h_sites = (int32_t *)(ctx->na_pinned + NA_HDR_BYTES), *h_cnt = (int32_t *)(ctx->na_pinned + NA_HDR_BYTES + NA_SITES_BYTES);
+    size_t used = 0;
+    if (int rc = prepare_reads(ctx, reads, params, &R, &P, h_hdr, &used)) return rc;
+    unsigned char *d_hdr = dev, *d_sites = dev + NA_HDR_BYTES, *d_cnt = dev + NA_HDR_BYTES + NA_SITES_BYTES;
+    set_header_ptrs(&R, (char *)d_hdr);
+    for (int64_t i = 0; i < n_sites; i++) { h_sites[2 * i] = h_contig_id[i]; h_sites[2 * i + 1] = h_pos[i]; }
+    HIPCHK(hipMemcpyAsync(d_hdr, h_hdr, (used + 15) & ~(size_t)15, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(d_sites, h_sites, (size_t)n_sites * 8, hipMemcpyHostToDevice, st));
+    HIPCHK(hipEventRecord(ctx->ev0, st));
+    hipLaunchKernelGGL(k_recall, dim3((unsigned)n_sites), dim3(n_sites >= 2048 ? 256 : 1024), 0, st, R, P, (const int32_t *)d_sites, (uint32_t)n_sites, (int32_t *)d_cnt);
+    KCHK();
+    HIPCHK(hipEventRecord(ctx->ev1, st));
+    HIPCHK(hipMemcpyAsync(h_cnt, d_cnt, (size_t)n_sites * 40, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    memcpy(h_counts, h_cnt, (size_t)n_sites * 40);
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1) == hipSuccess) ctx->last_ms = ms;
+    return 0;
+}

@@ -52,6 +52,7 @@ struct mfk_ctx {
     std::string strs;
     int64_t pstats[MFK_N_STATS];
     std::vector<int32_t> isq_f, isq_r;   // inferseq pairing result (mfk_inferseq_pairs)
+    char *na_pinned;                // pinned staging of mfk_recall_noalloc (header | sites | counts), allocated by mfk_create
     std::vector<int32_t> ir_ov;     // external inverted-repeat table for the next pairflanks call: rows i5 i3 has a1s a1e a2s a2e, sorted
 };
 
@@ -106,6 +107,10 @@ int fill_commit2(FillGroup &zeros, FillGroup &ones);   // both groups (values 0 
 
 size_t upload_reads_pinned_bytes(int n_contigs);
 int upload_reads(mfk_ctx *ctx, const mfk_reads *reads, const mfk_params *params, DevReads *R, DevParams *P);
+int prepare_reads(mfk_ctx *ctx, const mfk_reads *reads, const mfk_params *params, DevReads *R, DevParams *P, char *h, size_t *used);   // validation, R / P, header bytes into h
+void set_header_ptrs(DevReads *R, char *d_hdr);
+int noalloc_setup(mfk_ctx *ctx);     // mfk_findflanks.hip: device address of the no-allocation scratch array + pinned staging, once per ctx (mfk_create)
+void noalloc_teardown(mfk_ctx *ctx);
 
 static inline unsigned nblocks(int64_t n, int threads) { int64_t b = (n + threads - 1) / threads; return (unsigned)(b < 1 ? 1 : b); }
 

@@ -120,6 +120,8 @@ class Binding:
             f("flankpairs", C.c_int, [_p, C.POINTER(MfkReads), C.POINTER(MfkParams), _p, _p, _p] + [C.POINTER(C.c_int64)] * 5)
         f("ir_detect", C.c_int, [_p, _p, _p, C.c_int64, _p])
         f("recall", C.c_int, [_p, C.POINTER(MfkReads), C.POINTER(MfkParams), _p, _p, C.c_int64, _p])
+        if hasattr(self.so, prefix + "recall_noalloc"):
+            f("recall_noalloc", C.c_int, [_p, C.POINTER(MfkReads), C.POINTER(MfkParams), _p, _p, C.c_int64, _p])
         f("overlap", C.c_int, [_p, _p, _p, _p, _p, C.c_int64, _p])
         f("pairflanks_set_ir", C.c_int, [_p, C.c_int64, _p, _p, _p])
         f("inferseq_pairs", C.c_int, [_p, _p, C.c_int64, C.c_double, C.c_double, C.c_int64, C.c_int64, C.POINTER(C.c_int64)])
@@ -247,6 +249,15 @@ class Binding:
         out = np.zeros((cid.shape[0], 10), dtype=np.int32)
         self._check(self.recall(self.ctx, C.byref(reads), C.byref(params), cid.ctypes.data, pos.ctypes.data, cid.shape[0],
                                 out.ctypes.data))
+        return out
+
+    def run_recall_noalloc(self, reads, params, contig_ids, positions):
+        """``run_recall`` through the entry point that allocates nothing (mfk_recall_noalloc; <= 16384 sites per call)."""
+        cid = np.ascontiguousarray(contig_ids, dtype=np.int32)
+        pos = np.ascontiguousarray(positions, dtype=np.int32)
+        out = np.zeros((cid.shape[0], 10), dtype=np.int32)
+        self._check(self.recall_noalloc(self.ctx, C.byref(reads), C.byref(params), cid.ctypes.data, pos.ctypes.data, cid.shape[0],
+                                        out.ctypes.data))
         return out
 
     def run_overlap(self, seqs5, seqs3):
