@@ -18,6 +18,7 @@
 // All pairwise work (LCP, bit-parallel Myers edit distance) is spread over the whole GPU; words live in an 8-byte
 // aligned byte pool so LCPs are 64-bit XOR + count-trailing-zeros.
 #include "mfk_host.h"
+#include <stdlib.h>
 
 #define MAX_WORD_LEN 512
 #define ERR_READ_NUMBER 1u
@@ -25,7 +26,8 @@
 #define ERR_WORD_TOO_LONG 4u
 
 struct CMeta {          // small device struct the host reads back once
-    uint32_t err, max_len, max_R, pad;
+    uint32_t err, max_len, max_R, n_big;   // n_big: jobs k_job_small left to the device-wide kernels
+    uint32_t n_retry, pad[3];              // jobs that did not fit the first LDS budget of k_job_small
 };
 
 // per trie node: quality sum (low 40 bits) and #words through the node (high 24 bits) in ONE 64-bit word, so that a node
@@ -71,6 +73,7 @@ struct Words {
 struct Jobs {
     uint32_t n;                       // 2 * n_act slots
     uint32_t *w0, *R, *nl;            // word range, leaf count
+    uint32_t *Rbig;                   // k_job_small: 0 = job done there, R = left to the device-wide kernels, R | 2^31 = try again with more LDS
     uint32_t *adj_words;              // adjacency words of the job: R * ceil(R/32)
     uint64_t *adj_off;
     uint32_t *adj;
@@ -377,6 +380,7 @@ __global__ __launch_bounds__(256) void k_leaf_flags(Words W, Jobs J, int lf) {
         if (w >= W.n) break;
         if ((cov >> (i * N_LONGEST)) & ((1ull << N_LONGEST) - 1)) { if (lane == 0) W.is_leaf[w] = 0; continue; }
         const uint32_t w0 = __shfl(m_w0, i * N_LONGEST, 64), R = __shfl(m_R, i * N_LONGEST, 64);
+        if (R == 0) continue;   // word of a job that k_job_small has done
         const int la = __shfl(m_la, i * N_LONGEST, 64);
         if (la <= 0) { if (lane == 0) W.is_leaf[w] = R > 1 ? 0 : 1; continue; }   // an empty word is a prefix of everything (cannot happen: clips have >= 1 base)
         const uint8_t *a = W.ch + __shfl(m_off, i * N_LONGEST, 64);
@@ -1029,6 +1033,7 @@ __global__ __launch_bounds__(256) void k_job_best(DevParams P, Words W, Jobs J, 
     __shared__ uint32_t s_key, s_slot;
     const uint32_t job = blockIdx.x;
     if (job >= J.n) return;
+    if (J.R[job] == 0) return;   // inactive, or done by k_job_small: its outputs stand
     const uint32_t w0 = J.w0[job], nl = J.nl[job];
     if (threadIdx.x == 0) { s_npl = 0; s_npb = 0; s_hi = 0; s_key = 0; s_slot = 0xFFFFFFFFu; }
     __syncthreads();
@@ -1079,6 +1084,369 @@ __global__ __launch_bounds__(256) void k_job_best(DevParams P, Words W, Jobs J, 
     for (int d = threadIdx.x; d < len; d += blockDim.x) dst[d] = src[d];
 }
 
+// ---- small jobs: the whole consensus of one site-side in ONE workgroup, state in LDS -------------------------------------
+// A 100-200x site-side has ~50-200 words and a few dozen leaves: ~10 KB of characters.  The device-wide kernels above pay,
+// per job and per kernel, a chain of dependent global loads (job -> word range -> offsets -> characters); with 20 000 such
+// jobs (50 Mb at 200x) that chain IS the run time, and with 40 jobs (an isolate) the dozen launches are.  Here one
+// workgroup copies the job's characters into LDS once and runs every step on them:
+//   leaves            word v is no leaf iff another word extends it (or equals it and comes first): the job's longest
+//                     word settles the error-free words, the rest scan the job
+//   M[a][v]           longest common prefix of leaf a and word v (one byte each: words here are <= 255 characters)
+//   DFS order         T[a][b] = first word that shares more than LCP(a, b) characters with a; b is visited before a iff
+//                     T[b][a] < T[a][b] (children in insertion order, flanktrie.py:157-170)
+//   clusters          Myers bit-vector distances in rounds of 4 pattern leaves (match vectors in LDS): the first 4 leaves
+//                     against all later ones, then every leaf outside the largest component against the leaves of other
+//                     components (every cross-component pair is tested, so the components are those of the full graph);
+//                     label propagation on the adjacency bits
+//   vote              per cluster: leaf a contributes the nodes of its path below share(a) = deepest node it has in common
+//                     with an earlier member.  The node of a at depth d sums the words v with M[a][v] > d, so every such
+//                     (a, v) adds q_v[d] and a count at (d, character) for d in [share(a), M[a][v]): a job's characters
+//                     are each added once for the trunk and a few more times for the branches.  Sum of qualities (<= 256 x
+//                     255) and number of words (<= 256) of a (depth, character) share one 32-bit LDS word.
+//   count             words v with M[a][v] == len(v) for some member a (make_subtrie, flanktrie.py:89-118)
+// and writes the job's result exactly as k_job_best does.  A job that does not fit (more than SJ_MAX_R words, a word longer
+// than SJ_MAX_LEN, tables beyond the LDS budget of the launch) is left to a second launch with a larger budget or to the
+// device-wide kernels: J.Rbig says which.
+#define SJ_THREADS 256
+#define SJ_MAX_R 256
+#define SJ_MAX_LEN 255
+
+__device__ __forceinline__ int d_lcp16(const uint8_t *a, int la, const uint8_t *b, int lb) {
+    const int m = la < lb ? la : lb;
+    for (int o = 0; o < m; o += 16) {
+        const uint4 x = *reinterpret_cast<const uint4 *>(a + o), y = *reinterpret_cast<const uint4 *>(b + o);
+        const uint32_t d[4] = {x.x ^ y.x, x.y ^ y.y, x.z ^ y.z, x.w ^ y.w};
+        if (d[0] | d[1] | d[2] | d[3]) {
+            int k = m;
+#pragma unroll
+            for (int i = 3; i >= 0; i--) if (d[i]) k = o + 4 * i + (__builtin_ctz(d[i]) >> 3);
+            return k < m ? k : m;
+        }
+    }
+    return m;
+}
+
+// block-wide maximum / sum over SJ_THREADS threads (4 waves); sh = 4 words of LDS
+__device__ __forceinline__ uint32_t sj_block_max(uint32_t v, uint32_t *sh) {
+    for (int o = 32; o > 0; o >>= 1) { const uint32_t t = __shfl_xor(v, o, 64); if (t > v) v = t; }
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    uint32_t r = sh[0];
+    for (int w = 1; w < SJ_THREADS / 64; w++) if (sh[w] > r) r = sh[w];
+    return r;
+}
+__device__ __forceinline__ uint32_t sj_block_sum(uint32_t v, uint32_t *sh) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    uint32_t r = 0;
+    for (int w = 0; w < SJ_THREADS / 64; w++) r += sh[w];
+    return r;
+}
+
+// words here are at most SJ_MAX_LEN = 255 characters: four limbs at most (the 8-limb variant would cost the kernel half its waves)
+__device__ __forceinline__ int d_myers_le4(const uint64_t *peq, int need, const uint8_t *text, int m) {
+    switch (need) {
+        case 1: return d_myers<1>(peq, text, m);
+        case 2: return d_myers<2>(peq, text, m);
+        case 3: return d_myers<3>(peq, text, m);
+        default: return d_myers<4>(peq, text, m);
+    }
+}
+
+#define SJ_A16(x) (((x) + 15u) & ~15u)
+__global__ __launch_bounds__(SJ_THREADS) void k_job_small(DevParams P, Words W, Jobs J, ConsensusIO io, CMeta *meta, uint32_t lds_bytes, int pass) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    __shared__ uint16_t s_len[SJ_MAX_R], s_loff[SJ_MAX_R];            // word length; offset of its characters in units of 16 bytes
+    __shared__ uint16_t s_leafw[SJ_MAX_R], s_label[SJ_MAX_R], s_rank[SJ_MAX_R], s_share[SJ_MAX_R], s_list[SJ_MAX_R];
+    __shared__ uint8_t s_hasm[SJ_MAX_R];
+    __shared__ uint32_t s_red[8], s_u[8];
+    __shared__ int s_changed;
+    const uint32_t job = blockIdx.x;
+    if (job >= J.n) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t R = J.R[job];
+    if (pass == 0) {
+        if (R == 0 || R > SJ_MAX_R) {
+            if (tid == 0) { J.Rbig[job] = R; if (R) atomicAdd(&meta->n_big, 1u); }
+            return;
+        }
+    } else if (!(J.Rbig[job] >> 31)) return;
+    // every exit below is taken by the whole workgroup
+#define SJ_FAIL(permanent)                                                                                          \
+    do {                                                                                                            \
+        if (tid == 0) {                                                                                             \
+            if ((permanent) || pass != 0) { J.Rbig[job] = R; atomicAdd(&meta->n_big, 1u); }                         \
+            else { J.Rbig[job] = R | 0x80000000u; atomicAdd(&meta->n_retry, 1u); }                                  \
+        }                                                                                                           \
+        return;                                                                                                     \
+    } while (0)
+    const uint32_t w0 = J.w0[job];
+    const uint64_t goff0 = W.off[w0];
+    const uint32_t C = (uint32_t)(W.off[w0 + R] - goff0);     // characters of the job, every word padded to 16
+    int mylen = 0;
+    if ((uint32_t)tid < R) {
+        mylen = (int)W.len[w0 + tid];
+        s_len[tid] = (uint16_t)mylen;
+        s_loff[tid] = (uint16_t)((W.off[w0 + tid] - goff0) >> 4);
+    }
+    const uint32_t lkey = sj_block_max(((uint32_t)mylen << 16) | (0xFFFFu - (uint32_t)tid), s_red);   // longest word, the first of them
+    const uint32_t maxlen = lkey >> 16, longest = 0xFFFFu - (lkey & 0xFFFFu);
+    if (maxlen > SJ_MAX_LEN) SJ_FAIL(true);
+    if (C + 4096u > lds_bytes) SJ_FAIL(false);
+    uint8_t *ch = smem;
+    {
+        const uint4 *src = reinterpret_cast<const uint4 *>(W.ch + goff0);
+        for (uint32_t i = tid; i < (C >> 4); i += SJ_THREADS) reinterpret_cast<uint4 *>(ch)[i] = src[i];
+    }
+    __syncthreads();
+    // ---- leaves ---------------------------------------------------------------------------------------------------
+    bool leaf = false;
+    if ((uint32_t)tid < R) {
+        const uint8_t *a = ch + ((uint32_t)s_loff[tid] << 4);
+        const int la = mylen;
+        bool cov = false;
+        if (la <= 0) cov = R > 1;
+        else {
+            if ((uint32_t)tid != longest) {
+                const int lb = (int)s_len[longest];
+                if (lb >= la && d_lcp16(a, la, ch + ((uint32_t)s_loff[longest] << 4), lb) >= la && (lb > la || longest < (uint32_t)tid)) cov = true;
+            }
+            for (uint32_t w = 0; w < R && !cov; w++) {
+                if (w == (uint32_t)tid) continue;
+                const int lb = (int)s_len[w];
+                if (lb < la) continue;
+                if (d_lcp16(a, la, ch + ((uint32_t)s_loff[w] << 4), lb) >= la && (lb > la || w < (uint32_t)tid)) cov = true;
+            }
+        }
+        leaf = !cov;
+    }
+    uint32_t NL;
+    {
+        const uint32_t k = block_excl_scan(leaf ? 1u : 0u, s_red, &NL);
+        if (leaf) { s_leafw[k] = (uint16_t)tid; s_label[k] = (uint16_t)k; }
+    }
+    // ---- LDS layout --------------------------------------------------------------------------------------------------
+    const uint32_t NLW = (NL + 31) >> 5, needmax = (maxlen + 63) >> 6;
+    uint32_t o = SJ_A16(C);
+    uint8_t *M = smem + o; o += SJ_A16(NL * R);
+    uint32_t *adj = reinterpret_cast<uint32_t *>(smem + o); o += SJ_A16(NL * NLW * 4);
+    uint64_t *peq = reinterpret_cast<uint64_t *>(smem + o); o += 4 * needmax * 128;
+    uint8_t *bestc = smem + o; o += SJ_A16(maxlen + 1);
+    const uint32_t X = o;   // first the DFS tables (T: NL x NL bytes, tmin: maxlen words per wave), then the vote (maxlen x 16 words)
+    {
+        const uint32_t x1 = SJ_A16(NL * NL) + 4 * maxlen * 4, x2 = maxlen * 64;
+        o += x1 > x2 ? x1 : x2;
+    }
+    if (o > lds_bytes) SJ_FAIL(false);
+    __syncthreads();
+    // ---- M, adjacency cleared ------------------------------------------------------------------------------------------
+    for (uint32_t it = tid; it < NL * R; it += SJ_THREADS) {
+        const uint32_t a = it / R, v = it - a * R, wa = s_leafw[a];
+        M[it] = (uint8_t)d_lcp16(ch + ((uint32_t)s_loff[wa] << 4), (int)s_len[wa], ch + ((uint32_t)s_loff[v] << 4), (int)s_len[v]);
+    }
+    for (uint32_t i = tid; i < NL * NLW; i += SJ_THREADS) adj[i] = 0;
+    __syncthreads();
+    // ---- DFS order ---------------------------------------------------------------------------------------------------
+    {
+        uint8_t *T = smem + X;
+        uint32_t *tmin = reinterpret_cast<uint32_t *>(smem + X + SJ_A16(NL * NL)) + (uint32_t)wave * maxlen;
+        for (uint32_t a = wave; a < NL; a += SJ_THREADS / 64) {
+            const uint32_t wa = s_leafw[a];
+            const int la = (int)s_len[wa];
+            for (int d = lane; d < la; d += 64) tmin[d] = 0xFFFFFFFFu;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+            for (uint32_t v = lane; v < R; v += 64) { const uint32_t l = M[a * R + v]; if (l > 0) atomicMin(&tmin[l - 1], v); }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+            const int per = (la + 63) >> 6, d0 = lane * per;
+            uint32_t mine = 0xFFFFFFFFu;
+            for (int d = d0 + per - 1; d >= d0; d--) if (d < la) { const uint32_t v = tmin[d]; if (v < mine) mine = v; }
+            uint32_t suf = mine;
+            for (int s2 = 1; s2 < 64; s2 <<= 1) { const uint32_t other = __shfl_down(suf, s2, 64); if (lane + s2 < 64 && other < suf) suf = other; }
+            uint32_t m = __shfl_down(suf, 1, 64);
+            if (lane == 63) m = 0xFFFFFFFFu;
+            for (int d = d0 + per - 1; d >= d0; d--) if (d < la) { const uint32_t v = tmin[d]; if (v < m) m = v; tmin[d] = m; }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+            for (uint32_t b = lane; b < NL; b += 64) T[a * NL + b] = b == a ? (uint8_t)0 : (uint8_t)tmin[M[a * R + s_leafw[b]]];
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        }
+        __syncthreads();
+        if ((uint32_t)tid < NL) {
+            uint32_t rk = 0;
+            for (uint32_t b = 0; b < NL; b++) if (b != (uint32_t)tid && T[b * NL + tid] < T[(uint32_t)tid * NL + b]) rk++;
+            s_rank[tid] = (uint16_t)rk;
+        }
+    }
+    // ---- clusters ------------------------------------------------------------------------------------------------------
+    // one round: up to 4 pattern leaves (plist[p0 ..] or p0 .. when plist is null) against the partners `mode` names
+    uint32_t giant = 0;
+    auto round = [&](const uint16_t *plist, uint32_t p0, uint32_t np, int mode) {
+        __syncthreads();   // the previous round's readers are done with the match vectors
+        if ((uint32_t)wave < np) {
+            const uint32_t a = plist ? plist[p0 + wave] : p0 + wave, wa = s_leafw[a];
+            const int la = (int)s_len[wa];
+            d_peq_wave(ch + ((uint32_t)s_loff[wa] << 4), la, (la + 63) >> 6, lane, peq + (uint32_t)wave * needmax * 16);
+        }
+        __syncthreads();
+        for (uint32_t it = tid; it < np * NL; it += SJ_THREADS) {
+            const uint32_t pi = it / NL, b = it - pi * NL, a = plist ? plist[p0 + pi] : p0 + pi;
+            if (mode == 0) { if (b <= a) continue; }
+            else {
+                if (b == a) continue;
+                const uint32_t lbl = s_label[b];
+                if (lbl == s_label[a]) continue;
+                if (lbl != giant && b < a) continue;   // two leaves outside the giant component: the lower one's round takes the pair
+            }
+            const uint32_t wa = s_leafw[a], wb = s_leafw[b];
+            const int la = (int)s_len[wa], lb = (int)s_len[wb], m = la < lb ? la : lb;
+            const int d = d_myers_le4(peq + pi * needmax * 16, (m + 63) >> 6, ch + ((uint32_t)s_loff[wb] << 4), m);
+            if (4 * d <= m) {   // similarity = 1 - d/m >= 0.75 (findflanks.py:1044-1048, quirk Q11)
+                atomicOr(&adj[a * NLW + (b >> 5)], 1u << (b & 31));
+                atomicOr(&adj[b * NLW + (a >> 5)], 1u << (a & 31));
+            }
+        }
+    };
+    auto components = [&]() {
+        for (;;) {
+            __syncthreads();
+            if (tid == 0) s_changed = 0;
+            __syncthreads();
+            if ((uint32_t)tid < NL) {
+                const uint32_t l0 = s_label[tid];
+                uint32_t l = l0;
+                for (uint32_t x = 0; x < NLW; x++) {
+                    uint32_t bits = adj[(uint32_t)tid * NLW + x];
+                    while (bits) { const int b = __builtin_ctz(bits); bits &= bits - 1; const uint32_t lb = s_label[x * 32 + b]; if (lb < l) l = lb; }
+                }
+                const uint32_t ll = s_label[l];
+                if (ll < l) l = ll;
+                if (l < l0) { s_label[tid] = (uint16_t)l; s_changed = 1; }
+            }
+            __syncthreads();
+            if (!s_changed) break;
+        }
+    };
+    if (NL >= 2) {
+        round(nullptr, 0, NL < N_PIVOTS ? NL : N_PIVOTS, 0);
+        components();
+        // the largest component among those of the first leaves
+        const uint32_t npv = NL < N_PIVOTS ? NL : N_PIVOTS;
+        if (tid < N_PIVOTS) s_u[tid] = 0;
+        __syncthreads();
+        if ((uint32_t)tid < NL) {
+            const uint32_t l = s_label[tid];
+            for (uint32_t p = 0; p < npv; p++) if (s_label[p] == l) { atomicAdd(&s_u[p], 1u); break; }
+        }
+        __syncthreads();
+        {
+            uint32_t best = 0;
+            for (uint32_t p = 1; p < npv; p++) if (s_u[p] > s_u[best]) best = p;
+            giant = s_label[best];
+        }
+        uint32_t n_out;
+        {
+            const bool out = (uint32_t)tid < NL && s_label[tid] != giant;
+            const uint32_t k = block_excl_scan(out ? 1u : 0u, s_red, &n_out);
+            if (out) s_list[k] = (uint16_t)tid;
+        }
+        if (n_out) {
+            for (uint32_t p0 = 0; p0 < n_out; p0 += 4) round(s_list, p0, n_out - p0 < 4 ? n_out - p0 : 4, 1);
+            components();
+        }
+    }
+    __syncthreads();
+    if ((uint32_t)tid < NL) {
+        bool any = false;
+        for (uint32_t x = 0; x < NLW; x++) if (adj[(uint32_t)tid * NLW + x]) { any = true; break; }
+        s_hasm[tid] = any ? 1 : 0;
+        uint32_t share = 0;
+        const uint32_t wl = s_leafw[tid], lbl = s_label[tid];
+        for (uint32_t kp = 0; kp < (uint32_t)tid; kp++) if (s_label[kp] == lbl) { const uint32_t c = M[kp * R + wl]; if (c > share) share = c; }
+        s_share[tid] = (uint16_t)share;
+    }
+    __syncthreads();
+    // ---- vote, cluster by cluster; the best one so far is kept ------------------------------------------------------------
+    uint32_t *h = reinterpret_cast<uint32_t *>(smem + X);
+    const uint8_t *qbase = W.q + goff0;
+    uint32_t npl = 0, npb = 0, best_key = 0;
+    unsigned long long best_hi = 0;
+    bool have = false;
+    const uint32_t nchunk = (R + 63) >> 6;
+    const char codes[17] = "=ACMGRSVTWYHKDBN";
+    for (uint32_t r = 0; r < NL; r++) {
+        if (s_label[r] != r) continue;   // block-uniform
+        const bool mem = (uint32_t)tid < NL && s_label[tid] == r;
+        uint32_t nmem;
+        {
+            const uint32_t k = block_excl_scan(mem ? 1u : 0u, s_red, &nmem);
+            if (mem) s_list[k] = (uint16_t)tid;
+        }
+        const uint32_t maxd = sj_block_max(mem ? (uint32_t)s_len[s_leafw[tid]] : 0u, s_red);
+        const uint32_t minrank = 0xFFFFu - sj_block_max(mem ? 0xFFFFu - (uint32_t)s_rank[tid] : 0u, s_red);
+        for (uint32_t i = tid; i < maxd * 16; i += SJ_THREADS) h[i] = 0;
+        if (tid == 0) s_u[0] = maxd;
+        __syncthreads();
+        for (uint32_t it = wave; it < nmem * nchunk; it += SJ_THREADS / 64) {
+            const uint32_t a = s_list[it / nchunk], c = it % nchunk, v = c * 64 + lane, sh = s_share[a];
+            const uint32_t mv = v < R ? (uint32_t)M[a * R + v] : 0u;
+            unsigned long long mask = __ballot(mv > sh);
+            while (mask) {   // wave-uniform
+                const int vl = __builtin_ctzll(mask);
+                mask &= mask - 1;
+                const uint32_t Mv = __shfl(mv, vl, 64), vv = c * 64 + (uint32_t)vl, co = (uint32_t)s_loff[vv] << 4;
+                for (uint32_t d = sh + lane; d < Mv; d += 64) atomicAdd(&h[d * 16 + (ch[co + d] & 15)], (uint32_t)qbase[co + d] | 0x10000u);
+            }
+        }
+        uint32_t ends = 0;
+        if ((uint32_t)tid < R)
+            for (uint32_t i = 0; i < nmem; i++) if ((uint32_t)M[(uint32_t)s_list[i] * R + tid] == (uint32_t)s_len[tid]) { ends = 1; break; }
+        const uint32_t words = sj_block_sum(ends, s_red);   // (its barriers also complete the vote)
+        for (uint32_t d = tid; d < maxd; d += SJ_THREADS) {
+            uint32_t tot = 0;
+#pragma unroll
+            for (int c = 0; c < 16; c++) tot += h[d * 16 + c] >> 16;
+            if ((int64_t)tot < (int64_t)P.mcc) atomicMin(&s_u[0], d);
+        }
+        __syncthreads();
+        const uint32_t stop = s_u[0];
+        const uint32_t key = ((s_hasm[r] ? 1u : 0u) << 31) | (minrank & 0x7fffffffu);
+        if ((int32_t)stop >= P.minlen) {
+            npl++;
+            if ((int32_t)words >= P.mincount) {
+                npb++;
+                const unsigned long long cand = ((unsigned long long)words << 32) | (unsigned long long)stop;
+                if (!have || cand > best_hi || (cand == best_hi && key > best_key)) {   // max by (count, len); ties: the last in list order
+                    have = true; best_hi = cand; best_key = key;
+                    for (uint32_t d = tid; d < stop; d += SJ_THREADS) {
+                        int best = -1, nbest = 0;
+                        for (int c = 0; c < 16; c++) {
+                            const uint32_t x = h[d * 16 + c];
+                            if (!(x >> 16)) continue;
+                            if (best < 0 || (x & 0xFFFFu) > (h[d * 16 + best] & 0xFFFFu)) { best = c; nbest = 1; }
+                            else if ((x & 0xFFFFu) == (h[d * 16 + best] & 0xFFFFu)) nbest++;
+                        }
+                        bestc[d] = nbest > 1 ? 'N' : codes[best < 0 ? 15 : best];   // get_best_qual_chars flanktrie.py:344-353
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        io.n_pass_len[job] = npl; io.n_pass_both[job] = npb;
+        if (have) { io.cons_count[job] = (int32_t)(best_hi >> 32); io.cons_len[job] = (int32_t)(best_hi & 0xFFFFFFFFull); }
+        J.Rbig[job] = 0;
+    }
+    if (have) {
+        const int len = (int)(best_hi & 0xFFFFFFFFull), side = (int)(job & 1);
+        char *dst = io.cons_chars + (size_t)job * io.cons_stride;
+        for (int d = tid; d < len; d += SJ_THREADS) dst[side == 0 ? d : len - 1 - d] = (char)bestc[d];   // 3p consensus is reversed back (findflanks.py:894-895)
+    }
+#undef SJ_FAIL
+}
+
 // =====================================================================================================================
 int run_consensus(mfk_ctx *ctx, const DevReads &R, const DevParams &P, ConsensusIO &io) {
     hipStream_t st = ctx->stream;
@@ -1094,6 +1462,7 @@ int run_consensus(mfk_ctx *ctx, const DevReads &R, const DevParams &P, Consensus
     J.n = 2 * n_act;
     J.w0 = aalloc<uint32_t>(ctx, (size_t)J.n + 1); J.R = aalloc<uint32_t>(ctx, J.n); J.nl = aalloc<uint32_t>(ctx, J.n);
     J.adj_words = aalloc<uint32_t>(ctx, J.n); J.adj_off = aalloc<uint64_t>(ctx, (size_t)J.n + 1); J.best = aalloc<uint32_t>(ctx, J.n); J.giant = aalloc<uint32_t>(ctx, J.n); J.longest = aalloc<uint32_t>(ctx, 4 * (size_t)J.n);
+    J.Rbig = aalloc<uint32_t>(ctx, J.n);
     W.first = aalloc<int32_t>(ctx, E); W.job = aalloc<uint32_t>(ctx, E); W.len = aalloc<uint32_t>(ctx, E); W.src = aalloc<WordSrc>(ctx, E);
     W.off = aalloc<uint64_t>(ctx, (size_t)E + 1); W.is_leaf = aalloc<uint8_t>(ctx, E); W.leaf_word = aalloc<uint32_t>(ctx, E);
     W.cl_count = aalloc<int32_t>(ctx, E); W.cl_len = aalloc<int32_t>(ctx, E); W.cl_key = aalloc<uint32_t>(ctx, E);
@@ -1103,7 +1472,7 @@ int run_consensus(mfk_ctx *ctx, const DevReads &R, const DevParams &P, Consensus
         z.want(&meta, 1); z.want(&W.nextra, E); z.want(&W.plen, E); z.want(&W.leaf_rank, E);
         z.want(&W.has_match, E); z.want(&W.n_list, 8);
         f.want(&W.second, E); f.want(&W.label, E); f.want(&W.cover, E);
-        if (!wid || !J.w0 || !J.R || !J.nl || !J.adj_words || !J.adj_off || !J.best || !J.giant || !J.longest || !W.first || !W.job || !W.len || !W.src || !W.off ||
+        if (!wid || !J.w0 || !J.R || !J.nl || !J.adj_words || !J.adj_off || !J.best || !J.giant || !J.longest || !J.Rbig || !W.first || !W.job || !W.len || !W.src || !W.off ||
             !W.is_leaf || !W.leaf_word || !W.cl_count || !W.cl_len || !W.cl_key || !W.leaf_list || !W.rep_list || !W.share || !W.out_list || fill_commit2(z, f)) return 1;
     }
     if (J.n <= JM_ONE_MAX) {
@@ -1130,22 +1499,54 @@ int run_consensus(mfk_ctx *ctx, const DevReads &R, const DevParams &P, Consensus
     if (hm.err & ERR_READ_NUMBER) { snprintf(ctx->err, sizeof ctx->err, "READ NUMBER ERROR - ZERO OR MORE THAN TWO READS ASSOCIATED WITH QUERY NAME"); return 3; }
     if (hm.err & ERR_NO_SEQUENCE) { snprintf(ctx->err, sizeof ctx->err, "a clipped read at a surviving site has no sequence in the pool (pack with pool='clipped')"); return 2; }
     if (hm.err & ERR_WORD_TOO_LONG) { snprintf(ctx->err, sizeof ctx->err, "soft clip longer than %d bases: not supported by this build", MAX_WORD_LEN); return 6; }
+    W.ch = aalloc<uint8_t>(ctx, (size_t)total_chars + 64); W.q = aalloc<uint8_t>(ctx, (size_t)total_chars + 64);
+    if (total_chars >= 0xFFFFFFF0ull) { snprintf(ctx->err, sizeof ctx->err, "more than 2^32 clipped bases at the surviving sites of one call"); return 1; }
+    if (!W.ch || !W.q) return 1;
+    PROF_LAUNCH(k_word_fill, dim3(ww), dim3(256), 0, st, R, W);
+    KCHK();
+    const uint32_t max_len = hm.max_len ? hm.max_len : 1;
+    io.cons_stride = (max_len + 7) & ~7u;
+    io.cons_chars = aalloc<char>(ctx, (size_t)J.n * io.cons_stride);
+    if (!io.cons_chars) return 1;
+    io.err_dev = &meta->err;   // ERR_NO_SEQUENCE can still be raised by k_word_fill: the caller reads it with the results
+    // ---- small jobs: one workgroup per job, everything in LDS (k_job_small).  What it cannot take (more than SJ_MAX_R words,
+    // a word beyond SJ_MAX_LEN, tables beyond 128 KB of LDS) is counted in meta->n_big and goes through the device-wide kernels.
+    {
+        const char *ns_env = getenv("MFK_NO_SMALL_JOBS");   // test hook: everything through the device-wide kernels
+        const bool no_small = ns_env && *ns_env && *ns_env != '0';
+        if (no_small) {
+            hm.n_big = 1;
+            HIPCHK(hipMemcpyAsync(J.Rbig, J.R, (size_t)J.n * 4, hipMemcpyDeviceToDevice, st));
+        } else {
+            const uint32_t lds0 = 40 * 1024, lds1 = 128 * 1024;
+            if (!ctx->sj_attr) { HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_job_small), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1)); ctx->sj_attr = true; }
+            PROF_LAUNCH(k_job_small, dim3(J.n), dim3(SJ_THREADS), lds0, st, P, W, J, io, meta, lds0, 0);
+            KCHK();
+            if (int rc = read_back(ctx, meta, &hm, sizeof hm)) return rc;
+            if (hm.n_retry) {
+                PROF_LAUNCH(k_job_small, dim3(J.n), dim3(SJ_THREADS), lds1, st, P, W, J, io, meta, lds1, 1);
+                KCHK();
+                if (int rc = read_back(ctx, meta, &hm, sizeof hm)) return rc;
+            }
+        }
+    }
+    if (!hm.n_big) return 0;
+    // ---- the device-wide kernels, for the jobs left: they see R = 0 for every job that is done ------------------------
+    J.R = J.Rbig;
     {
         FillGroup z(ctx, 0);
         z.want(&J.adj, (size_t)adj_total); z.want(&W.agg_qc, (size_t)total_chars + 8); z.want(&W.agg_e, (size_t)total_chars + 8);
-        // first touched by k_leaf_compact and later: the fill runs on the third stream next to the three kernels before it
+        // first touched by k_leaf_compact and later: the fill runs on the third stream next to the two kernels before it
+        HIPCHK(hipEventRecord(ctx->ev_fork3, st));
+        HIPCHK(hipStreamWaitEvent(ctx->stream3, ctx->ev_fork3, 0));   // the arena block may be one an earlier kernel of this call has used
         ctx->fill_stream = ctx->stream3;
         const int fill_rc = z.commit();
         ctx->fill_stream = nullptr;
         if (fill_rc) return 1;
         HIPCHK(hipEventRecord(ctx->ev_fill, ctx->stream3));
     }
-    W.ch = aalloc<uint8_t>(ctx, (size_t)total_chars + 64); W.q = aalloc<uint8_t>(ctx, (size_t)total_chars + 64);
-    if (total_chars >= 0xFFFFFFF0ull) { snprintf(ctx->err, sizeof ctx->err, "more than 2^32 clipped bases at the surviving sites of one call"); return 1; }
     W.npos = aalloc<uint32_t>(ctx, (size_t)total_chars + 8);
-    if (!W.ch || !W.q || !W.npos) return 1;
-    PROF_LAUNCH(k_word_fill, dim3(ww), dim3(256), 0, st, R, W);
-    KCHK();
+    if (!W.npos) return 1;
     PROF_LAUNCH(k_job_longest, dim3(J.n), dim3(256), 0, st, W, J);
     KCHK();
     const int lf = Wn >= (1u << 18) ? LF_WORDS : (Wn >= (1u << 17) ? 4 : (Wn >= (1u << 16) ? 2 : 1));
@@ -1197,7 +1598,6 @@ int run_consensus(mfk_ctx *ctx, const DevReads &R, const DevParams &P, Consensus
     else { PROF_LAUNCH(k_leaf_rank, dim3(g_leaf4), dim3(256), 0, sc, W, J, (const uint16_t *)lcpm); }
     KCHK();
     HIPCHK(hipEventRecord(ctx->ev_join3, sc));
-    const uint32_t max_len = hm.max_len ? hm.max_len : 1;
     {
         const size_t ns_lds = (size_t)max_len * NS_SLOTS * 16;   // <= 64 KB with MAX_WORD_LEN 512
         PROF_LAUNCH(k_node_sums, dim3(nblocks(Wn, NS_WORDS)), dim3(1024), ns_lds, st, W, J, max_len);
@@ -1208,16 +1608,13 @@ int run_consensus(mfk_ctx *ctx, const DevReads &R, const DevParams &P, Consensus
     HIPCHK(hipStreamWaitEvent(st, ctx->ev_join3, 0));
     size_t lds = (size_t)max_len * 16 * 8;
     if (lds > 64 * 1024) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_cluster_vote), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    io.cons_stride = (max_len + 7) & ~7u;
-    io.cons_chars = aalloc<char>(ctx, (size_t)J.n * io.cons_stride);
     char *cl_chars = aalloc<char>(ctx, (size_t)Wn * io.cons_stride);
-    if (!io.cons_chars || !cl_chars) return 1;
+    if (!cl_chars) return 1;
     PROF_LAUNCH(k_leaf_share, dim3(g_leaf4), dim3(256), 0, st, W, J, (const uint16_t *)lcpm);
     KCHK();
     PROF_LAUNCH(k_cluster_vote, dim3(g_rep), dim3(CV_THREADS), lds, st, P, W, J, max_len, cl_chars, io.cons_stride);
     KCHK();
     PROF_LAUNCH(k_job_best, dim3(J.n), dim3(256), 0, st, P, W, J, io, (const char *)cl_chars, io.cons_stride);
     KCHK();
-    io.err_dev = &meta->err;   // ERR_NO_SEQUENCE can still be raised by k_word_fill: the caller reads it with the results
     return 0;
 }

@@ -194,6 +194,7 @@ __device__ inline void d_fetch_range_2waves(const DevReads &R, int32_t contig, i
     if ((threadIdx.x & 63) == 0) range[w] = v;
 }
 __device__ inline int64_t d_pool_index_wave(const DevReads &R, int64_t r) {
+    if (R.n_pool == R.n) return r;   // every read is pooled (pool_read is ascending and distinct, so it is the identity)
     const int64_t lo = d_wave_lower_bound<uint32_t, int64_t>(R.pool_read, 0, R.n_pool, r);
     if (lo >= R.n_pool || (int64_t)R.pool_read[lo] != r) return -1;
     return lo;
@@ -207,6 +208,7 @@ __device__ __forceinline__ bool d_overlaps(const DevReads &R, int64_t r, int32_t
 
 // ---- sequence pool ----------------------------------------------------------------------------------------------
 __device__ inline int64_t d_pool_index(const DevReads &R, int64_t r) {
+    if (R.n_pool == R.n) return r;   // every read is pooled: no search
     int64_t lo = 0, hi = R.n_pool;
     while (lo < hi) { int64_t m = (lo + hi) >> 1; if ((int64_t)R.pool_read[m] < r) lo = m + 1; else hi = m; }
     if (lo >= R.n_pool || (int64_t)R.pool_read[lo] != r) return -1;

@@ -48,8 +48,16 @@ def _is_library(rng, n=8):
 
 def synth_packed(contig_lens=(200_000,), coverage=60, n_insertions=6, seed=1, read_len=150, frag_mean=400, frag_sd=50,
                  end_error=(0.002, 0.01), clip_error=0.004, indel_frac=0.02, low_mapq_frac=0.03, wildtype_frac=0.05,
-                 tsd_choices=(2, 3, 4, 5, 8, 9)):
-    """Returns (PackedReads, genome dict name -> str, truth list of (contig, pos_5p, pos_3p))."""
+                 tsd_choices=(2, 3, 4, 5, 8, 9), pool="near"):
+    """Returns (PackedReads, genome dict name -> str, truth list of (contig, pos_5p, pos_3p)).
+
+    pool: which reads carry their sequence + qualities.  "all": every read, which is what a ONE-pass run (findflanks and
+    pairflanks on the same resident arrays, ``mfk_flankpairs``) needs when it cannot know beforehand where the
+    direct-repeat windows of pairflanks will be; it uses no knowledge of the insertions (bench.py).  "near": the
+    lenient-clipped reads plus the reads within 60 bp of a simulated insertion -- the same bytes reach the kernels, at
+    a fraction of the generation time and memory, but the choice uses the ground truth (parity tests only)."""
+    if pool not in ("near", "all"):
+        raise ValueError("pool must be 'near' or 'all'")
     rng = np.random.Generator(np.random.PCG64(seed))
     lib = _is_library(rng)
     L = read_len
@@ -195,35 +203,49 @@ def synth_packed(contig_lens=(200_000,), coverage=60, n_insertions=6, seed=1, re
         link = np.full(nr, -1, np.int64)
         later, earlier = by_frag[1:][same], by_frag[:-1][same]
         link[later] = earlier + read_base
-        # pool: clipped reads and reads near an insertion site
+        # pool: clipped reads and reads near an insertion site, or every read
         near = np.zeros(nr, bool)
-        if n_ins:
+        if n_ins and pool == "near":
             lo_w, hi_w = pos - 60, pos + tsd + 60
             j = np.searchsorted(hi_w, rs_)                       # first window ending after the read start
             jj = np.minimum(j, n_ins - 1)
             near = (j < n_ins) & (re_ > lo_w[jj]) & (rs_ < hi_w[jj])
-        pooled = ((flags & 15) != 0) | near
+        pooled = np.ones(nr, bool) if pool == "all" else (((flags & 15) != 0) | near)
         flags[pooled] |= FLAG_POOL
-        pidx = np.nonzero(pooled)[0]
-        src = a[order][pidx]
-        wtp = iswt[order][pidx]
+        pidx_all = np.nonzero(pooled)[0]
         plen = L + (L & 1)
-        off = np.arange(L)[None, :]
-        seqs = np.zeros((pidx.shape[0], plen), np.uint8)
-        samp_rows = np.nonzero(~wtp)[0]; wt_rows = np.nonzero(wtp)[0]
-        seqs[samp_rows, :L] = sample[src[samp_rows][:, None] + off]
-        seqs[wt_rows, :L] = ref[src[wt_rows][:, None] + off]
-        # sequencing errors inside pooled reads (clip bases get realistic disagreement -> several trie leaves)
-        err = rng.random((pidx.shape[0], L)) < clip_error
-        seqs[:, :L] = np.where(err, (seqs[:, :L] + rng.integers(1, 4, (pidx.shape[0], L))) % 4, seqs[:, :L])
-        # MD-mismatch ends must really mismatch nothing in particular (the clipped base is just the terminal base)
-        quals = np.zeros((pidx.shape[0], plen), np.uint8)
-        quals[:, :L] = rng.integers(2, 41, (pidx.shape[0], L))
-        codes = _CODE[seqs]
-        codes[:, L:] = 0
-        pool_read.append(pidx + read_base)
-        pool_len.append(np.full(pidx.shape[0], plen, np.int64))
-        pool_codes.append(codes.reshape(-1)); pool_quals.append(quals.reshape(-1))
+        sample_win = np.lib.stride_tricks.sliding_window_view(sample, L)
+        ref_win = np.lib.stride_tricks.sliding_window_view(ref, L)
+        a_ord, wt_ord = a[order], iswt[order]
+        # in chunks: "all" at the 50 Mb / 200x size is 69 M reads x 150 bases
+        CH = 1 << 21
+        for c0 in range(0, pidx_all.shape[0], CH):
+            pidx = pidx_all[c0:c0 + CH]
+            src = a_ord[pidx]
+            wtp = wt_ord[pidx]
+            seqs = np.zeros((pidx.shape[0], plen), np.uint8)
+            samp_rows = np.nonzero(~wtp)[0]; wt_rows = np.nonzero(wtp)[0]
+            seqs[samp_rows, :L] = sample_win[src[samp_rows]]     # row copies: no n x L index array
+            seqs[wt_rows, :L] = ref_win[src[wt_rows]]
+            # sequencing errors inside pooled reads (clip bases get realistic disagreement -> several trie leaves)
+            if pool == "near":
+                err = rng.random((pidx.shape[0], L)) < clip_error
+                seqs[:, :L] = np.where(err, (seqs[:, :L] + rng.integers(1, 4, (pidx.shape[0], L))) % 4, seqs[:, :L])
+            else:   # the same error model drawn sparsely (number of errors, then their places): 150 x fewer random numbers
+                n_err = int(rng.binomial(pidx.shape[0] * L, clip_error))
+                er, ec = rng.integers(0, pidx.shape[0], n_err), rng.integers(0, L, n_err)
+                seqs[er, ec] = (seqs[er, ec] + rng.integers(1, 4, n_err).astype(np.uint8)) % 4
+            quals = np.zeros((pidx.shape[0], plen), np.uint8)
+            if pool == "near":
+                quals[:, :L] = rng.integers(2, 41, (pidx.shape[0], L), dtype=np.uint8)
+            else:   # raw generator bytes scaled to 2..40: ten times faster than bounded integers, same range
+                raw = rng.bit_generator.random_raw((pidx.shape[0] * L + 7) // 8).view(np.uint8)[:pidx.shape[0] * L]
+                quals[:, :L] = (2 + ((raw.astype(np.uint16) * 39) >> 8)).astype(np.uint8).reshape(-1, L)
+            codes = np.left_shift(np.uint8(1), seqs, dtype=np.uint8)   # A C G T -> 1 2 4 8 (_CODE)
+            codes[:, L:] = 0
+            pool_read.append(pidx + read_base)
+            pool_len.append(np.full(pidx.shape[0], plen, np.int64))
+            pool_codes.append(pack_nibbles(codes.reshape(-1))); pool_quals.append(quals.reshape(-1))
         # columns
         cols["ref_start"].append(rs_); cols["ref_end"].append(re_); cols["link"].append(link)
         cols["contig_id"].append(np.full(nr, ci)); cols["qlen"].append(np.full(nr, L))
@@ -244,7 +266,7 @@ def synth_packed(contig_lens=(200_000,), coverage=60, n_insertions=6, seed=1, re
     arrays["pool_read"] = np.concatenate(pool_read).astype(np.uint32)
     plen_all = np.concatenate(pool_len)
     arrays["pool_off"] = np.concatenate([[0], np.cumsum(plen_all)]).astype(np.uint64)
-    arrays["pool_bases"] = pack_nibbles(np.concatenate(pool_codes))
+    arrays["pool_bases"] = np.concatenate(pool_codes)   # per chunk an even number of bases: the packed pieces join on byte boundaries
     arrays["pool_quals"] = np.concatenate(pool_quals).astype(np.uint8)
     max_span = int((arrays["ref_end"].astype(np.int64) - arrays["ref_start"]).max()) if read_base else 1
     packed = PackedReads(list(genome.keys()), arrays, max_span)

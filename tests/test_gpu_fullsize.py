@@ -74,3 +74,49 @@ def test_list_and_device_sort_path_gives_the_same_bytes(hip, monkeypatch):
     b = hip.run_findflanks(rd, lib.make_params())
     assert a["seqs"] == b["seqs"] and a["flanks"].tobytes() == b["flanks"].tobytes() and a["sites"].tobytes() == b["sites"].tobytes()
     assert list(a["stats"]) == list(b["stats"]) and len(a["flanks"]) > 0
+
+
+@pytest.mark.parametrize("name", ["C4_batch12", "C5_meta_50mb"])
+def test_fullsize_digest(hip, name):
+    """BASELINE configs[3] (the 12 isolates one GPU holds of the 96, as ONE batch) and configs[4] (50 Mb, 200x, 10 000
+    insertions: 69 M reads) at full size.  The oracle needs minutes for these, so its results travel as sha256 digests
+    (tests/golden/fullsize_digests.json, written by tests/golden/make_fullsize_digests.py in the build container from the
+    same seeds); every byte of both result tables and the logged counters go into them."""
+    import json
+    import torch
+    from tests.util import FULLSIZE_DIGESTS, fullsize_inputs, result_digests
+    want = json.load(open(FULLSIZE_DIGESTS))
+    assert want["numpy"].split(".")[:2] == np.__version__.split(".")[:2], "digests were made with another numpy: the seeded inputs may differ"
+    packed, g, goff, ranks = fullsize_inputs(name)
+    assert packed.n_reads == want[name]["n_reads"]
+    rd = device_reads(hip, packed, "cuda:0")
+    params = lib.make_params()
+    ff = hip.run_findflanks(rd, params)
+    pf = hip.run_pairflanks(rd, params, ff["flanks"], ff["seqs"], ranks, torch.from_numpy(g).to("cuda:0"), goff)
+    got = result_digests(ff, pf)
+    for k in ("n_flanks", "n_pairs", "stats", "pair_stats", "flanks", "seqs", "pairs", "strs"):
+        assert got[k] == want[name][k], k
+    # and the fused entry point gives the same bytes at this size
+    ff2, pf2 = hip.run_flankpairs(rd, params, ranks, torch.from_numpy(g).to("cuda:0"), goff)
+    assert result_digests(ff2, pf2) == got
+
+
+@pytest.mark.parametrize("kw", [dict(CONFIGS["tiny"]), dict(contig_lens=(400_000,), coverage=200, n_insertions=40),
+                                dict(contig_lens=(150_000,), coverage=230, n_insertions=12, clip_error=0.05),
+                                dict(contig_lens=(60_000,), coverage=420, n_insertions=6, clip_error=0.02)])
+def test_small_job_kernel_and_device_wide_kernels_agree(hip, oracle, monkeypatch, kw):
+    """The consensus of a site-side runs in one workgroup (k_job_small: up to 256 words that fit the LDS budget, a second
+    launch with a larger budget for those that do not) or through the device-wide kernels; MFK_NO_SMALL_JOBS sends every
+    job down the second way.  Same bytes either way, and the oracle's: shallow sites, 200x sites, sites where nearly
+    every word is a leaf (5 % errors: the tables outgrow the first budget), sites around the 256-word limit."""
+    packed, genome, _ = synth_packed(**kw, seed=13)
+    rd = device_reads(hip, packed, "cuda:0")
+    params = lib.make_params()
+    a = hip.run_findflanks(rd, params)
+    monkeypatch.setenv("MFK_NO_SMALL_JOBS", "1")
+    b = hip.run_findflanks(rd, params)
+    monkeypatch.delenv("MFK_NO_SMALL_JOBS")
+    assert a["seqs"] == b["seqs"] and a["flanks"].tobytes() == b["flanks"].tobytes() and list(a["stats"]) == list(b["stats"])
+    want = oracle.run_findflanks(oracle.reads(packed), params)
+    assert a["seqs"] == want["seqs"] and a["flanks"].tobytes() == want["flanks"].tobytes() and len(a["flanks"]) > 0
+    assert list(a["stats"][:12]) == list(want["stats"][:12])

@@ -73,3 +73,38 @@ def overlap_text(binding, entry):
     p = dict(min_overlap_score=10, min_overlap_perc_identity=0.9, min_inferseq_size=30)
     p.update(entry["params"])
     return iso.inferseq_overlap_frame(binding, pairs, **p).to_csv(sep="\t", index=False)
+
+
+# ---- full-size BASELINE configs whose oracle run is too long for the GPU suite: compared through digests ---------------
+FULLSIZE_DIGESTS = os.path.join(GOLDEN, "fullsize_digests.json")
+
+
+def fullsize_inputs(name):
+    """(packed, genome bytes, genome offsets, contig ranks) of a digest case; deterministic in the numpy version's PCG64.
+    C5_meta_50mb: BASELINE configs[4] (50 Mb, 200x, 10 000 insertions), seed 7.  C4_batch12: what one GPU holds of
+    configs[3] (96 E. coli isolates over 8 GPUs): 12 x C1 in one batch, the seeds bench.py uses on rank 0."""
+    from mustache_amd import cohort
+    from mustache_amd.synth import CONFIGS, synth_packed
+    if name == "C5_meta_50mb":
+        packed, genome, _ = synth_packed(**CONFIGS["C5_meta_50mb"], seed=7)
+        g, goff = pfh.genome_arrays(genome, packed.contig_names)
+        return packed, g, goff, pfh.contig_ranks(packed.contig_names)
+    if name == "C4_batch12":
+        packs, genomes = [], []
+        for i in range(12):
+            p_, g_, _ = synth_packed(**CONFIGS["C1_ecoli_100x"], seed=1000 + i)
+            packs.append(p_); genomes.append(g_)
+        batch = cohort.concat_samples(packs, ["isolate%d" % i for i in range(12)])
+        g, goff = cohort.batch_genome(batch, genomes)
+        return batch.packed, g, goff, cohort.batch_contig_ranks(batch)
+    raise KeyError(name)
+
+
+def result_digests(ff, pf):
+    """sha256 of every byte the two result tables hold (+ the logged counters), and the sizes for a readable failure."""
+    import hashlib
+    h = lambda b: hashlib.sha256(bytes(b)).hexdigest()
+    return {"flanks": h(np.ascontiguousarray(ff["flanks"]).tobytes()), "seqs": h(ff["seqs"]),
+            "stats": [int(x) for x in ff["stats"][:12]], "pairs": h(np.ascontiguousarray(pf["pairs"]).tobytes()),
+            "strs": h(pf["strs"]), "pair_stats": [int(x) for x in pf["stats"][:5]],
+            "n_flanks": int(len(ff["flanks"])), "n_pairs": int(len(pf["pairs"]))}
