@@ -100,6 +100,27 @@ __device__ __forceinline__ int d_lcp(const uint8_t *a, int la, const uint8_t *b,
     return m;
 }
 
+// Hamming distance of a[0:m) and b[0:m), 16 bytes per step, given up once it exceeds `limit` (returns limit + 1 or more).
+// The edit distance never exceeds it, so a pair with 4 * hamming <= m is a match without running the bit-vector recurrence
+// (words of one site-side are copies of one sequence with substitution errors: nearly every pair is settled here).
+__device__ __forceinline__ int d_hamming16(const uint8_t *a, const uint8_t *b, int m, int limit) {
+    int hd = 0;
+    for (int o = 0; o < m && hd <= limit; o += 16) {
+        const uint4 x = *reinterpret_cast<const uint4 *>(a + o), y = *reinterpret_cast<const uint4 *>(b + o);
+        uint32_t d[4] = {x.x ^ y.x, x.y ^ y.y, x.z ^ y.z, x.w ^ y.w};
+        const int left = m - o;   // bytes of this step that count
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            uint32_t w = d[i];
+            w |= w >> 4; w |= w >> 2; w |= w >> 1; w &= 0x01010101u;   // one bit per differing byte
+            const int nb = left - 4 * i;
+            if (nb < 4) w &= nb <= 0 ? 0u : ((1u << (8 * nb)) - 1u);
+            hd += __popc(w);
+        }
+    }
+    return hd;
+}
+
 // ---- words ------------------------------------------------------------------------------------------------------
 // words of a job = the first reads of the distinct query names of its site-side, i.e. the events with info bit 2: their
 // number is the site's distinct-name count (k_site_accumulate), so the word ranges come from a scan over the job slots
@@ -722,7 +743,9 @@ __global__ __launch_bounds__(256) void k_leaf_myers(Words W, Jobs J, int mode, u
             const uint32_t wb = w0 + W.leaf_word[w0 + kb];
             const int lb = (int)W.len[wb];
             const int m = la < lb ? la : lb;
-            const int d = d_myers_any(peq, need, W.ch + W.off[wb], m);
+            const uint8_t *tb = W.ch + W.off[wb];
+            int d = d_hamming16(a, tb, m, m >> 2);
+            if (4 * d > m) d = d_myers_any(peq, need, tb, m);
             if (4 * d <= m) {   // similarity = 1 - d/m >= 0.75 (findflanks.py:1044-1048, quirk Q11)
                 atomicOr(&adj[(size_t)ka * rw + (kb >> 5)], 1u << (kb & 31));
                 atomicOr(&adj[(size_t)kb * rw + (ka >> 5)], 1u << (ka & 31));
@@ -1157,13 +1180,26 @@ __device__ __forceinline__ int d_myers_le4(const uint64_t *peq, int need, const 
 }
 
 #define SJ_A16(x) (((x) + 15u) & ~15u)
+// diagnostic build only (make SJ_STAMP=1): shader cycles of thread 0 between the phases of k_job_small, summed over the jobs
+#ifdef SJ_STAMP
+__device__ unsigned long long g_sj_cyc[16];
+#define SJ_T(i) do { if (tid == 0) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); atomicAdd(&g_sj_cyc[i], t_ - sj_last); sj_last = t_; } } while (0)
+extern "C" int mfk_debug_sj(unsigned long long *out) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_sj_cyc), sizeof(unsigned long long) * 16) != hipSuccess) return 1;
+    unsigned long long z[16] = {0};
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_sj_cyc), z, sizeof z) == hipSuccess ? 0 : 1;
+}
+#else
+#define SJ_T(i) do { } while (0)
+#endif
 __global__ __launch_bounds__(SJ_THREADS) void k_job_small(DevParams P, Words W, Jobs J, ConsensusIO io, CMeta *meta, uint32_t lds_bytes, int pass) {
     extern __shared__ __align__(16) unsigned char smem[];
     __shared__ uint16_t s_len[SJ_MAX_R], s_loff[SJ_MAX_R];            // word length; offset of its characters in units of 16 bytes
-    __shared__ uint16_t s_leafw[SJ_MAX_R], s_label[SJ_MAX_R], s_rank[SJ_MAX_R], s_share[SJ_MAX_R], s_list[SJ_MAX_R];
+    __shared__ uint16_t s_leafw[SJ_MAX_R], s_label[SJ_MAX_R], s_rank[SJ_MAX_R], s_list[SJ_MAX_R];
     __shared__ uint8_t s_hasm[SJ_MAX_R];
+    __shared__ __align__(16) uint32_t s_sig[SJ_MAX_R], s_usig[SJ_MAX_R], s_wr[SJ_MAX_R + 8];   // signatures (leaves); reach | character offset << 8 of a word (vote)
     __shared__ uint32_t s_red[8], s_u[8];
-    __shared__ int s_changed;
+    __shared__ int s_changed, s_other;
     const uint32_t job = blockIdx.x;
     if (job >= J.n) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1183,6 +1219,9 @@ __global__ __launch_bounds__(SJ_THREADS) void k_job_small(DevParams P, Words W, 
         }                                                                                                           \
         return;                                                                                                     \
     } while (0)
+#ifdef SJ_STAMP
+    unsigned long long sj_last = __builtin_amdgcn_s_memtime();
+#endif
     const uint32_t w0 = J.w0[job];
     const uint64_t goff0 = W.off[w0];
     const uint32_t C = (uint32_t)(W.off[w0 + R] - goff0);     // characters of the job, every word padded to 16
@@ -1193,72 +1232,108 @@ __global__ __launch_bounds__(SJ_THREADS) void k_job_small(DevParams P, Words W, 
         s_loff[tid] = (uint16_t)((W.off[w0 + tid] - goff0) >> 4);
     }
     const uint32_t lkey = sj_block_max(((uint32_t)mylen << 16) | (0xFFFFu - (uint32_t)tid), s_red);   // longest word, the first of them
-    const uint32_t maxlen = lkey >> 16, longest = 0xFFFFu - (lkey & 0xFFFFu);
+    const uint32_t maxlen = lkey >> 16;
     if (maxlen > SJ_MAX_LEN) SJ_FAIL(true);
-    if (C + 4096u > lds_bytes) SJ_FAIL(false);
-    uint8_t *ch = smem;
+    if (2 * C + 4096u > lds_bytes) SJ_FAIL(false);
+    uint8_t *ch = smem, *qs = smem + SJ_A16(C);   // characters and qualities of the job's words
     {
-        const uint4 *src = reinterpret_cast<const uint4 *>(W.ch + goff0);
-        for (uint32_t i = tid; i < (C >> 4); i += SJ_THREADS) reinterpret_cast<uint4 *>(ch)[i] = src[i];
+        const uint4 *src = reinterpret_cast<const uint4 *>(W.ch + goff0), *qsrc = reinterpret_cast<const uint4 *>(W.q + goff0);
+        for (uint32_t i = tid; i < (C >> 4); i += SJ_THREADS) { reinterpret_cast<uint4 *>(ch)[i] = src[i]; reinterpret_cast<uint4 *>(qs)[i] = qsrc[i]; }
     }
     __syncthreads();
+    SJ_T(0);   // load
     // ---- leaves ---------------------------------------------------------------------------------------------------
-    bool leaf = false;
-    if ((uint32_t)tid < R) {
-        const uint8_t *a = ch + ((uint32_t)s_loff[tid] << 4);
-        const int la = mylen;
+    // Up to four reference words L_0 .. L_3: L_0 is the job's (first) longest word, L_k the longest word not yet settled.
+    // p_k(v) = LCP(v, L_k).  A word that is a prefix of a reference is no leaf; a reference is a leaf (nothing longer is
+    // left that could extend it).  A word v still unsettled leaves every reference at p_k(v) < len(v), and so does every
+    // word that extends v: candidates must have the same four p_k ("signature"), and only those are compared in full.
+    // The signatures also give most of M below without looking at a character.
+    const uint8_t *mych = ch + ((uint32_t)s_loff[tid < (int)R ? tid : 0] << 4);
+    bool unsettled = (uint32_t)tid < R, leaf = false;
+    uint32_t sig = 0;
+    for (int k = 0; k < 4; k++) {
+        const uint32_t key = sj_block_max(unsettled ? (((uint32_t)mylen << 16) | (0xFFFFu - (uint32_t)tid)) : 0u, s_red);
+        if (!key) break;   // block-uniform: every word is settled
+        const uint32_t Lk = 0xFFFFu - (key & 0xFFFFu);
+        const int lenL = (int)(key >> 16);
+        if ((uint32_t)tid < R) {
+            const int p = (uint32_t)tid == Lk ? mylen : d_lcp16(mych, mylen, ch + ((uint32_t)s_loff[Lk] << 4), lenL);
+            sig |= (uint32_t)p << (8 * k);
+            if ((uint32_t)tid == Lk) { leaf = true; unsettled = false; }
+            else if (unsettled && p == mylen) unsettled = false;   // a prefix of L_k (or a later copy of it)
+        }
+    }
+    if ((uint32_t)tid < R) s_sig[tid] = sig;
+    uint32_t nU;
+    {
+        const uint32_t k = block_excl_scan(unsettled ? 1u : 0u, s_red, &nU);
+        if (unsettled) { s_list[k] = (uint16_t)tid; s_usig[k] = sig; }
+    }
+    __syncthreads();
+    if (unsettled) {
         bool cov = false;
-        if (la <= 0) cov = R > 1;
-        else {
-            if ((uint32_t)tid != longest) {
-                const int lb = (int)s_len[longest];
-                if (lb >= la && d_lcp16(a, la, ch + ((uint32_t)s_loff[longest] << 4), lb) >= la && (lb > la || longest < (uint32_t)tid)) cov = true;
-            }
-            for (uint32_t w = 0; w < R && !cov; w++) {
+        for (uint32_t i0 = 0; i0 < nU && !cov; i0 += 4) {
+            uint32_t sg[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) sg[u] = i0 + u < nU ? s_usig[i0 + u] : ~sig;
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                if (sg[u] != sig || cov) continue;
+                const uint32_t w = s_list[i0 + u];
                 if (w == (uint32_t)tid) continue;
                 const int lb = (int)s_len[w];
-                if (lb < la) continue;
-                if (d_lcp16(a, la, ch + ((uint32_t)s_loff[w] << 4), lb) >= la && (lb > la || w < (uint32_t)tid)) cov = true;
+                if (lb < mylen) continue;
+                if (d_lcp16(mych, mylen, ch + ((uint32_t)s_loff[w] << 4), lb) >= mylen && (lb > mylen || w < (uint32_t)tid)) cov = true;
             }
         }
         leaf = !cov;
     }
     uint32_t NL;
     {
-        const uint32_t k = block_excl_scan(leaf ? 1u : 0u, s_red, &NL);
+        const uint32_t k = block_excl_scan(leaf ? 1u : 0u, s_red, &NL);   // (its first barrier also ends the reads of s_list)
         if (leaf) { s_leafw[k] = (uint16_t)tid; s_label[k] = (uint16_t)k; }
     }
     // ---- LDS layout --------------------------------------------------------------------------------------------------
     const uint32_t NLW = (NL + 31) >> 5, needmax = (maxlen + 63) >> 6;
-    uint32_t o = SJ_A16(C);
-    uint8_t *M = smem + o; o += SJ_A16(NL * R);
+    uint32_t o = 2 * SJ_A16(C);
     uint32_t *adj = reinterpret_cast<uint32_t *>(smem + o); o += SJ_A16(NL * NLW * 4);
     uint64_t *peq = reinterpret_cast<uint64_t *>(smem + o); o += 4 * needmax * 128;
     uint8_t *bestc = smem + o; o += SJ_A16(maxlen + 1);
-    const uint32_t X = o;   // first the DFS tables (T: NL x NL bytes, tmin: maxlen words per wave), then the vote (maxlen x 16 words)
+    const uint32_t X = o;   // first the DFS table (first[a][d], NL x Ls bytes), then the vote (rows of the rare base codes: maxlen x 16 words; 4 KB of partial sums)
     {
-        const uint32_t x1 = SJ_A16(NL * NL) + 4 * maxlen * 4, x2 = maxlen * 64;
+        const uint32_t x1 = SJ_A16(NL * NL) + 4 * maxlen * 4, x2 = maxlen * 64 + 4096;
         o += x1 > x2 ? x1 : x2;
     }
     if (o > lds_bytes) SJ_FAIL(false);
-    __syncthreads();
-    // ---- M, adjacency cleared ------------------------------------------------------------------------------------------
-    for (uint32_t it = tid; it < NL * R; it += SJ_THREADS) {
-        const uint32_t a = it / R, v = it - a * R, wa = s_leafw[a];
-        M[it] = (uint8_t)d_lcp16(ch + ((uint32_t)s_loff[wa] << 4), (int)s_len[wa], ch + ((uint32_t)s_loff[v] << 4), (int)s_len[v]);
-    }
     for (uint32_t i = tid; i < NL * NLW; i += SJ_THREADS) adj[i] = 0;
     __syncthreads();
+    SJ_T(1);   // leaves
+    // LCP of two words of the job.  Two words that leave a reference at different positions share exactly the shorter of the
+    // two stretches, so the signatures settle it without a look at the characters unless all four positions agree.
+    auto wlcp = [&](uint32_t sa, uint32_t wa, uint32_t sv, uint32_t v) -> uint32_t {
+        const uint32_t x = sa ^ sv;
+        if (x) {
+            const int k8 = (__builtin_ctz(x) >> 3) << 3;   // first reference they leave at different positions
+            const uint32_t pa = (sa >> k8) & 0xFFu, pv = (sv >> k8) & 0xFFu;
+            return pa < pv ? pa : pv;
+        }
+        if (wa == v) return (uint32_t)s_len[v];   // a leaf and its own word: every lane meets that once, each at another step
+        return (uint32_t)d_lcp16(ch + ((uint32_t)s_loff[wa] << 4), (int)s_len[wa], ch + ((uint32_t)s_loff[v] << 4), (int)s_len[v]);
+    };
     // ---- DFS order ---------------------------------------------------------------------------------------------------
+    // T[a][b] = first word that shares more than LCP(a, b) characters with leaf a (that word made the trie node where the
+    // branch of a starts below the node where a and b part); b is visited before a iff T[b][a] < T[a][b] (children in
+    // insertion order).  One wave per leaf: lanes over the words put their index at depth LCP - 1 (atomicMin), a suffix
+    // minimum over the depths gives the first word for every prefix of the leaf.
     {
         uint8_t *T = smem + X;
         uint32_t *tmin = reinterpret_cast<uint32_t *>(smem + X + SJ_A16(NL * NL)) + (uint32_t)wave * maxlen;
         for (uint32_t a = wave; a < NL; a += SJ_THREADS / 64) {
-            const uint32_t wa = s_leafw[a];
+            const uint32_t wa = s_leafw[a], sa = s_sig[wa];
             const int la = (int)s_len[wa];
             for (int d = lane; d < la; d += 64) tmin[d] = 0xFFFFFFFFu;
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-            for (uint32_t v = lane; v < R; v += 64) { const uint32_t l = M[a * R + v]; if (l > 0) atomicMin(&tmin[l - 1], v); }
+            for (uint32_t v = lane; v < R; v += 64) { const uint32_t l = wlcp(sa, wa, s_sig[v], v); if (l > 0) atomicMin(&tmin[l - 1], v); }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
             const int per = (la + 63) >> 6, d0 = lane * per;
             uint32_t mine = 0xFFFFFFFFu;
@@ -1269,7 +1344,10 @@ __global__ __launch_bounds__(SJ_THREADS) void k_job_small(DevParams P, Words W, 
             if (lane == 63) m = 0xFFFFFFFFu;
             for (int d = d0 + per - 1; d >= d0; d--) if (d < la) { const uint32_t v = tmin[d]; if (v < m) m = v; tmin[d] = m; }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-            for (uint32_t b = lane; b < NL; b += 64) T[a * NL + b] = b == a ? (uint8_t)0 : (uint8_t)tmin[M[a * R + s_leafw[b]]];
+            for (uint32_t b = lane; b < NL; b += 64) {
+                const uint32_t wb = s_leafw[b];
+                T[a * NL + b] = b == a ? (uint8_t)0 : (uint8_t)tmin[wlcp(sa, wa, s_sig[wb], wb)];
+            }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
         }
         __syncthreads();
@@ -1279,6 +1357,7 @@ __global__ __launch_bounds__(SJ_THREADS) void k_job_small(DevParams P, Words W, 
             s_rank[tid] = (uint16_t)rk;
         }
     }
+    SJ_T(3);   // DFS order
     // ---- clusters ------------------------------------------------------------------------------------------------------
     // one round: up to 4 pattern leaves (plist[p0 ..] or p0 .. when plist is null) against the partners `mode` names
     uint32_t giant = 0;
@@ -1301,7 +1380,9 @@ __global__ __launch_bounds__(SJ_THREADS) void k_job_small(DevParams P, Words W, 
             }
             const uint32_t wa = s_leafw[a], wb = s_leafw[b];
             const int la = (int)s_len[wa], lb = (int)s_len[wb], m = la < lb ? la : lb;
-            const int d = d_myers_le4(peq + pi * needmax * 16, (m + 63) >> 6, ch + ((uint32_t)s_loff[wb] << 4), m);
+            const uint8_t *tb = ch + ((uint32_t)s_loff[wb] << 4);
+            int d = d_hamming16(ch + ((uint32_t)s_loff[wa] << 4), tb, m, m >> 2);
+            if (4 * d > m) d = d_myers_le4(peq + pi * needmax * 16, (m + 63) >> 6, tb, m);
             if (4 * d <= m) {   // similarity = 1 - d/m >= 0.75 (findflanks.py:1044-1048, quirk Q11)
                 atomicOr(&adj[a * NLW + (b >> 5)], 1u << (b & 31));
                 atomicOr(&adj[b * NLW + (a >> 5)], 1u << (a & 31));
@@ -1330,7 +1411,10 @@ __global__ __launch_bounds__(SJ_THREADS) void k_job_small(DevParams P, Words W, 
     };
     if (NL >= 2) {
         round(nullptr, 0, NL < N_PIVOTS ? NL : N_PIVOTS, 0);
+        __syncthreads();
+        SJ_T(4);   // pivot round
         components();
+        SJ_T(5);   // components
         // the largest component among those of the first leaves
         const uint32_t npv = NL < N_PIVOTS ? NL : N_PIVOTS;
         if (tid < N_PIVOTS) s_u[tid] = 0;
@@ -1353,7 +1437,10 @@ __global__ __launch_bounds__(SJ_THREADS) void k_job_small(DevParams P, Words W, 
         }
         if (n_out) {
             for (uint32_t p0 = 0; p0 < n_out; p0 += 4) round(s_list, p0, n_out - p0 < 4 ? n_out - p0 : 4, 1);
+            __syncthreads();
+            SJ_T(6);   // rounds of the leaves outside the giant component
             components();
+            SJ_T(7);
         }
     }
     __syncthreads();
@@ -1361,54 +1448,93 @@ __global__ __launch_bounds__(SJ_THREADS) void k_job_small(DevParams P, Words W, 
         bool any = false;
         for (uint32_t x = 0; x < NLW; x++) if (adj[(uint32_t)tid * NLW + x]) { any = true; break; }
         s_hasm[tid] = any ? 1 : 0;
-        uint32_t share = 0;
-        const uint32_t wl = s_leafw[tid], lbl = s_label[tid];
-        for (uint32_t kp = 0; kp < (uint32_t)tid; kp++) if (s_label[kp] == lbl) { const uint32_t c = M[kp * R + wl]; if (c > share) share = c; }
-        s_share[tid] = (uint16_t)share;
     }
-    __syncthreads();
     // ---- vote, cluster by cluster; the best one so far is kept ------------------------------------------------------------
-    uint32_t *h = reinterpret_cast<uint32_t *>(smem + X);
-    const uint8_t *qbase = W.q + goff0;
+    // The sub-trie of a cluster holds the node of v[:d+1] iff some member leaf shares more than d characters with word v:
+    // reach(v) = max over the members a of M[a][v].  Word v then votes with q_v[d] under v[d] at every depth d < reach(v)
+    // and is counted iff it ends inside (reach(v) == len(v)).  A thread adds up one depth (two when words are longer than
+    // 128) over one half of the words, eight words per step (their reach and offsets are read together, then the sixteen
+    // bytes): A, C, G, T in two 64-bit registers of four 16-bit fields (sum of qualities <= 256 x 255, words <= 256),
+    // any other base code in an LDS table; the thread of the second half hands its registers over through LDS.
+    uint32_t *hx = reinterpret_cast<uint32_t *>(smem + X);
+    unsigned long long *part = reinterpret_cast<unsigned long long *>(smem + X + maxlen * 64);   // the registers of the second half of the threads
+    for (uint32_t i = tid; i < maxlen * 16; i += SJ_THREADS) hx[i] = 0;
+    if (tid == 0) s_other = 0;
     uint32_t npl = 0, npb = 0, best_key = 0;
     unsigned long long best_hi = 0;
     bool have = false;
-    const uint32_t nchunk = (R + 63) >> 6;
     const char codes[17] = "=ACMGRSVTWYHKDBN";
+    const uint32_t half = (uint32_t)tid >> 7, dl = (uint32_t)tid & 127u;
+    const uint32_t Rh = ((R >> 1) + 7u) & ~7u, vb = half ? Rh : 0u, ve = half ? R : (Rh < R ? Rh : R);
+    __syncthreads();
     for (uint32_t r = 0; r < NL; r++) {
         if (s_label[r] != r) continue;   // block-uniform
         const bool mem = (uint32_t)tid < NL && s_label[tid] == r;
         uint32_t nmem;
         {
             const uint32_t k = block_excl_scan(mem ? 1u : 0u, s_red, &nmem);
-            if (mem) s_list[k] = (uint16_t)tid;
+            if (mem) { const uint32_t wl = s_leafw[tid]; s_list[k] = (uint16_t)wl; s_usig[k] = s_sig[wl]; }   // the members' words and signatures
         }
         const uint32_t maxd = sj_block_max(mem ? (uint32_t)s_len[s_leafw[tid]] : 0u, s_red);
         const uint32_t minrank = 0xFFFFu - sj_block_max(mem ? 0xFFFFu - (uint32_t)s_rank[tid] : 0u, s_red);
-        for (uint32_t i = tid; i < maxd * 16; i += SJ_THREADS) h[i] = 0;
-        if (tid == 0) s_u[0] = maxd;
-        __syncthreads();
-        for (uint32_t it = wave; it < nmem * nchunk; it += SJ_THREADS / 64) {
-            const uint32_t a = s_list[it / nchunk], c = it % nchunk, v = c * 64 + lane, sh = s_share[a];
-            const uint32_t mv = v < R ? (uint32_t)M[a * R + v] : 0u;
-            unsigned long long mask = __ballot(mv > sh);
-            while (mask) {   // wave-uniform
-                const int vl = __builtin_ctzll(mask);
-                mask &= mask - 1;
-                const uint32_t Mv = __shfl(mv, vl, 64), vv = c * 64 + (uint32_t)vl, co = (uint32_t)s_loff[vv] << 4;
-                for (uint32_t d = sh + lane; d < Mv; d += 64) atomicAdd(&h[d * 16 + (ch[co + d] & 15)], (uint32_t)qbase[co + d] | 0x10000u);
-            }
-        }
         uint32_t ends = 0;
-        if ((uint32_t)tid < R)
-            for (uint32_t i = 0; i < nmem; i++) if ((uint32_t)M[(uint32_t)s_list[i] * R + tid] == (uint32_t)s_len[tid]) { ends = 1; break; }
-        const uint32_t words = sj_block_sum(ends, s_red);   // (its barriers also complete the vote)
-        for (uint32_t d = tid; d < maxd; d += SJ_THREADS) {
-            uint32_t tot = 0;
+        if ((uint32_t)tid < R) {
+            uint32_t rc = 0;
+            for (uint32_t i0 = 0; i0 < nmem; i0 += 4) {
+                const uint4 sg4 = *reinterpret_cast<const uint4 *>(&s_usig[i0]);
+                const uint32_t sg[4] = {sg4.x, sg4.y, sg4.z, sg4.w};
 #pragma unroll
-            for (int c = 0; c < 16; c++) tot += h[d * 16 + c] >> 16;
-            if ((int64_t)tot < (int64_t)P.mcc) atomicMin(&s_u[0], d);
+                for (int u = 0; u < 4; u++)
+                    if (i0 + u < nmem) { const uint32_t l = wlcp(sg[u], sg[u] == sig ? (uint32_t)s_list[i0 + u] : 0u, sig, (uint32_t)tid); if (l > rc) rc = l; }
+            }
+            s_wr[tid] = rc | ((uint32_t)s_loff[tid] << 8);
+            ends = rc == (uint32_t)mylen ? 1u : 0u;
         }
+        if ((uint32_t)tid < 8) s_wr[R + tid] = 0;   // the eight-word steps may look past the last word
+        if (tid == 0) s_u[0] = maxd;
+        const uint32_t words = sj_block_sum(ends, s_red);   // (its barriers also publish s_wr and s_u[0])
+        unsigned long long qa[2] = {0, 0}, ca[2] = {0, 0};
+        for (int t = 0; t < 2; t++) {
+            const uint32_t d = dl + 128u * t;
+            if (t && maxd <= 128) break;   // block-uniform
+            unsigned long long qacc = 0, cacc = 0;
+            if (d < maxd)
+                for (uint32_t v0 = vb; v0 < ve; v0 += 8) {
+                    const uint4 w0 = *reinterpret_cast<const uint4 *>(&s_wr[v0]), w1 = *reinterpret_cast<const uint4 *>(&s_wr[v0 + 4]);
+                    const uint32_t wr[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+                    uint32_t c[8], q[8];
+#pragma unroll
+                    for (int u = 0; u < 8; u++) {
+                        const bool act = (wr[u] & 0xFFu) > d && v0 + u < ve;
+                        const uint32_t co = act ? ((wr[u] >> 8) << 4) + d : 0u;
+                        c[u] = act ? (uint32_t)ch[co] & 15u : 16u;   // 16 = nothing to add
+                        q[u] = qs[co];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; u++) {
+                        const uint32_t cc = c[u];
+                        const bool pw2 = cc < 16u && cc && !(cc & (cc - 1));   // A C G T
+                        const int shf = (__builtin_ctz(cc | 16u) & 3) << 4;
+                        qacc += (unsigned long long)(pw2 ? q[u] : 0u) << shf;
+                        cacc += (unsigned long long)(pw2 ? 1u : 0u) << shf;
+                        if (cc < 16u && !pw2) { atomicAdd(&hx[d * 16 + cc], q[u] | 0x10000u); s_other = 1; }
+                    }
+                }
+            qa[t] = qacc; ca[t] = cacc;
+        }
+        if (half) { part[2 * tid - 256] = qa[0]; part[2 * tid - 255] = ca[0]; part[2 * tid] = qa[1]; part[2 * tid + 1] = ca[1]; }
+        __syncthreads();
+        const bool other = s_other != 0;
+        if (!half)
+            for (int t = 0; t < 2; t++) {
+                const uint32_t d = dl + 128u * t;
+                if (d >= maxd) break;
+                qa[t] += part[2 * tid + 256 * t]; ca[t] += part[2 * tid + 256 * t + 1];
+                uint32_t tot = (uint32_t)(ca[t] & 0xFFFF) + (uint32_t)((ca[t] >> 16) & 0xFFFF) + (uint32_t)((ca[t] >> 32) & 0xFFFF) + (uint32_t)(ca[t] >> 48);
+                if (other)
+                    for (int c = 0; c < 16; c++) tot += hx[d * 16 + c] >> 16;
+                if ((int64_t)tot < (int64_t)P.mcc) atomicMin(&s_u[0], d);
+            }
         __syncthreads();
         const uint32_t stop = s_u[0];
         const uint32_t key = ((s_hasm[r] ? 1u : 0u) << 31) | (minrank & 0x7fffffffu);
@@ -1419,21 +1545,36 @@ __global__ __launch_bounds__(SJ_THREADS) void k_job_small(DevParams P, Words W, 
                 const unsigned long long cand = ((unsigned long long)words << 32) | (unsigned long long)stop;
                 if (!have || cand > best_hi || (cand == best_hi && key > best_key)) {   // max by (count, len); ties: the last in list order
                     have = true; best_hi = cand; best_key = key;
-                    for (uint32_t d = tid; d < stop; d += SJ_THREADS) {
-                        int best = -1, nbest = 0;
-                        for (int c = 0; c < 16; c++) {
-                            const uint32_t x = h[d * 16 + c];
-                            if (!(x >> 16)) continue;
-                            if (best < 0 || (x & 0xFFFFu) > (h[d * 16 + best] & 0xFFFFu)) { best = c; nbest = 1; }
-                            else if ((x & 0xFFFFu) == (h[d * 16 + best] & 0xFFFFu)) nbest++;
+                    if (!half)
+                        for (int t = 0; t < 2; t++) {
+                            const uint32_t d = dl + 128u * t;
+                            if (d >= stop) break;
+                            int best = -1, nbest = 0;
+                            uint32_t bq = 0;
+                            for (int c = 0; c < 16; c++) {
+                                uint32_t xq, xc;
+                                if (c == 1 || c == 2 || c == 4 || c == 8) { const int shf = (__builtin_ctz((uint32_t)c) & 3) << 4; xq = (uint32_t)(qa[t] >> shf) & 0xFFFFu; xc = (uint32_t)(ca[t] >> shf) & 0xFFFFu; }
+                                else { const uint32_t x = other ? hx[d * 16 + c] : 0u; xq = x & 0xFFFFu; xc = x >> 16; }
+                                if (!xc) continue;
+                                if (best < 0 || xq > bq) { best = c; nbest = 1; bq = xq; }
+                                else if (xq == bq) nbest++;
+                            }
+                            bestc[d] = nbest > 1 ? 'N' : codes[best < 0 ? 15 : best];   // get_best_qual_chars flanktrie.py:344-353
                         }
-                        bestc[d] = nbest > 1 ? 'N' : codes[best < 0 ? 15 : best];   // get_best_qual_chars flanktrie.py:344-353
-                    }
                 }
             }
         }
         __syncthreads();
+        if (other) {   // block-uniform
+            for (uint32_t i = tid; i < maxd * 16; i += SJ_THREADS) hx[i] = 0;
+            if (tid == 0) s_other = 0;
+        }
+        __syncthreads();
     }
+    SJ_T(8);   // vote over all clusters
+#ifdef SJ_STAMP
+    if (tid == 0) { atomicAdd(&g_sj_cyc[12], 1ull); atomicAdd(&g_sj_cyc[13], (unsigned long long)NL); atomicAdd(&g_sj_cyc[14], (unsigned long long)npl | ((unsigned long long)R << 32)); }
+#endif
     if (tid == 0) {
         io.n_pass_len[job] = npl; io.n_pass_both[job] = npb;
         if (have) { io.cons_count[job] = (int32_t)(best_hi >> 32); io.cons_len[job] = (int32_t)(best_hi & 0xFFFFFFFFull); }
@@ -1518,7 +1659,7 @@ int run_consensus(mfk_ctx *ctx, const DevReads &R, const DevParams &P, Consensus
             hm.n_big = 1;
             HIPCHK(hipMemcpyAsync(J.Rbig, J.R, (size_t)J.n * 4, hipMemcpyDeviceToDevice, st));
         } else {
-            const uint32_t lds0 = 40 * 1024, lds1 = 128 * 1024;
+            const uint32_t lds0 = 48 * 1024, lds1 = 128 * 1024;
             if (!ctx->sj_attr) { HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_job_small), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1)); ctx->sj_attr = true; }
             PROF_LAUNCH(k_job_small, dim3(J.n), dim3(SJ_THREADS), lds0, st, P, W, J, io, meta, lds0, 0);
             KCHK();
