@@ -1,14 +1,26 @@
 """Multi-GPU layer: one process per GPU (torch.distributed; backend "nccl" is RCCL on ROCm, "gloo" in CPU tests).
 
 The path shards without any data-path collective: samples are independent (C4), contigs are
-independent (C3), and coordinate ranges of one contig are independent given a halo (C5).  The only exchange is the
-merge of the per-rank flank tables -- one all-gather of a few KB..MB of fixed-width records, latency-bound on xGMI.
+independent (C3), and coordinate ranges of one contig are independent given a halo (C5).  The only exchanges are the
+merges of the per-rank result tables -- an all-gather of a few KB..MB of fixed-width records after each stage,
+latency-bound on xGMI.
 
-* ``shard_samples``    round-robin assignment of isolates to ranks
-* ``shard_contigs``    greedy bin-packing of whole contigs by read count
-* ``coordinate_shards``/``slice_for_range``  read-balanced coordinate ranges of one contig with the halo that the
-  three chained min-distance filters need (3 x mindist + 3, not just one pairing window)
-* ``allgather_flanks`` the merge: every rank ends up with the concatenated table in rank order
+Partitioning
+* ``shard_samples``    round-robin assignment of isolates to ranks (``cohort.py`` runs a rank's isolates as one batch)
+* ``plan_shards``      what every rank OWNS and which reads it needs for that:
+    ``sharding="coordinate"``  cuts in BAM order balanced by read count; a rank owns the positions between two cuts
+                               (a cut inside a small contig moves to the contig's border) and computes ``halo`` positions
+                               beyond them: the three chained min-distance filters reach 3 x mindist + 3, not one window
+    ``sharding="contig"``      whole contigs, largest first into the least loaded rank
+
+Stages (the same functions run under RCCL, under gloo with the CPU oracle in tests/, and for K shards one after the other
+on a single GPU in the GPU suite):
+* ``shard_findflanks``   ``mfk_findflanks`` on the rank's reads -> the flank rows it owns
+* ``merge_flanks``       parts of all ranks -> the table of the unsharded run, byte for byte
+* ``shard_pairflanks``   ``mfk_pairflanks`` on the merged rows around the rank's range -> the pairs whose 5p flank it owns
+* ``merge_pairs``        parts of all ranks -> the pair table of the unsharded run
+* ``findflanks_sharded`` / ``pairflanks_sharded``  = stage + all-gather + merge for the calling rank
+* ``run_sharded_sequential``  all ranks of a world one after the other in this process (no collective)
 """
 from __future__ import annotations
 
@@ -21,7 +33,9 @@ def halo(min_distance_to_mate=22, max_direct_repeat_length=20):
     """Positions a shard must compute beyond the range it owns.  filter_softclips_mindistance runs three times
     (reference findflanks.py:40, 43, 49) and each round's verdict on a site depends on its neighbours' survival in the
     previous round, so the reach is 3 x mindist; pairing looks back maxdr + 1."""
-    return max(3 * min_distance_to_mate + 3, max_direct_repeat_length + 2)
+    # pairflanks on the owner of pos_5p: the spanning fetch starts at pos_3p - 1 >= pos_5p - maxdr - 2, the 50-bp
+    # direct-repeat window reaches 25 beyond the middle of the pair (pairflanks.py:294-305, 377)
+    return max(3 * min_distance_to_mate + 3, max_direct_repeat_length + 2, (max_direct_repeat_length + 1) // 2 + 27)
 
 
 def shard_samples(n_samples, world_size, rank):
@@ -54,12 +68,17 @@ def coordinate_shards(packed, contig, world_size):
 def slice_for_range(packed, contig, own, h, max_span=None):
     """Reads a shard needs to compute every site in [own[0]-h, own[1]+h): all reads that can overlap
     [a-h-1, b+h+2).  Returns a self-contained PackedReads (read indices renumbered)."""
+    lo, hi = _read_range(packed, contig, own, h, max_span)
+    return packed.slice_reads(lo, max(lo, hi))
+
+
+def _read_range(packed, contig, own, h, max_span=None):
     r0, r1 = int(packed.contig_read_start[contig]), int(packed.contig_read_start[contig + 1])
     span = packed.max_span if max_span is None else max_span
     starts = packed.ref_start[r0:r1]
     lo = r0 + int(np.searchsorted(starts, own[0] - h - 1 - span, side="left"))
     hi = r0 + int(np.searchsorted(starts, own[1] + h + 2, side="left"))
-    return packed.slice_reads(lo, max(lo, hi))
+    return lo, max(lo, hi)
 
 
 def owned(rows, own, contig=None):
@@ -70,6 +89,214 @@ def owned(rows, own, contig=None):
     return rows[m]
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# shard plans
+# ---------------------------------------------------------------------------------------------------------------------
+class ShardPlan:
+    """What one rank owns: ``pieces`` = [(contig, a, b)] owned site positions a <= pos < b (a site position runs from -1
+    to the contig length), ``ranges`` = the read index ranges it computes on (pieces + halo, merged, ascending)."""
+
+    def __init__(self, pieces, ranges):
+        self.pieces, self.ranges = list(pieces), list(ranges)
+
+    def n_reads(self):
+        return sum(hi - lo for lo, hi in self.ranges)
+
+    def owns(self, contig_id, pos):
+        """Boolean mask over arrays of contig ids and positions."""
+        contig_id, pos = np.asarray(contig_id), np.asarray(pos)
+        m = np.zeros(contig_id.shape, dtype=bool)
+        for c, a, b in self.pieces:
+            m |= (contig_id == c) & (pos >= a) & (pos < b)
+        return m
+
+    def __repr__(self):
+        return "ShardPlan(pieces=%r, ranges=%r)" % (self.pieces, self.ranges)
+
+
+def _merge_ranges(ranges):
+    out = []
+    for lo, hi in sorted(r for r in ranges if r[1] > r[0]):
+        if out and lo <= out[-1][1]:
+            out[-1] = (out[-1][0], max(out[-1][1], hi))
+        else:
+            out.append((lo, hi))
+    return out
+
+
+def plan_shards(packed, world_size, sharding="coordinate", h=None, small_contig_reads=None, cuts=None):
+    """One ShardPlan per rank.  Every (contig, position) is owned by exactly one rank, whatever the world size.
+
+    coordinate: cut k sits at read ``n k / world`` of the BAM order: (contig of that read, its reference start).  A cut
+    inside a contig with fewer than ``small_contig_reads`` reads (default: a quarter of a rank's share) moves to the nearer
+    border of that contig, so plasmids stay whole.  contig: whole contigs by ``shard_contigs``.  ``cuts``: the
+    world_size - 1 inner cuts of a coordinate plan given outright as ascending (contig, first owned position) pairs."""
+    if h is None:
+        h = halo()
+    n, nc = packed.n_reads, len(packed.contig_names)
+    crs = np.asarray(packed.contig_read_start, dtype=np.int64)
+    clen = np.asarray(packed.contig_len, dtype=np.int64)
+    if sharding == "contig":
+        bins = shard_contigs([int(crs[c + 1] - crs[c]) for c in range(nc)], world_size)
+        return [ShardPlan([(c, -1, int(clen[c]) + 1) for c in b], _merge_ranges([(int(crs[c]), int(crs[c + 1])) for c in b]))
+                for b in bins]
+    if sharding != "coordinate":
+        raise ValueError("sharding must be 'coordinate' or 'contig', not %r" % (sharding,))
+    if small_contig_reads is None:
+        small_contig_reads = max(n // (4 * world_size), 1)
+    given = cuts
+    cuts = [(0, -1)]                                       # (contig, first owned position)
+    if given is not None:
+        if len(given) != world_size - 1 or sorted(given) != list(given):
+            raise ValueError("cuts must be world_size - 1 ascending (contig, position) pairs")
+        cuts += [(int(c), int(p)) for c, p in given]
+    for k in range(1, world_size if given is None else 0):
+        r = n * k // world_size
+        if r >= n:
+            cuts.append((nc, -1))
+            continue
+        c = int(np.searchsorted(crs, r, side="right") - 1)
+        if crs[c + 1] - crs[c] < small_contig_reads:
+            cut = (c, -1) if r - crs[c] < crs[c + 1] - r else (c + 1, -1)
+        else:
+            cut = (c, int(packed.ref_start[r]))
+        cuts.append(max(cut, cuts[-1]))                    # cuts never go backwards
+    cuts.append((nc, -1))
+    plans = []
+    for k in range(world_size):
+        (c0, p0), (c1, p1) = cuts[k], cuts[k + 1]
+        pieces = []
+        for c in range(c0, min(c1, nc - 1) + 1):
+            a = p0 if c == c0 else -1
+            b = p1 if c == c1 else int(clen[c]) + 1
+            if c < nc and b > a:
+                pieces.append((c, a, b))
+        ranges = []
+        for c, a, b in pieces:
+            if a == -1 and b == int(clen[c]) + 1:
+                ranges.append((int(crs[c]), int(crs[c + 1])))
+            else:
+                ranges.append(_read_range(packed, c, (a, b), h))
+        plans.append(ShardPlan(pieces, _merge_ranges(ranges)))
+    return plans
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# stages
+# ---------------------------------------------------------------------------------------------------------------------
+def _compact(rows, blob, off_len_fields):
+    """Copy of ``rows`` whose strings lie in row order (fields in the given order inside a row) at the front of a fresh
+    blob, offsets re-based; a negative length (None) takes no bytes."""
+    rows = rows.copy()
+    n = len(rows)
+    if n == 0:
+        return rows, b""
+    lens = np.stack([np.maximum(rows[fl].astype(np.int64), 0) for _, fl in off_len_fields], 1).reshape(-1)
+    offs = np.stack([rows[fo].astype(np.int64) for fo, _ in off_len_fields], 1).reshape(-1)
+    new_off = np.concatenate([[0], np.cumsum(lens)])
+    total = int(new_off[-1])
+    src = np.frombuffer(bytes(blob), dtype=np.uint8)
+    out = src[np.repeat(offs - new_off[:-1], lens) + np.arange(total, dtype=np.int64)].tobytes() if total else b""
+    placed = new_off[:-1].reshape(n, len(off_len_fields))
+    for j, (fo, _) in enumerate(off_len_fields):
+        rows[fo] = placed[:, j]
+    return rows, out
+
+
+_FLANK_STR = (("seq_off", "seq_len"),)
+_PAIR_STR = (("ir5_off", "ir5_len"), ("ir3_off", "ir3_len"), ("dr_ref_off", "dr_ref_len"), ("dr_reads_off", "dr_len"))
+
+
+def shard_findflanks(binding, reads_struct, plan, params):
+    """Stage 1 of one rank: ``mfk_findflanks`` on the rank's reads, keep the flank rows the rank owns.
+    Returns (rows, seqs) with the sequences packed in row order."""
+    res = binding.run_findflanks(reads_struct, params)
+    fl = res["flanks"]
+    mine = fl[plan.owns(fl["contig_id"], fl["pos"])] if len(fl) else fl
+    return _compact(mine, res["seqs"], _FLANK_STR)
+
+
+def merge_flanks(parts):
+    """Per-rank (rows, seqs) -> the flank table of the unsharded run: contigs in BAM header order (first-seen order of a
+    sorted BAM, findflanks.py:640-666), positions ascending, 5p before 3p (kept from the rank that owns the position)."""
+    rows, blobs, off = [], [], 0
+    for r, b in parts:
+        r = np.array(r, dtype=_lib.FLANK_DTYPE, copy=True)
+        r["seq_off"] += off
+        off += len(b)
+        rows.append(r)
+        blobs.append(bytes(b))
+    tab = np.concatenate(rows) if rows else np.zeros(0, dtype=_lib.FLANK_DTYPE)
+    order = np.lexsort((tab["pos"], tab["contig_id"]))            # stable: the 5p / 3p order inside a position survives
+    return _compact(tab[order], b"".join(blobs), _FLANK_STR)
+
+
+def _flank_rows_for(plan, tab, reach):
+    """Rows of the merged flank table a rank hands to ``mfk_pairflanks``: on each contig it owns a piece of, every run of
+    flanks with gaps <= reach (= maxdr + 1: candidate pairs, and through shared flanks the greedy assignment, never cross a
+    wider gap, pairflanks.py:155-157, 229-245) that holds an owned position."""
+    keep = np.zeros(len(tab), dtype=bool)
+    if len(tab) == 0:
+        return np.zeros(0, dtype=np.int64)
+    cid, pos = tab["contig_id"], tab["pos"].astype(np.int64)
+    new_run = np.ones(len(tab), dtype=bool)
+    new_run[1:] = (cid[1:] != cid[:-1]) | (pos[1:] - pos[:-1] > reach)
+    run = np.cumsum(new_run) - 1
+    own = plan.owns(cid, pos)
+    keep = np.isin(run, np.unique(run[own]))
+    return np.flatnonzero(keep)
+
+
+def shard_pairflanks(binding, reads_struct, plan, params, tab, seqs, contig_rank, genome, genome_off):
+    """Stage 2 of one rank: ``mfk_pairflanks`` on the merged rows around the rank's range (its reads cover the spanning
+    fetches and direct-repeat windows of every pair whose 5p flank it owns: halo >= maxdr + 2 + half a window), keep those
+    pairs; flank indices are rows of the merged table (quirk P2).  Returns (rows, strs)."""
+    sel = _flank_rows_for(plan, tab, int(params.max_direct_repeat_length) + 1)
+    if len(sel) == 0:
+        return np.zeros(0, dtype=_lib.PAIR_DTYPE), b""
+    res = binding.run_pairflanks(reads_struct, params, tab[sel], seqs, contig_rank, genome, genome_off)
+    pr = res["pairs"]
+    mine = pr[plan.owns(pr["contig_id"], pr["pos_5p"])].copy() if len(pr) else pr
+    mine["index_5p"] = sel[mine["index_5p"]]
+    mine["index_3p"] = sel[mine["index_3p"]]
+    return _compact(mine, res["strs"], _PAIR_STR)
+
+
+def merge_pairs(parts, contig_rank):
+    """Per-rank (rows, strs) -> the pair table of the unsharded run: sorted by (contig name, pos_5p, pos_3p)
+    (pairflanks.py:248)."""
+    rows, blobs, off = [], [], 0
+    for r, b in parts:
+        r = np.array(r, dtype=_lib.PAIR_DTYPE, copy=True)
+        for fo, _ in _PAIR_STR:
+            r[fo] += off
+        off += len(b)
+        rows.append(r)
+        blobs.append(bytes(b))
+    tab = np.concatenate(rows) if rows else np.zeros(0, dtype=_lib.PAIR_DTYPE)
+    rank = np.asarray(contig_rank)[tab["contig_id"]] if len(tab) else np.zeros(0, np.int64)
+    order = np.lexsort((tab["pos_3p"], tab["pos_5p"], rank))
+    return _compact(tab[order], b"".join(blobs), _PAIR_STR)
+
+
+def run_sharded_sequential(binding, reads_of, packed, params, world_size, sharding, contig_rank, genome, genome_off,
+                           plans=None):
+    """Every rank of a ``world_size`` job one after the other in this process: the sharded path without a second GPU.
+    ``reads_of(PackedReads)`` gives the reads struct of ``binding`` (device tensors for HIP).  Returns
+    ((flank rows, seqs), (pair rows, strs), plans)."""
+    h = halo(params.min_distance_to_mate, params.max_direct_repeat_length)
+    if plans is None:
+        plans = plan_shards(packed, world_size, sharding, h)
+    structs = [reads_of(packed.take_ranges(p.ranges)) for p in plans]
+    tab, seqs = merge_flanks([shard_findflanks(binding, s, p, params) for s, p in zip(structs, plans)])
+    pairs = merge_pairs([shard_pairflanks(binding, s, p, params, tab, seqs, contig_rank, genome, genome_off)
+                         for s, p in zip(structs, plans)], contig_rank)
+    return (tab, seqs), pairs, plans
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the merge collective
+# ---------------------------------------------------------------------------------------------------------------------
 GATHER_CAP = 64 * 1024     # bytes per rank that travel in the first (normally only) collective
 
 
@@ -86,22 +313,22 @@ def _all_gather_bytes(mine, ws):
     return torch.stack(parts)
 
 
-def allgather_flanks(flanks, seqs, device=None, cap=GATHER_CAP):
-    """Merge per-rank flank tables (FLANK_DTYPE rows + their sequence bytes).  Returns (rows, seqs) with seq_off
-    rebased, ranks concatenated in rank order.  Works without torch.distributed initialised (single process).
+def allgather_records(rows, blob, device=None, cap=GATHER_CAP):
+    """All-gather of one table per rank (fixed-width rows + their string bytes) -> list over ranks of (rows, blob).
+    Without torch.distributed initialised (or with one rank) it is [(rows, blob)].
 
-    One collective in the common case: every rank sends a 16-byte header (row count, sequence bytes) followed by its
-    rows and sequences, padded to `cap` bytes.  Only if some rank's table is larger than `cap` does a second all-gather
+    One collective in the common case: every rank sends a 16-byte header (row count, string bytes) followed by its
+    rows and strings, padded to `cap` bytes.  Only if some rank's table is larger than `cap` does a second all-gather
     with the true maximum follow (all ranks see the same headers, so they agree on that without talking)."""
     import torch
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
-        return flanks, seqs
+        return [(rows, blob)]
     ws = dist.get_world_size()
     dev = device if device is not None else ("cuda" if dist.get_backend() == "nccl" else "cpu")
-    rec = _lib.FLANK_DTYPE.itemsize
-    body = np.ascontiguousarray(flanks).tobytes() + bytes(seqs)
-    head = np.array([flanks.shape[0], len(seqs)], dtype=np.int64).tobytes()
+    rec = rows.dtype.itemsize
+    body = np.ascontiguousarray(rows).tobytes() + bytes(blob)
+    head = np.array([rows.shape[0], len(blob)], dtype=np.int64).tobytes()
 
     def exchange(size):
         buf = np.zeros(16 + size, dtype=np.uint8)
@@ -115,13 +342,37 @@ def allgather_flanks(flanks, seqs, device=None, cap=GATHER_CAP):
     need = int((counts[:, 0] * rec + counts[:, 1]).max())
     if need > cap:
         got = exchange(need)
-    rows, blobs, off = [], [], 0
+    parts = []
     for r in range(ws):
         nr, nb = int(counts[r, 0]), int(counts[r, 1])
         g = got[r, 16:]
-        part = np.frombuffer(g[:nr * rec].tobytes(), dtype=_lib.FLANK_DTYPE).copy()
+        parts.append((np.frombuffer(g[:nr * rec].tobytes(), dtype=rows.dtype).copy(), g[nr * rec:nr * rec + nb].tobytes()))
+    return parts
+
+
+def allgather_flanks(flanks, seqs, device=None, cap=GATHER_CAP):
+    """Merge per-rank flank tables (FLANK_DTYPE rows + their sequence bytes).  Returns (rows, seqs) with seq_off
+    rebased, ranks concatenated in rank order.  Works without torch.distributed initialised (single process)."""
+    parts = allgather_records(flanks, seqs, device, cap)
+    if len(parts) == 1:
+        return parts[0]
+    rows, blobs, off = [], [], 0
+    for part, b in parts:
         part["seq_off"] += off
         rows.append(part)
-        blobs.append(g[nr * rec:nr * rec + nb].tobytes())
-        off += nb
-    return np.concatenate(rows) if rows else flanks, b"".join(blobs)
+        blobs.append(b)
+        off += len(b)
+    return np.concatenate(rows), b"".join(blobs)
+
+
+def findflanks_sharded(binding, reads_struct, plan, params, device=None, cap=GATHER_CAP):
+    """Stage 1 of the calling rank + the all-gather of the owned rows -> the merged flank table on every rank."""
+    rows, seqs = shard_findflanks(binding, reads_struct, plan, params)
+    return merge_flanks(allgather_records(rows, seqs, device, cap))
+
+
+def pairflanks_sharded(binding, reads_struct, plan, params, tab, seqs, contig_rank, genome, genome_off, device=None,
+                       cap=GATHER_CAP):
+    """Stage 2 of the calling rank + the all-gather of its pairs -> the merged pair table on every rank."""
+    rows, strs = shard_pairflanks(binding, reads_struct, plan, params, tab, seqs, contig_rank, genome, genome_off)
+    return merge_pairs(allgather_records(rows, strs, device, cap), contig_rank)

@@ -143,6 +143,49 @@ class PackedReads:
         out["pool_quals"] = a["pool_quals"][ob:o1].copy()
         return PackedReads(self.contig_names, out, self.max_span)
 
+    def take_ranges(self, ranges):
+        """Reads of several disjoint ascending index ranges [(lo, hi), ...] as one self-contained PackedReads (what a
+        rank holding several whole contigs, or the tail of one contig and the head of the next, computes on).  Links
+        that point outside the kept reads become -1."""
+        ranges = [(int(lo), int(hi)) for lo, hi in ranges if hi > lo]
+        if len(ranges) == 1:
+            return self.slice_reads(*ranges[0])
+        if not ranges:
+            return self.slice_reads(0, 0)
+        for (_, h0), (l1, _) in zip(ranges, ranges[1:]):
+            if l1 < h0:
+                raise ValueError("read ranges must be disjoint and ascending")
+        parts = [self.slice_reads(lo, hi) for lo, hi in ranges]
+        base = np.concatenate([[0], np.cumsum([p.n_reads for p in parts])]).astype(np.int64)
+        los = np.asarray([lo for lo, _ in ranges], dtype=np.int64)
+        his = np.asarray([hi for _, hi in ranges], dtype=np.int64)
+        a, out = self.a, {}
+        for k, _ in _HOT_FIELDS:
+            if k != "link":
+                out[k] = np.concatenate([p.a[k] for p in parts])
+        # a link may reach from one kept range into an earlier one: re-base it there instead of dropping it
+        link = np.concatenate([a["link"][lo:hi] for lo, hi in ranges]).astype(np.int64)
+        r = np.searchsorted(los, link, side="right") - 1
+        ok = (link >= 0) & (r >= 0)
+        ok &= link < his[np.maximum(r, 0)]
+        out["link"] = np.where(ok, link - los[np.maximum(r, 0)] + base[np.maximum(r, 0)], -1).astype(np.int32)
+        out["contig_len"] = a["contig_len"].copy()
+        # reads kept in front of a contig's start = sum over the parts of the reads each holds in front of it
+        out["contig_read_start"] = np.sum([p.a["contig_read_start"] for p in parts], axis=0).astype(np.int64)
+        out["cx_read"] = np.concatenate([p.a["cx_read"].astype(np.int64) + b for p, b in zip(parts, base[:-1])]).astype(np.uint32)
+        nblk = np.concatenate([[0], np.cumsum([p.a["blk_start"].shape[0] for p in parts])]).astype(np.int64)
+        out["cx_off"] = np.concatenate([p.a["cx_off"][:-1].astype(np.int64) + o for p, o in zip(parts, nblk[:-1])]
+                                       + [nblk[-1:]]).astype(np.uint32)
+        for k in ("blk_start", "blk_end", "blk_ins"):
+            out[k] = np.concatenate([p.a[k] for p in parts])
+        out["pool_read"] = np.concatenate([p.a["pool_read"].astype(np.int64) + b for p, b in zip(parts, base[:-1])]).astype(np.uint32)
+        nb = [int(p.a["pool_off"][-1]) for p in parts]          # even: every pooled read starts on a byte boundary
+        pbase = np.concatenate([[0], np.cumsum(nb)]).astype(np.uint64)
+        out["pool_off"] = np.concatenate([p.a["pool_off"][:-1] + o for p, o in zip(parts, pbase[:-1])] + [pbase[-1:]]).astype(np.uint64)
+        out["pool_bases"] = np.concatenate([p.a["pool_bases"][:n // 2] for p, n in zip(parts, nb)])
+        out["pool_quals"] = np.concatenate([p.a["pool_quals"][:n] for p, n in zip(parts, nb)])
+        return PackedReads(self.contig_names, out, self.max_span)
+
     def pool_sequence(self, read_idx):
         """(sequence str, qualities list) of a pooled read; host-side helper for tests."""
         from .records import BASE_CODES
