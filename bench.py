@@ -1,19 +1,28 @@
 #!/usr/bin/env python3
 """bench.py -- aligned reads/sec of the flank-discovery hot path (findflanks + pairflanks) on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--config NAME]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config NAME] [--sharding sample|coordinate|contig]
 
-A step is one pass of the hot path over one resident batch (``mfk_flankpairs``): ``mfk_findflanks`` (read scan -> sites -> filters -> site x read
-join -> consensus) followed by ``mfk_pairflanks`` (window join, inverted repeats, assignment, spanning reads, direct
+A step is one pass of the hot path over one resident batch: ``mfk_findflanks`` (read scan -> sites -> filters -> site x
+read join -> consensus) followed by ``mfk_pairflanks`` (window join, inverted repeats, assignment, spanning reads, direct
 repeats) on the packed alignments that already sit in HBM.  The workload is synthetic simulated-insertion alignments
-(mustache_amd/synth.py); the default is BASELINE.json configs[1], "S. aureus single isolate at 1000x" (2.8 Mb, 2x150 bp,
-18.7 M reads, 20 insertions).  With N > 1 every rank holds its own isolate of that size (sample sharding, weak scaling)
-and the per-rank flank tables are merged by one all-gather (RCCL) inside the step.
+(mustache_amd/synth.py, every read carrying its bases: nothing in the input uses the simulated truth); the default is
+BASELINE.json configs[1], "S. aureus single isolate at 1000x" (2.8 Mb, 2x150 bp, 18.7 M reads, 20 insertions).
 
-Prints ONE JSON line (rank 0): whole-job reads/s, the roofline of the dominant kernel (HIP-event timing inside the library,
-on the library's stream) and, at N = 1, the CPU port (oracle/mfk_oracle.c) timed on a bounded sample of the same workload.
+--sharding sample      (default) N > 1: every rank holds its own isolate (weak scaling; BASELINE configs[3] with
+                       --config C4_ecoli_batch: --isolates per GPU in one call); one all-gather of the flank tables per step
+--sharding coordinate  the ONE data set of --config cut into N read-balanced coordinate ranges with a halo (strong
+                       scaling; BASELINE configs[4] with --config C5_meta_50mb); mustache_amd/dist.py
+--sharding contig      whole contigs bin-packed over the ranks (strong scaling; BASELINE configs[2], C3_klebsiella)
+
+Prints ONE JSON line (rank 0): whole-job reads/s; `roofline` of the kernel that takes most device time (durations from
+HIP events inside the library on the stream of each launch, inside the timed region); and at N = 1 also
+`cpu_baseline` (the CPU port oracle/mfk_oracle.c on one core and on all cores, on a bounded sample), `parity_in_run`
+(sha256 of both TSVs, GPU vs CPU port, on that sample), `configs` (ms/step of the other BASELINE configs) and
+`end_to_end` (BAM file + FASTA on disk -> both TSVs through the drop-in stage drivers, host decode and PCIe included).
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -22,7 +31,15 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s is what a float4 copy reaches
+HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s is what a float4 copy reaches
+# vector-ALU issue peak: 256 CUs x 4 SIMDs x 32 lanes per cycle x 2.4 GHz (MI355X_MICROARCH.md: SIMD-32 units, a 64-lane
+# wave issues over 2 cycles; = half the 157.3 TFLOP/s fp32 FMA figure) in 10^12 32-bit lane-operations per second
+VALU_PEAK_TOPS = 256 * 4 * 32 * 2.4e9 / 1e12
+# VALU instructions one wave issues per unit of work, from the rocprofv3 SQ_INSTS_VALU pass of the same command
+# (profiles/r02_pmc_valu.json, scripts/pmc_table.py) divided by the work counter the kernel keeps (stats[12])
+VALU_MODELS_FILE = os.path.join(ROOT, "profiles", "r02_valu_models.json")
+PMC_TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+SCAN_KERNELS = ["k_scan_clips", "k_clip_events_bkt", "k_clip_events"]   # _bkt: bucketed path; plain: list + rocPRIM sort fallback
 
 
 def algorithmic_bytes(kernel, meta):
@@ -33,10 +50,10 @@ def algorithmic_bytes(kernel, meta):
     if kernel.startswith("k_clip_events"):
         return listed * (8 + 7) + ev * 8       # list entry + mapq, contig_id, one position column (7 B) + one key per event
     if kernel == "k_classify":
-        return meta["join_visits"] * 13        # ref_start, ref_end (8 B) + mapq, flags, link (5 B) per (site, read) visit
+        return meta["join_visits"] * 13        # ref_start, ref_end (8 B) + mapq, flags, link (5 B) per (site, read) visit (estimated count)
     if kernel.startswith("rocprim::radix_sort_keys") or kernel == "k_bucket_sort":
         return ev * 8 * 2                      # a sort has to read and write every key once
-    if kernel == "k_direct_repeats":
+    if kernel.startswith("k_direct_repeats"):
         # (150 x 1.5 + 8) B per read over a pair's 50-bp window; a window of W bp at coverage c sees c (150 + W) / 150 reads
         return int(meta["pairs"] * meta["coverage"] * (150 + 50) / 150 * (150 * 1.5 + 8))
     if kernel == "k_event_info":
@@ -44,16 +61,233 @@ def algorithmic_bytes(kernel, meta):
     return None
 
 
-def pmc_traffic(kernel, config):
-    """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/r01_pmc_traffic.json, made by
-    scripts/profile_round.sh + scripts/pmc_table.py from this same command), or None."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+def _json_file(path):
     try:
         with open(path) as fh:
-            tab = json.load(fh)
-        return tab.get(config, {}).get(kernel, {}).get("traffic_bytes")
+            return json.load(fh)
     except (OSError, ValueError):
+        return {}
+
+
+def kernel_entry(names, table, share, meta, config):
+    """Roofline object of one kernel (or of kernels that run once each per step, summed): HBM model where the kernel
+    streams, VALU model where it is an integer recurrence.  Work (bytes / operations) and time are both per step; a kernel
+    launched several times per step reports the sum of its launches against the sum of their durations."""
+    rows = [r for r in table if r[0] in names]
+    if not rows:
         return None
+    steps = max(meta["timed_steps"], 1)
+    ms = sum(r[3] for r in rows) / steps                                    # device ms per step of these kernels
+    launches = max(int(round(sum(r[2] for r in rows) / steps)), 1)
+    e = {"kernel": "+".join(r[0] for r in rows), "avg_ms": round(ms / launches, 5), "launches_per_step": launches,
+         "share_of_device_time": round(sum(share.get(r[0], 0.0) for r in rows), 3)}
+    ab = [algorithmic_bytes(r[0], meta) for r in rows]
+    traffic = _json_file(PMC_TRAFFIC_FILE).get(config, {})
+    tr = [traffic.get(r[0], {}).get("traffic_bytes") for r in rows]
+    valu = _json_file(VALU_MODELS_FILE)
+    m = valu.get(rows[0][0]) if len(rows) == 1 else None
+    if all(a is not None for a in ab):
+        ach = sum(ab) / (ms * 1e-3) / 1e9
+        e.update({"bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5),
+                  "algorithmic_bytes_per_step": sum(ab),
+                  "traffic": (sum(tr) if all(t is not None for t in tr) else None),
+                  "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, profiles/r02_pmc_traffic.json"})
+    elif m and meta["work"].get(m["work_counter"]):
+        units = meta["work"][m["work_counter"]]                               # per step, counted in this run
+        ops = units * m["valu_insts_per_unit"] * 64.0                         # lane-operations: 64 lanes per wave instruction
+        ach = ops / (ms * 1e-3) / 1e12
+        e.update({"bound": "valu", "achieved": round(ach, 3), "peak": round(VALU_PEAK_TOPS, 1), "unit": "Tlane-op/s",
+                  "frac": round(ach / VALU_PEAK_TOPS, 5), "work_units_per_step": units, "work_unit": m["unit"],
+                  "valu_insts_per_unit": m["valu_insts_per_unit"], "model_source": m.get("source"), "traffic": None,
+                  "note": m.get("note")})
+    else:
+        e.update({"bound": "valu", "achieved": None, "peak": round(VALU_PEAK_TOPS, 1), "unit": "Tlane-op/s", "frac": None, "traffic": None})
+    return e
+
+
+def sha(text):
+    return hashlib.sha256(text.encode() if isinstance(text, str) else bytes(text)).hexdigest()
+
+
+def tsv_texts(ff, pf, contig_names):
+    """Both result tables as the TSV text the stage drivers write (sample column = 'bench')."""
+    from mustache_amd.findflanks import flank_frame
+    from mustache_amd.pairflanks import pair_frame
+    a = flank_frame(ff, contig_names)
+    a.insert(0, "flank_id", list(a.index + 1)); a.insert(0, "sample", "bench")
+    b = pair_frame(pf, ff["flanks"], ff["seqs"], contig_names)
+    b.insert(0, "sample", "bench")
+    return a.to_csv(sep="\t", index=False), b.to_csv(sep="\t", index=False)
+
+
+# ---- CPU legs (before anything touches the GPU: the all-cores leg forks) ------------------------------------------------
+_cpu = {}
+
+
+def _cpu_stage1(k):
+    from mustache_amd import dist as md
+    plan = _cpu["plans"][k]
+    rd = _cpu["ora"].reads(_cpu["sample"].take_ranges(plan.ranges))
+    _cpu["rd"] = rd                      # a worker keeps its shard for stage 2 (imap with chunksize 1 and P workers: one shard each)
+    _cpu["k"] = k
+    return md.shard_findflanks(_cpu["ora"], rd, plan, _cpu["params"])
+
+
+def _cpu_stage2(args):
+    from mustache_amd import dist as md
+    k, tab, seqs = args
+    plan = _cpu["plans"][k]
+    rd = _cpu["rd"] if _cpu.get("k") == k else _cpu["ora"].reads(_cpu["sample"].take_ranges(plan.ranges))
+    return md.shard_pairflanks(_cpu["ora"], rd, plan, _cpu["params"], tab, seqs, _cpu["ranks"], _cpu["g"], _cpu["goff"])
+
+
+def cpu_legs(packed, genome, truth, params, n_insertions, cores):
+    """The CPU port (oracle) on a bounded sample: the reads of the first `n_insertions` insertion sites' stretch of the
+    genome.  One core like the reference (single-threaded Python), then all cores over coordinate shards of the sample
+    (the same shard plans and merges the GPUs use).  Returns (cpu_baseline object, sample, TSV hashes of the CPU result)."""
+    import multiprocessing as mp
+    import numpy as np
+    from mustache_amd import dist as md, pairflanks as pfh
+    from oracle.oracle import Oracle
+    ora = Oracle()
+    pos = sorted(t[1] for t in truth if t[0] == packed.contig_names[0])
+    cut = pos[min(n_insertions, len(pos)) - 1] + 2000 if pos else int(packed.contig_len[0])
+    hi = int(np.searchsorted(packed.ref_start[:int(packed.contig_read_start[1])], cut))
+    sub = packed.slice_reads(0, hi)
+    R = ora.reads(sub)
+    g, goff = pfh.genome_arrays(genome, packed.contig_names)
+    ranks = pfh.contig_ranks(packed.contig_names)
+    t0 = time.perf_counter()
+    ff = ora.run_findflanks(R, params)
+    pf = ora.run_pairflanks(R, params, ff["flanks"], ff["seqs"], ranks, g, goff)
+    dt1 = time.perf_counter() - t0
+    texts = tsv_texts(ff, pf, packed.contig_names)
+    out = {"value": round(sub.n_reads / dt1, 1), "unit": "reads/s", "cores": 1, "kind": "port",
+           "sample": "first %d reads (%d insertion sites, %.1f%% of the workload), findflanks+pairflanks in %.2f s"
+                     % (sub.n_reads, min(n_insertions, len(pos)), 100.0 * sub.n_reads / packed.n_reads, dt1)}
+    if cores > 1:
+        h = md.halo(params.min_distance_to_mate, params.max_direct_repeat_length)
+        _cpu.update(ora=ora, sample=sub, params=params, ranks=ranks, g=g, goff=goff, plans=md.plan_shards(sub, cores, "coordinate", h))
+        t0 = time.perf_counter()
+        with mp.get_context("fork").Pool(cores) as pool:
+            tab, seqs = md.merge_flanks(list(pool.imap(_cpu_stage1, range(cores), chunksize=1)))
+            pairs, strs = md.merge_pairs(list(pool.imap(_cpu_stage2, [(k, tab, seqs) for k in range(cores)], chunksize=1)), ranks)
+        dtn = time.perf_counter() - t0
+        wp, ws = md._compact(pf["pairs"], pf["strs"], md._PAIR_STR)
+        same = tab.tobytes() == ff["flanks"].tobytes() and seqs == ff["seqs"] and pairs.tobytes() == wp.tobytes() and strs == ws
+        out["all_cores"] = {"value": round(sub.n_reads / dtn, 1), "unit": "reads/s", "cores": cores, "seconds": round(dtn, 2),
+                            "sharding": "coordinate ranges of the sample, one process per core (fork), slicing and merges included",
+                            "tables_equal_one_core": bool(same)}
+        _cpu.clear()
+    return out, sub, {"findflanks_tsv_sha256": sha(texts[0]), "pairflanks_tsv_sha256": sha(texts[1]),
+                      "flank_rows": int(len(ff["flanks"])), "pairs": int(len(pf["pairs"]))}
+
+
+# ---- other configs, end to end -----------------------------------------------------------------------------------------
+def make_workload(name, seed, pool, isolates=12, rank=0):
+    """(packed, genome bytes, genome offsets, contig ranks, cfg, truth, batch or None, per-isolate inputs for the CPU leg)."""
+    from mustache_amd import cohort, pairflanks as pfh
+    from mustache_amd.synth import CONFIGS, synth_packed
+    if name == "C4_ecoli_batch":
+        # BASELINE configs[3]: a batch of E. coli isolates per GPU (96 over the 8 GPUs of a node), run as ONE call per stage
+        cfg = dict(CONFIGS["C1_ecoli_100x"])
+        packs, genomes, truths = [], [], []
+        for i in range(isolates):
+            p_, g_, t_ = synth_packed(**cfg, seed=1000 * (rank + 1) + i, pool=pool)
+            packs.append(p_); genomes.append(g_); truths.append(t_)
+        batch = cohort.concat_samples(packs, ["isolate%d" % (rank * isolates + i) for i in range(isolates)])
+        g, goff = cohort.batch_genome(batch, genomes)
+        return (batch.packed, g, goff, cohort.batch_contig_ranks(batch), cfg, [t for ts in truths for t in ts], batch,
+                (packs[0], genomes[0], truths[0]))
+    cfg = dict(CONFIGS[name])
+    packed, genome, truth = synth_packed(**cfg, seed=seed, pool=pool)
+    g, goff = pfh.genome_arrays(genome, packed.contig_names)
+    return packed, g, goff, pfh.contig_ranks(packed.contig_names), cfg, truth, None, (packed, genome, truth)
+
+
+def time_config(hip, name, pool, device, steps=5, warmup=2, isolates=12):
+    """ms/step of one more BASELINE config on this GPU (resident inputs, the fused call), for the `configs` table."""
+    import torch
+    from mustache_amd import lib
+    from mustache_amd.findflanks import device_reads
+    t0 = time.time()
+    packed, g, goff, ranks, cfg, truth, batch, _ = make_workload(name, 100, pool, isolates)
+    gen_s = time.time() - t0
+    reads = device_reads(hip, packed, device)
+    g_dev = torch.from_numpy(g).to(device)
+    params = lib.make_params()
+    for _ in range(warmup):
+        ff, pf = hip.run_flankpairs(reads, params, ranks, g_dev, goff)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    dev_ms = 0.0
+    for _ in range(steps):
+        ff, pf = hip.run_flankpairs(reads, params, ranks, g_dev, goff)
+        dev_ms += hip.device_ms()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    row = {"workload": name if batch is None else "%s (%d isolates in one call)" % (name, isolates), "reads": packed.n_reads,
+           "ms_per_step": round(dt / steps * 1e3, 4), "reads_per_s": round(packed.n_reads * steps / dt, 1), "steps": steps,
+           "pairflanks_device_ms": round(dev_ms / steps, 4), "insertions": len(truth), "flank_rows": int(len(ff["flanks"])),
+           "pairs": int(len(pf["pairs"])), "pool": pool, "generate_s": round(gen_s, 1)}
+    del reads, g_dev, packed
+    torch.cuda.empty_cache()
+    return row
+
+
+def end_to_end(n_records, tmp, device):
+    """BAM + FASTA on disk -> findflanks TSV -> pairflanks TSV through the drop-in stage drivers (`_findflanks`,
+    `_pairflanks`: multi-threaded BGZF decode + packing on the host, copies over PCIe, kernels, table assembly, to_csv).
+    The file is a simulated read set repeated on its own contigs per copy (mustache_amd/bigbam.py), so the expected tables
+    are the base set's tables repeated: checked."""
+    import pandas as pd
+    from mustache_amd import bamio, bigbam, lib
+    from mustache_amd.findflanks import _findflanks
+    from mustache_amd.pairflanks import _pairflanks
+    from mustache_amd.simulate import simulate_readset
+    genome, rs, truth = simulate_readset(seed=7, contig_lens=(60000, 8000), n_insertions=8, coverage=100)
+    copies = max(1, n_records // len(rs.reads))
+    bam, fa = os.path.join(tmp, "mfk_bench_e2e.bam"), os.path.join(tmp, "mfk_bench_e2e.fa")
+    one, tsv1, tsv2 = os.path.join(tmp, "mfk_bench_e2e_one.bam"), os.path.join(tmp, "mfk_bench_e2e.ff.tsv"), os.path.join(tmp, "mfk_bench_e2e.pf.tsv")
+    t0 = time.time()
+    contigs, n_rec = bigbam.write_replicated_bam(bam, rs, copies, procs=8)
+    bamio.write_fasta(fa, {n: genome[n.rsplit("_", 1)[0]] for n, _ in contigs})
+    bigbam.write_replicated_bam(one, rs, 1, procs=1)
+    bamio.write_fasta(one + ".fa", {n: genome[n.rsplit("_", 1)[0]] for n, _ in bigbam.replicated_contigs(rs.contigs, 1)})
+    write_s = time.time() - t0
+    d = lib.DEFAULT_PARAMS
+    ff_args = (d["min_softclip_length"], d["min_softclip_count"], d["min_alignment_quality"], d["min_alignment_inner_length"],
+               d["min_distance_to_mate"], d["min_softclip_ratio"], d["max_indel_ratio"], d["large_insertion_cutoff"], d["min_count_consensus"], "bench")
+    pf_args = (d["max_direct_repeat_length"], d["min_alignment_quality"], d["min_alignment_inner_length"], d["max_junction_spanning_prop"], d["large_insertion_cutoff"])
+    try:
+        # base set first (one copy): the expectation, and the warm-up of the library
+        _findflanks(one, *ff_args, output_file=tsv1, device=device, verbose=False)
+        _pairflanks(tsv1, one, one + ".fa", *pf_args, output_file=tsv2, device=device, verbose=False)
+        def base_table(path, id_col):      # the one-copy file names its contigs <name>_000000: back to <name>, then repeated per copy
+            t = pd.read_csv(path, sep="\t").drop(columns=[id_col])
+            t["contig"] = [str(c).rsplit("_", 1)[0] for c in t["contig"]]
+            return bigbam.replicate_table(t, copies)
+        want_ff, want_pf = base_table(tsv1, "flank_id"), base_table(tsv2, "pair_id")
+        t0 = time.perf_counter()
+        _findflanks(bam, *ff_args, output_file=tsv1, device=device, verbose=False)
+        t1 = time.perf_counter()
+        _pairflanks(tsv1, bam, fa, *pf_args, output_file=tsv2, device=device, verbose=False)
+        t2 = time.perf_counter()
+        got_ff = pd.read_csv(tsv1, sep="\t").drop(columns=["flank_id"])
+        got_pf = pd.read_csv(tsv2, sep="\t").drop(columns=["pair_id"])
+        ok = got_ff.to_csv(sep="\t", index=False) == want_ff.to_csv(sep="\t", index=False) and \
+            got_pf.to_csv(sep="\t", index=False) == want_pf.to_csv(sep="\t", index=False)
+        return {"records": n_rec, "bam_bytes": os.path.getsize(bam), "contigs": len(contigs), "flank_rows": int(len(got_ff)), "pairs": int(len(got_pf)),
+                "findflanks_s": round(t1 - t0, 3), "pairflanks_s": round(t2 - t1, 3),
+                "value": round(n_rec / (t2 - t0), 1), "unit": "reads/s",
+                "what": "BAM + FASTA files -> findflanks TSV -> pairflanks TSV (two BAM passes like the reference's two commands), host decode threads = %s" % os.environ.get("OMP_NUM_THREADS", "all"),
+                "tables_equal_base_repeated": bool(ok), "write_inputs_s": round(write_s, 1)}
+    finally:
+        for p in (bam, fa, one, one + ".fa", tsv1, tsv2):
+            try:
+                os.remove(p)
+            except OSError:
+                pass
 
 
 def main():
@@ -62,67 +296,83 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default="C2_saureus_1000x")
+    ap.add_argument("--sharding", default="sample", choices=["sample", "coordinate", "contig"])
+    ap.add_argument("--pool", default="all", choices=["all", "near"], help="'near' picks the pooled reads with the simulated truth (quicker to generate; not for reported numbers)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-insertions", type=int, default=20)
     ap.add_argument("--dump-profile", default=None, help="write the per-kernel table to this file")
     ap.add_argument("--isolates", type=int, default=12, help="isolates per GPU of --config C4_ecoli_batch (96 over 8 GPUs)")
+    ap.add_argument("--table-configs", default="C1_ecoli_100x,C3_klebsiella,C4_ecoli_batch,C5_meta_50mb",
+                    help="other configs measured for the `configs` table at N = 1 ('' = none)")
+    ap.add_argument("--end-to-end-reads", type=int, default=4_000_000, help="records of the BAM file of the end_to_end leg (0 = skip)")
+    ap.add_argument("--quick", action="store_true", help="only the timed region and the roofline (no CPU legs, no configs table, no end-to-end leg)")
     args = ap.parse_args()
+    if args.quick:
+        args.no_cpu_baseline, args.table_configs, args.end_to_end_reads = True, "", 0
 
     import numpy as np
-    import torch
-    import torch.distributed as dist
+    from mustache_amd import pairflanks as pfh
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    sharded = args.sharding != "sample"
+
+    from mustache_amd import lib
+    params = lib.make_params()
+    t0 = time.time()
+    # sample sharding: every rank its own data set; coordinate / contig sharding: every rank generates the SAME data set
+    # (there is no file to read it from) and keeps only its share
+    packed, g, goff, ranks, cfg, truth, batch, cpu_args = make_workload(args.config, 100 + (0 if sharded else rank), args.pool, args.isolates, rank)
+    gen_s = time.time() - t0
+    total_reads_here = packed.n_reads
+    n_insertions, contig_names = len(truth), list(packed.contig_names)
+    flags = packed.flags
+    clipped_reads = int(((flags & 15) != 0).sum())
+
+    # ---- CPU legs first: nothing has touched the GPU yet, so the all-cores leg may fork --------------------------------
+    cpu = sample = cpu_hashes = None
+    if world == 1 and not args.no_cpu_baseline:
+        cores = int(os.environ.get("OMP_NUM_THREADS") or 0) or min(os.cpu_count() or 1, 16)
+        cpu, sample, cpu_hashes = cpu_legs(cpu_args[0], cpu_args[1], cpu_args[2], params, args.cpu_sample_insertions, cores)
+        sample_g = pfh.genome_arrays(cpu_args[1], cpu_args[0].contig_names)
+
+    import torch
+    import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world)
     torch.cuda.set_device(local_rank)
     device = "cuda:%d" % local_rank
 
-    from mustache_amd import lib, pairflanks as pfh
-    from mustache_amd.dist import allgather_flanks
+    from mustache_amd import cohort, dist as mdist
     from mustache_amd.findflanks import device_reads
-    from mustache_amd.synth import CONFIGS, synth_packed
-
-    t0 = time.time()
-    batch = None
-    if args.config == "C4_ecoli_batch":
-        # BASELINE configs[3]: a batch of E. coli isolates per GPU (96 over the 8 GPUs of a node), run as ONE call per stage
-        # (mustache_amd/cohort.py); the per-rank candidate-site tables are merged by the all-gather
-        from mustache_amd import cohort
-        cfg = dict(CONFIGS["C1_ecoli_100x"])
-        packs, genomes, truths = [], [], []
-        for i in range(args.isolates):
-            p_, g_, t_ = synth_packed(**cfg, seed=1000 * (rank + 1) + i)
-            packs.append(p_); genomes.append(g_); truths.append(t_)
-        batch = cohort.concat_samples(packs, ["isolate%d" % (rank * args.isolates + i) for i in range(args.isolates)])
-        packed = batch.packed
-        truth = [t for ts in truths for t in ts]
-        g, goff = cohort.batch_genome(batch, genomes)
-        ranks = cohort.batch_contig_ranks(batch)
-        cpu_args = (packs[0], genomes[0], truths[0])
-    else:
-        cfg = dict(CONFIGS[args.config])
-        packed, genome, truth = synth_packed(**cfg, seed=100 + rank)
-        g, goff = pfh.genome_arrays(genome, packed.contig_names)
-        ranks = pfh.contig_ranks(packed.contig_names)
-        cpu_args = (packed, genome, truth)
-    gen_s = time.time() - t0
     hip = lib.load(local_rank)
-    params = lib.make_params()
-    reads = device_reads(hip, packed, device)
+    plan = None
+    if sharded:
+        h = mdist.halo(params.min_distance_to_mate, params.max_direct_repeat_length)
+        plan = mdist.plan_shards(packed, world, args.sharding, h)[rank]
+        mine = packed.take_ranges(plan.ranges)
+        reads = device_reads(hip, mine, device)
+        reads_here = mine.n_reads
+        del mine
+    else:
+        reads = device_reads(hip, packed, device)
+        reads_here = packed.n_reads
     g_dev = torch.from_numpy(g).to(device)
 
     def step():
+        if sharded:     # the rank's shard through both stages, each followed by the all-gather + merge of the owned rows
+            tab, seqs = mdist.findflanks_sharded(hip, reads, plan, params, device)
+            pairs, strs = mdist.pairflanks_sharded(hip, reads, plan, params, tab, seqs, ranks, g_dev, goff, device)
+            return {"flanks": tab, "seqs": seqs, "stats": np.zeros(16, np.int64)}, {"pairs": pairs, "strs": strs, "stats": np.zeros(16, np.int64)}
         ff, pf = hip.run_flankpairs(reads, params, ranks, g_dev, goff)   # mfk_findflanks then mfk_pairflanks inside one library call
         if batch is not None:
             per_sample = cohort.split_flanks(batch, ff)          # per-isolate tables, as the per-sample runs give them
             if world > 1:
                 cohort.cohort_table(per_sample, sample_numbers=[rank * args.isolates + i for i in range(args.isolates)], device=device)
         elif world > 1:
-            allgather_flanks(ff["flanks"], ff["seqs"], device)
+            mdist.allgather_flanks(ff["flanks"], ff["seqs"], device)
         return ff, pf
 
     for _ in range(args.warmup):
@@ -133,12 +383,13 @@ def main():
     for _ in range(warm_calls):
         ff, pf = step()
     full = hip.profile_totals()
-    scan_kernels = ["k_scan_clips", "k_clip_events_bkt", "k_clip_events"]   # _bkt: bucketed path; plain: list + rocPRIM sort fallback
-    watched = list(scan_kernels)
+    # work counters of one step, for the VALU models: kept by the kernels (stats[12]) or known from the tables
+    work = {"myers_limb_steps": int(hip.last_stats[12]), "candidate_pairs": int(hip.last_pair_stats[0]), "events": int(hip.last_stats[10])}
+    watched = list(SCAN_KERNELS)
     if full:
         watched.insert(0, max(full.items(), key=lambda kv: kv[1][0])[0])
     else:                                   # --warmup 0: no ranking yet, watch the usual suspects
-        watched = ["k_direct_repeats"] + watched
+        watched = ["k_leaf_myers"] + watched
 
     def barrier():
         if world > 1:
@@ -160,20 +411,19 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        nr = torch.tensor([packed.n_reads], dtype=torch.int64, device=device)
+        nr = torch.tensor([0 if sharded else packed.n_reads], dtype=torch.int64, device=device)
         dist.all_reduce(nr)
-        total_reads = int(nr.item())
+        total_reads = total_reads_here if sharded else int(nr.item())   # sharded: the ranks share ONE data set
     else:
-        total_reads = packed.n_reads
+        total_reads = total_reads_here
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = total_reads * args.steps / elapsed
-        flags = packed.flags
-        meta = {"n_reads": packed.n_reads, "clipped_reads": int(((flags & 15) != 0).sum()),
-                "events": int(ff["stats"][10]),
-                "join_visits": int(ff["stats"][3]) * 3 * int(cfg["coverage"]),
-                "pairs": int(pf["stats"][1]), "coverage": int(cfg["coverage"])}
+        st_ff, st_pf = hip.last_stats, hip.last_pair_stats
+        meta = {"n_reads": reads_here, "clipped_reads": clipped_reads if not sharded else clipped_reads // world, "events": int(st_ff[10]),
+                "join_visits": int(st_ff[3]) * 3 * int(cfg["coverage"]),       # an estimate: sites after the first neighbour filter x 3 positions x coverage
+                "pairs": int(st_pf[1]), "coverage": int(cfg["coverage"]), "timed_steps": args.steps, "work": work}
         # per-kernel rows (name, avg ms per launch, launches, total ms).  Shares and the device total come from the fully
         # bracketed warm-up steps; the durations of the watched kernels come from the timed region.
         full_table = sorted(((nm, ms / max(calls, 1), calls, ms) for nm, (ms, calls) in full.items()), key=lambda r: -r[3])
@@ -181,34 +431,21 @@ def main():
         share = {r[0]: r[3] / full_tot for r in full_table}
         dev_ms = full_tot / warm_calls if full_table else None
         table = sorted(((nm, ms / max(calls, 1), calls, ms) for nm, (ms, calls) in prof.items()), key=lambda r: -share.get(r[0], 0.0))
+        # `roofline` = the kernel with the largest share of device time (HBM model if it streams, VALU model if it is an
+        # integer recurrence); `read_scan` beside it = the two kernels that touch every read (the metric's unit)
         roofline = None
         if table:
-            def entry(names):
-                rows = [r for r in table if r[0] in names]
-                if not rows:
-                    return None
-                ms = sum(r[1] for r in rows)                       # one launch of each per step
-                ab = sum(algorithmic_bytes(r[0], meta) or 0 for r in rows)
-                tr = [pmc_traffic(r[0], args.config) for r in rows]
-                e = {"kernel": "+".join(r[0] for r in rows), "bound": "hbm", "avg_ms": round(ms, 5),
-                     "share_of_device_time": round(sum(share.get(r[0], 0.0) for r in rows), 3), "peak": HBM_PEAK_GBS, "unit": "GB/s"}
-                if ab:
-                    ach = ab / (ms * 1e-3) / 1e9
-                    e.update({"achieved": round(ach, 2), "frac": round(ach / HBM_PEAK_GBS, 5), "algorithmic_bytes": ab})
-                else:
-                    e.update({"achieved": None, "frac": None})
-                e["traffic"] = sum(tr) if all(t is not None for t in tr) else None
-                return e
-
-            # The roofline object is that of the read scan: the two kernels that process the metric's unit (every read) and
-            # carry the path's algorithmic bytes.  By TIME no kernel dominates this path at C2: the largest is ~10 % of the
-            # summed kernel time, the step is a chain of ~70 short launches on two streams, and the largest ones are
-            # per-site / per-pair latency chains (bit-vector edit distance, direct-repeat pile-up, inverted-repeat
-            # alignment) on a few dozen workgroups; `dominant_by_time` reports that kernel with a byte model where one exists.
-            roofline = entry(scan_kernels)
-            roofline["dominant_by_time"] = entry([table[0][0]])
-            roofline["top5_by_time"] = [{"kernel": r[0], "avg_ms": round(r[1], 5), "launches_per_step": r[2] // warm_calls,
-                                         "share": round(share[r[0]], 3)} for r in full_table[:5]]
+            roofline = kernel_entry([table[0][0]], table, share, meta, args.config)
+            scan = kernel_entry(SCAN_KERNELS, table, share, meta, args.config)
+            if roofline is None:
+                roofline = scan
+            if roofline is not None:
+                roofline["read_scan"] = scan
+                roofline["top5_by_time"] = [{"kernel": r[0], "avg_ms": round(r[1], 5), "launches_per_step": r[2] // warm_calls,
+                                             "share": round(share[r[0]], 3)} for r in full_table[:5]]
+                roofline["whole_step"] = {"algorithmic_bytes": int(reads_here * 1 + meta["clipped_reads"] * 23 + meta["events"] * 24),
+                                          "GBps": round((reads_here * 1 + meta["clipped_reads"] * 23 + meta["events"] * 24) / (ms_per_step * 1e-3) / 1e9, 1),
+                                          "note": "the step is a chain of dependent launches over a few dozen sites: launch- and latency-bound, not HBM-bound"}
         if args.dump_profile:
             with open(args.dump_profile, "w") as fh:
                 fh.write("# per-kernel HIP-event timing, every launch bracketed, over %d untimed steps after the warm-up (config %s)\n" % (warm_calls, args.config))
@@ -219,44 +456,45 @@ def main():
                 for nm, avg_ms, calls, tot in table:
                     fh.write("%-40s %10.5f %8d %12.4f\n" % (nm, avg_ms, calls, tot))
                 fh.write("device ms per step (sum of kernels, bracketed steps) %.4f, wall ms per step (timed) %.4f\n" % (dev_ms or 0.0, ms_per_step))
-        cpu = None
-        if world == 1 and not args.no_cpu_baseline:
-            cpu = cpu_baseline(cpu_args[0], cpu_args[1], cpu_args[2], params, args.cpu_sample_insertions)
         out = {"metric": "aligned reads/sec (findflanks+pairflanks, whole node)", "value": round(value, 1), "unit": "reads/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
-               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8/int32 (+f64 ratio tests)",
+               "higher_is_better": True, "scaling": "strong" if sharded else "weak", "vs_baseline": None, "dtype": "u8/int32 (+f64 ratio tests)",
                "data": "synthetic",
-               "config": {"workload": args.config, "reads_per_gpu": packed.n_reads, "genome_bp": int(sum(cfg["contig_lens"])) * (args.isolates if batch is not None else 1),
+               "config": {"workload": args.config, "reads_per_gpu": reads_here, "reads_total": total_reads,
+                          "genome_bp": int(sum(cfg["contig_lens"])) * (args.isolates if batch is not None else 1),
                           "isolates_per_gpu": args.isolates if batch is not None else 1,
-                          "coverage": cfg["coverage"], "read_length": 150, "insertions": len(truth),
-                          "flank_rows": int(len(ff["flanks"])), "pairs": int(len(pf["pairs"])), "sharding": "sample per GPU",
+                          "coverage": cfg["coverage"], "read_length": 150, "insertions": n_insertions,
+                          "flank_rows": int(len(ff["flanks"])), "pairs": int(len(pf["pairs"])),
+                          "sharding": {"sample": "sample per GPU", "coordinate": "coordinate ranges of one data set, halo 69", "contig": "whole contigs of one data set"}[args.sharding],
+                          "pool": "every read carries its bases (no use of the simulated truth)" if args.pool == "all" else "clipped reads + reads near the simulated insertions (uses the truth)",
                           "device_ms_per_step": round(dev_ms, 4) if dev_ms else None, "generate_s": round(gen_s, 1)},
                "roofline": roofline, "cpu_baseline": cpu}
+        if world == 1:
+            del reads
+            torch.cuda.empty_cache()
+            if sample is not None:
+                # the GPU on the CPU legs' sample: sha256 of both TSVs must agree with the CPU port's
+                rd = device_reads(hip, sample, device)
+                sg = torch.from_numpy(sample_g[0]).to(device)
+                sff, spf = hip.run_flankpairs(rd, params, pfh.contig_ranks(sample.contig_names), sg, sample_g[1])
+                texts = tsv_texts(sff, spf, sample.contig_names)
+                mine_h = {"findflanks_tsv_sha256": sha(texts[0]), "pairflanks_tsv_sha256": sha(texts[1])}
+                out["parity_in_run"] = {"sample": cpu["sample"].split(",")[0], "gpu": mine_h, "cpu_port": cpu_hashes,
+                                        "equal": all(mine_h[k] == cpu_hashes[k] for k in mine_h)}
+                del rd, sg
+                torch.cuda.empty_cache()
+            rows = []
+            for name in [c for c in args.table_configs.split(",") if c and c != args.config]:
+                rows.append(time_config(hip, name, args.pool, device, isolates=args.isolates))
+            if rows or args.table_configs:
+                me = {"workload": args.config, "reads": reads_here, "ms_per_step": round(ms_per_step, 4), "reads_per_s": round(value, 1),
+                      "steps": args.steps, "insertions": n_insertions, "flank_rows": int(len(ff["flanks"])), "pairs": int(len(pf["pairs"])), "pool": args.pool}
+                out["configs"] = [me] + rows
+            if args.end_to_end_reads > 0:
+                out["end_to_end"] = end_to_end(args.end_to_end_reads, os.environ.get("TMPDIR", "/tmp"), device)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
-
-
-def cpu_baseline(packed, genome, truth, params, n_insertions):
-    """The CPU port (oracle) on a bounded sample: the reads of the first `n_insertions` insertion sites' stretch of the
-    genome.  1 core, like the reference (single-threaded Python)."""
-    import numpy as np
-    from mustache_amd import pairflanks as pfh
-    from oracle.oracle import Oracle
-    ora = Oracle()
-    pos = sorted(t[1] for t in truth if t[0] == packed.contig_names[0])
-    cut = pos[min(n_insertions, len(pos)) - 1] + 2000 if pos else int(packed.contig_len[0])
-    hi = int(np.searchsorted(packed.ref_start[:int(packed.contig_read_start[1])], cut))
-    sub = packed.slice_reads(0, hi)
-    R = ora.reads(sub)
-    g, goff = pfh.genome_arrays(genome, packed.contig_names)
-    t0 = time.perf_counter()
-    ff = ora.run_findflanks(R, params)
-    ora.run_pairflanks(R, params, ff["flanks"], ff["seqs"], pfh.contig_ranks(packed.contig_names), g, goff)
-    dt = time.perf_counter() - t0
-    return {"value": round(sub.n_reads / dt, 1), "unit": "reads/s", "cores": 1, "kind": "port",
-            "sample": "first %d reads (%d insertion sites, %.1f%% of the workload), findflanks+pairflanks in %.2f s"
-                      % (sub.n_reads, min(n_insertions, len(pos)), 100.0 * sub.n_reads / packed.n_reads, dt)}
 
 
 if __name__ == "__main__":

@@ -139,7 +139,8 @@ enum {
 #define MFK_N_STATS 16
 /* stats[0..5]: sites remaining after parse, minlength, mincount, mindistance#1, ratios, mindistance#2;
  * stats[6..8]: consensus sequences after the minlength, mincount and best-of filters; stats[9]: sites after
- * mindistance#3; stats[10]: soft-clip events; stats[11]: flank rows. (the reference logs these, findflanks.py:144...) */
+ * mindistance#3; stats[10]: soft-clip events; stats[11]: flank rows. (the reference logs these, findflanks.py:144...)
+ * stats[12]: work counter for bench.py: columns x 64-bit limbs of the bit-vector edit-distance recurrences that ran. */
 
 typedef struct mfk_ctx mfk_ctx;
 

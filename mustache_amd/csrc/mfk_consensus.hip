@@ -706,9 +706,10 @@ __device__ __forceinline__ int d_myers_any(const uint64_t *peq, int need, const 
 // c*64 + l, + 64*n_chunks, ...  A site at 200x has a few dozen leaves and one chunk, a 1000x site hundreds of leaves in
 // up to 16 chunks: either way the GPU is filled with waves that each run one bit-vector recurrence, and nothing waits
 // at a barrier.
-__global__ __launch_bounds__(256) void k_leaf_myers(Words W, Jobs J, int mode, uint32_t n_chunks) {
+__global__ __launch_bounds__(256) void k_leaf_myers(Words W, Jobs J, int mode, uint32_t n_chunks, unsigned long long *work) {
     __shared__ uint64_t s_peq[4][8 * 16];   // per wave: Eq[limb][code] of its current pattern leaf
     const int lane = threadIdx.x & 63;
+    uint32_t limb_steps = 0;   // columns x limbs of the bit-vector recurrences this lane ran (bench.py: work counter of the VALU roofline)
     uint64_t *peq = s_peq[threadIdx.x >> 6];
     const uint32_t wpb = blockDim.x >> 6;   // waves per block: 1 in the pivot pass (every item on its own SIMD), 4 otherwise
     const uint32_t wave = blockIdx.x * wpb + (threadIdx.x >> 6), n_waves = gridDim.x * wpb;
@@ -745,13 +746,15 @@ __global__ __launch_bounds__(256) void k_leaf_myers(Words W, Jobs J, int mode, u
             const int m = la < lb ? la : lb;
             const uint8_t *tb = W.ch + W.off[wb];
             int d = d_hamming16(a, tb, m, m >> 2);
-            if (4 * d > m) d = d_myers_any(peq, need, tb, m);
+            if (4 * d > m) { d = d_myers_any(peq, need, tb, m); limb_steps += (uint32_t)(m * (need > 4 ? 8 : need)); }
             if (4 * d <= m) {   // similarity = 1 - d/m >= 0.75 (findflanks.py:1044-1048, quirk Q11)
                 atomicOr(&adj[(size_t)ka * rw + (kb >> 5)], 1u << (kb & 31));
                 atomicOr(&adj[(size_t)kb * rw + (ka >> 5)], 1u << (ka & 31));
             }
         }
     }
+    for (int o = 32; o > 0; o >>= 1) limb_steps += __shfl_xor(limb_steps, o, 64);
+    if (lane == 0 && limb_steps && work) atomicAdd(work, (unsigned long long)limb_steps);
 }
 
 // one block per job: connected components by label propagation over the adjacency bit matrix
@@ -1360,7 +1363,7 @@ __global__ __launch_bounds__(SJ_THREADS) void k_job_small(DevParams P, Words W, 
     SJ_T(3);   // DFS order
     // ---- clusters ------------------------------------------------------------------------------------------------------
     // one round: up to 4 pattern leaves (plist[p0 ..] or p0 .. when plist is null) against the partners `mode` names
-    uint32_t giant = 0;
+    uint32_t giant = 0, limb_steps = 0;
     auto round = [&](const uint16_t *plist, uint32_t p0, uint32_t np, int mode) {
         __syncthreads();   // the previous round's readers are done with the match vectors
         if ((uint32_t)wave < np) {
@@ -1382,7 +1385,7 @@ __global__ __launch_bounds__(SJ_THREADS) void k_job_small(DevParams P, Words W, 
             const int la = (int)s_len[wa], lb = (int)s_len[wb], m = la < lb ? la : lb;
             const uint8_t *tb = ch + ((uint32_t)s_loff[wb] << 4);
             int d = d_hamming16(ch + ((uint32_t)s_loff[wa] << 4), tb, m, m >> 2);
-            if (4 * d > m) d = d_myers_le4(peq + pi * needmax * 16, (m + 63) >> 6, tb, m);
+            if (4 * d > m) { d = d_myers_le4(peq + pi * needmax * 16, (m + 63) >> 6, tb, m); limb_steps += (uint32_t)(m * ((m + 63) >> 6)); }
             if (4 * d <= m) {   // similarity = 1 - d/m >= 0.75 (findflanks.py:1044-1048, quirk Q11)
                 atomicOr(&adj[a * NLW + (b >> 5)], 1u << (b & 31));
                 atomicOr(&adj[b * NLW + (a >> 5)], 1u << (a & 31));
@@ -1444,6 +1447,10 @@ __global__ __launch_bounds__(SJ_THREADS) void k_job_small(DevParams P, Words W, 
         }
     }
     __syncthreads();
+    if (io.work) {
+        for (int o2 = 32; o2 > 0; o2 >>= 1) limb_steps += __shfl_xor(limb_steps, o2, 64);
+        if (lane == 0 && limb_steps) atomicAdd(io.work, (unsigned long long)limb_steps);
+    }
     if ((uint32_t)tid < NL) {
         bool any = false;
         for (uint32_t x = 0; x < NLW; x++) if (adj[(uint32_t)tid * NLW + x]) { any = true; break; }
@@ -1716,15 +1723,15 @@ int run_consensus(mfk_ctx *ctx, const DevReads &R, const DevParams &P, Consensus
     // chain (B)
     if (W.my_list) {   // one wave per block: consecutive work items land on different CUs
         const unsigned g_my0 = (unsigned)(my_items < 8192 ? (my_items ? my_items : 1) : 8192);
-        PROF_LAUNCH(k_leaf_myers, dim3(g_my0), dim3(64), 0, sb, W, J, 0, n_chunks);
+        PROF_LAUNCH(k_leaf_myers, dim3(g_my0), dim3(64), 0, sb, W, J, 0, n_chunks, io.work);
     } else {
         const unsigned g_my0 = (unsigned)(my_items / 4 + 1 < 8192 ? my_items / 4 + 1 : 8192);
-        PROF_LAUNCH(k_leaf_myers, dim3(g_my0), dim3(256), 0, sb, W, J, 0, n_chunks);
+        PROF_LAUNCH(k_leaf_myers, dim3(g_my0), dim3(256), 0, sb, W, J, 0, n_chunks, io.work);
     }
     KCHK();
     PROF_LAUNCH(k_components, dim3(J.n), dim3(256), 0, sb, W, J, 0);
     KCHK();
-    PROF_LAUNCH(k_leaf_myers, dim3(g_leaf4), dim3(256), 0, sb, W, J, 1, n_chunks);
+    PROF_LAUNCH(k_leaf_myers, dim3(g_leaf4), dim3(256), 0, sb, W, J, 1, n_chunks, io.work);
     KCHK();
     PROF_LAUNCH(k_components, dim3(J.n), dim3(256), 0, sb, W, J, 1);
     KCHK();

@@ -813,6 +813,7 @@ extern "C" int mfk_findflanks(mfk_ctx *ctx, const mfk_reads *reads, const mfk_pa
             io.ev_keys = ev_sorted; io.ev_info = ev_info; io.n_events = E;
             io.n_act = n_act; io.act_site = A.site; io.act_st = A.st; io.act_cnt2 = A.cnt2;
             io.site_ev_begin = T.ev_begin; io.site_ev_mid = T.ev_mid; io.site_ev_end = T.ev_end;
+            io.work = reinterpret_cast<unsigned long long *>(d_stats + 12);   // 8-byte aligned: d_stats is an arena block
             if (int rc = run_consensus(ctx, R, P, io)) return rc;
             if (one_wg && stop_after >= MFK_STAGE_ALL) {
                 PROF_LAUNCH(k_consfilters_mindist, dim3(1), dim3(1024), 0, st, A, n_act, (const uint32_t *)io.n_pass_len, (const uint32_t *)io.n_pass_both, P.mindist, st2, d_stats);
@@ -854,6 +855,7 @@ extern "C" int mfk_findflanks(mfk_ctx *ctx, const mfk_reads *reads, const mfk_pa
         if (int rc = rb.flush()) return rc;
     }
     for (int i = 0; i < 10; i++) ctx->stats[i] = h_stats[i];
+    ctx->stats[12] = (int64_t)((uint64_t)h_stats[12] | ((uint64_t)h_stats[13] << 32));
     prof_collect(ctx);
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1) == hipSuccess) ctx->last_ms = ms;

@@ -134,5 +134,6 @@ struct ConsensusIO {
     int32_t *cons_count, *cons_len; uint32_t *n_pass_len, *n_pass_both;
     char *cons_chars; uint32_t cons_stride;
     const uint32_t *err_dev; uint32_t err_flags;   // device error word of the consensus stage, read back with the results
+    unsigned long long *work;                      // device counter: columns x limbs of the edit-distance recurrences run (stats[12])
 };
 int run_consensus(mfk_ctx *ctx, const DevReads &R, const DevParams &P, ConsensusIO &io);

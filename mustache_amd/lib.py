@@ -130,6 +130,7 @@ class Binding:
             f("profile_enable", C.c_int, [_p, C.c_int])
             f("profile_fetch", C.c_int, [_p, _p, C.c_int64, _p, _p, C.c_int64, C.POINTER(C.c_int64)])
             f("profile_select", C.c_int, [_p, C.c_char_p])
+        self.last_stats = self.last_pair_stats = np.zeros(N_STATS, dtype=np.int64)   # counters of the last compute call
         self.ctx = self.create(device_id)
         if not self.ctx:
             raise MfkError("%screate(%d) failed: no usable HIP device for %s" % (prefix, device_id, path))
@@ -186,6 +187,7 @@ class Binding:
         stats = np.zeros(N_STATS, dtype=np.int64)
         self._check(self.findflanks_fetch(self.ctx, sites.ctypes.data, flanks.ctypes.data, seqs.ctypes.data,
                                           stats.ctypes.data))
+        self.last_stats = stats
         return {"sites": sites, "flanks": flanks, "seqs": seqs[:sb.value].tobytes(), "stats": stats}
 
     def run_pairflanks(self, reads, params, flanks, flank_seqs, contig_rank, genome, genome_off):
@@ -202,6 +204,7 @@ class Binding:
         strs = np.zeros(max(sb.value, 1), dtype=np.uint8)
         stats = np.zeros(N_STATS, dtype=np.int64)
         self._check(self.pairflanks_fetch(self.ctx, pairs.ctypes.data, strs.ctypes.data, stats.ctypes.data))
+        self.last_pair_stats = stats
         return {"pairs": pairs, "strs": strs[:sb.value].tobytes(), "stats": stats}
 
     def run_flankpairs(self, reads, params, contig_rank, genome, genome_off):
@@ -221,6 +224,7 @@ class Binding:
         strs = np.zeros(max(pb.value, 1), dtype=np.uint8)
         pstats = np.zeros(N_STATS, dtype=np.int64)
         self._check(self.pairflanks_fetch(self.ctx, pairs.ctypes.data, strs.ctypes.data, pstats.ctypes.data))
+        self.last_stats, self.last_pair_stats = stats, pstats
         return ({"sites": sites, "flanks": flanks, "seqs": seqs[:sb.value].tobytes(), "stats": stats},
                 {"pairs": pairs, "strs": strs[:pb.value].tobytes(), "stats": pstats})
 
@@ -317,7 +321,8 @@ def host_header(packed):
             "n_cx": a["cx_read"].shape[0], "n_blk": a["blk_start"].shape[0], "n_pool": a["pool_read"].shape[0]}
 
 
-LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libmfk.so")
+# MFK_LIB_PATH: another build of the same library (diagnostic builds, e.g. `make SJ_STAMP=1`)
+LIB_PATH = os.environ.get("MFK_LIB_PATH") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libmfk.so")
 _loaded = {}
 
 

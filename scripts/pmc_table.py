@@ -1,10 +1,13 @@
-"""rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes -> profiles/rNN_pmc_traffic.json (bytes per launch and kernel).
+"""rocprofv3 --pmc passes -> profiles/rNN_pmc_traffic.json (HBM bytes per launch and kernel) and, with a third pass,
+profiles/rNN_pmc_valu.json (vector-ALU instructions per launch and kernel).
 
-    python scripts/pmc_table.py gpurun_out/round/pmc_fetch gpurun_out/round/pmc_write C2_saureus_1000x profiles/r01_pmc_traffic.json
+    python scripts/pmc_table.py FETCH_DIR WRITE_DIR CONFIG OUT_TRAFFIC.json [VALU_DIR OUT_VALU.json]
 
+Existing output files are updated (one entry per config), so several configs share a file.
 FETCH_SIZE / WRITE_SIZE are reported in KB per dispatch.  As /opt/skills/guides/MI355X_MICROARCH.md prescribes for gfx950,
 FETCH_SIZE is doubled for kernels whose loads are 16 bytes per lane (a 128-byte request is counted as one 64-byte unit):
 here that is the flags stream of k_scan_clips; the sparse gathers of the other kernels are taken as reported.
+SQ_INSTS_VALU counts wave instructions (x 64 lanes = lane-operations whatever the exec mask); SQ_WAVES the waves launched.
 """
 import csv
 import glob
@@ -14,14 +17,13 @@ import sys
 from collections import defaultdict
 
 WIDE_LOAD_KERNELS = ("k_scan_clips",)
-MODELLED = ("k_scan_clips", "k_clip_events_bkt", "k_clip_events", "k_bucket_sort", "k_event_info", "k_classify", "k_direct_repeats")
 
 
 def short(name):
     n = name.split("(")[0]
     if n.startswith("void "):
         n = n[5:]
-    return n
+    return n.split("<")[0] if n.startswith("k_scan_small") or n.startswith("k_scan_chain") else n
 
 
 def per_launch(directory, counter):
@@ -33,23 +35,39 @@ def per_launch(directory, counter):
                     k = short(r["Kernel_Name"])
                     tot[k] += float(r["Counter_Value"])
                     cnt[k] += 1
-    return {k: tot[k] / cnt[k] for k in tot}
+    return {k: tot[k] / cnt[k] for k in tot}, dict(cnt)
+
+
+def update(path, config, entry):
+    try:
+        with open(path) as fh:
+            tab = json.load(fh)
+    except (OSError, ValueError):
+        tab = {}
+    tab[config] = entry
+    with open(path, "w") as fh:
+        json.dump(tab, fh, indent=1, sort_keys=True)
 
 
 def main():
     fetch_dir, write_dir, config, out = sys.argv[1:5]
-    f, w = per_launch(fetch_dir, "FETCH_SIZE"), per_launch(write_dir, "WRITE_SIZE")
-    tab = {config: {}, "_all_kernels_kb_per_launch": {}}
+    (f, _), (w, _) = per_launch(fetch_dir, "FETCH_SIZE"), per_launch(write_dir, "WRITE_SIZE")
+    entry = {}
     for k in sorted(set(f) | set(w)):
-        tab["_all_kernels_kb_per_launch"][k] = {"fetch_size_kb": round(f.get(k, 0.0), 2), "write_size_kb": round(w.get(k, 0.0), 2)}
-    for k in MODELLED:
-        if k in f or k in w:
-            mult = 2.0 if k in WIDE_LOAD_KERNELS else 1.0
-            tab[config][k] = {"fetch_size_kb": round(f.get(k, 0.0), 2), "write_size_kb": round(w.get(k, 0.0), 2), "fetch_multiplier": mult,
-                              "traffic_bytes": int(round((f.get(k, 0.0) * mult + w.get(k, 0.0)) * 1024))}
-    with open(out, "w") as fh:
-        json.dump(tab, fh, indent=1)
-    print(json.dumps(tab[config], indent=1))
+        if not k.startswith("k_") and not k.startswith("rocprim"):
+            continue
+        mult = 2.0 if k in WIDE_LOAD_KERNELS else 1.0
+        entry[k] = {"fetch_size_kb": round(f.get(k, 0.0), 2), "write_size_kb": round(w.get(k, 0.0), 2), "fetch_multiplier": mult,
+                    "traffic_bytes": int(round((f.get(k, 0.0) * mult + w.get(k, 0.0)) * 1024))}
+    update(out, config, entry)
+    print(json.dumps({k: v["traffic_bytes"] for k, v in entry.items()}, indent=1))
+    if len(sys.argv) >= 7:
+        valu_dir, out_valu = sys.argv[5:7]
+        (v, calls), (wv, _) = per_launch(valu_dir, "SQ_INSTS_VALU"), per_launch(valu_dir, "SQ_WAVES")
+        entry = {k: {"valu_insts_per_launch": int(round(v[k])), "waves_per_launch": int(round(wv.get(k, 0))), "launches_seen": calls[k]}
+                 for k in sorted(v) if k.startswith("k_") or k.startswith("rocprim")}
+        update(out_valu, config, entry)
+        print(json.dumps({k: e["valu_insts_per_launch"] for k, e in entry.items()}, indent=1))
 
 
 if __name__ == "__main__":
