@@ -23,7 +23,7 @@ mfk_ctx *mfk_create(int device_id) {
     { const char *e0 = getenv("MFK_SCAN_EPOCH0"); ctx->scan_epoch = e0 ? (uint32_t)atoi(e0) & 0xFFFFu : 0u; }   // test hook: start near the wrap
     ctx->fill_stream = nullptr;
     ctx->na_pinned = nullptr;
-    ctx->sj_attr = false;
+    ctx->sj_attr = false; ctx->sj_static = 0;
     ctx->err[0] = 0;
     ctx->prof_on = false;
     ctx->prof_skip = false;

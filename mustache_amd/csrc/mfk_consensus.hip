@@ -1182,27 +1182,49 @@ __device__ __forceinline__ int d_myers_le4(const uint64_t *peq, int need, const 
     }
 }
 
+// maximum over the 64 lanes, every lane gets it: row-wise by DPP lane permutations (no LDS round trips as in __shfl_xor), then
+// lane 15 of a row to the next row (row_bcast:15, rows 1 and 3), lane 31 to the upper half (row_bcast:31); lane 63 holds the result
+__device__ __forceinline__ uint32_t d_wave_max(uint32_t v) {
+#define SJ_DPP(x, ctrl, rows) (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(x), ctrl, rows, 0xF, false)
+    uint32_t t;
+    t = SJ_DPP(v, 0xB1, 0xF); v = t > v ? t : v;     // quad_perm [1,0,3,2]
+    t = SJ_DPP(v, 0x4E, 0xF); v = t > v ? t : v;     // quad_perm [2,3,0,1]
+    t = SJ_DPP(v, 0x141, 0xF); v = t > v ? t : v;    // row_half_mirror
+    t = SJ_DPP(v, 0x140, 0xF); v = t > v ? t : v;    // row_mirror
+    t = SJ_DPP(v, 0x142, 0xA); v = t > v ? t : v;    // row_bcast:15
+    t = SJ_DPP(v, 0x143, 0xC); v = t > v ? t : v;    // row_bcast:31
+#undef SJ_DPP
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+
 #define SJ_A16(x) (((x) + 15u) & ~15u)
 // diagnostic build only (make SJ_STAMP=1): shader cycles of thread 0 between the phases of k_job_small, summed over the jobs
 #ifdef SJ_STAMP
-__device__ unsigned long long g_sj_cyc[16];
-#define SJ_T(i) do { if (tid == 0) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); atomicAdd(&g_sj_cyc[i], t_ - sj_last); sj_last = t_; } } while (0)
+__device__ unsigned long long g_sj_cyc[16], g_sj_need[40];   // g_sj_need: jobs by dynamic LDS need, 4 KB bins
+// kept in registers and added to the totals once, at the end of the kernel: an atomic per stamp would make the next barrier
+// wait for it (thousands of workgroups on one address) and charge that to the phase behind the stamp
+#define SJ_T(i) do { if (tid == 0) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); sj_acc[i] += t_ - sj_last; sj_last = t_; } } while (0)
 extern "C" int mfk_debug_sj(unsigned long long *out) {
     if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_sj_cyc), sizeof(unsigned long long) * 16) != hipSuccess) return 1;
-    unsigned long long z[16] = {0};
-    return hipMemcpyToSymbol(HIP_SYMBOL(g_sj_cyc), z, sizeof z) == hipSuccess ? 0 : 1;
+    if (hipMemcpyFromSymbol(out + 16, HIP_SYMBOL(g_sj_need), sizeof(unsigned long long) * 40) != hipSuccess) return 1;
+    unsigned long long z[40] = {0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_sj_need), z, sizeof z) != hipSuccess) return 1;
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_sj_cyc), z, sizeof(unsigned long long) * 16) == hipSuccess ? 0 : 1;
 }
 #else
 #define SJ_T(i) do { } while (0)
 #endif
 __global__ __launch_bounds__(SJ_THREADS) void k_job_small(DevParams P, Words W, Jobs J, ConsensusIO io, CMeta *meta, uint32_t lds_bytes, int pass) {
     extern __shared__ __align__(16) unsigned char smem[];
-    __shared__ uint16_t s_len[SJ_MAX_R], s_loff[SJ_MAX_R];            // word length; offset of its characters in units of 16 bytes
-    __shared__ uint16_t s_leafw[SJ_MAX_R], s_label[SJ_MAX_R], s_rank[SJ_MAX_R], s_list[SJ_MAX_R];
+    // static LDS is part of every workgroup's footprint (four workgroups per CU: 40 KB each): indices and lengths are bytes
+    // (at most SJ_MAX_R = 256 words of at most SJ_MAX_LEN = 255 characters)
+    __shared__ uint16_t s_loff[SJ_MAX_R];                               // offset of a word's characters in units of 16 bytes
+    __shared__ __align__(16) uint8_t s_leafw[SJ_MAX_R + 16];            // word of a leaf (read four at a time)
+    __shared__ uint8_t s_len[SJ_MAX_R], s_label[SJ_MAX_R], s_rank[SJ_MAX_R], s_list[SJ_MAX_R];
     __shared__ uint8_t s_hasm[SJ_MAX_R];
     __shared__ __align__(16) uint32_t s_sig[SJ_MAX_R], s_usig[SJ_MAX_R], s_wr[SJ_MAX_R + 8];   // signatures (leaves); reach | character offset << 8 of a word (vote)
     __shared__ uint32_t s_red[8], s_u[8];
-    __shared__ int s_changed, s_other;
+    __shared__ int s_changed, s_other;   // s_other: bit c = a base code c other than A, C, G, T takes part in the vote
     const uint32_t job = blockIdx.x;
     if (job >= J.n) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1224,6 +1246,7 @@ __global__ __launch_bounds__(SJ_THREADS) void k_job_small(DevParams P, Words W, 
     } while (0)
 #ifdef SJ_STAMP
     unsigned long long sj_last = __builtin_amdgcn_s_memtime();
+    unsigned long long sj_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #endif
     const uint32_t w0 = J.w0[job];
     const uint64_t goff0 = W.off[w0];
@@ -1231,17 +1254,17 @@ __global__ __launch_bounds__(SJ_THREADS) void k_job_small(DevParams P, Words W, 
     int mylen = 0;
     if ((uint32_t)tid < R) {
         mylen = (int)W.len[w0 + tid];
-        s_len[tid] = (uint16_t)mylen;
+        s_len[tid] = (uint8_t)mylen;   // a longer word makes the job fail just below
         s_loff[tid] = (uint16_t)((W.off[w0 + tid] - goff0) >> 4);
     }
     const uint32_t lkey = sj_block_max(((uint32_t)mylen << 16) | (0xFFFFu - (uint32_t)tid), s_red);   // longest word, the first of them
     const uint32_t maxlen = lkey >> 16;
     if (maxlen > SJ_MAX_LEN) SJ_FAIL(true);
-    if (2 * C + 4096u > lds_bytes) SJ_FAIL(false);
-    uint8_t *ch = smem, *qs = smem + SJ_A16(C);   // characters and qualities of the job's words
+    if (C + 4096u > lds_bytes) SJ_FAIL(false);
+    uint8_t *ch = smem;   // characters of the job's words (the qualities are read once, by the vote, straight from memory)
     {
-        const uint4 *src = reinterpret_cast<const uint4 *>(W.ch + goff0), *qsrc = reinterpret_cast<const uint4 *>(W.q + goff0);
-        for (uint32_t i = tid; i < (C >> 4); i += SJ_THREADS) { reinterpret_cast<uint4 *>(ch)[i] = src[i]; reinterpret_cast<uint4 *>(qs)[i] = qsrc[i]; }
+        const uint4 *src = reinterpret_cast<const uint4 *>(W.ch + goff0);
+        for (uint32_t i = tid; i < (C >> 4); i += SJ_THREADS) reinterpret_cast<uint4 *>(ch)[i] = src[i];
     }
     __syncthreads();
     SJ_T(0);   // load
@@ -1270,7 +1293,7 @@ __global__ __launch_bounds__(SJ_THREADS) void k_job_small(DevParams P, Words W, 
     uint32_t nU;
     {
         const uint32_t k = block_excl_scan(unsettled ? 1u : 0u, s_red, &nU);
-        if (unsettled) { s_list[k] = (uint16_t)tid; s_usig[k] = sig; }
+        if (unsettled) { s_list[k] = (uint8_t)tid; s_usig[k] = sig; }
     }
     __syncthreads();
     if (unsettled) {
@@ -1294,19 +1317,26 @@ __global__ __launch_bounds__(SJ_THREADS) void k_job_small(DevParams P, Words W, 
     uint32_t NL;
     {
         const uint32_t k = block_excl_scan(leaf ? 1u : 0u, s_red, &NL);   // (its first barrier also ends the reads of s_list)
-        if (leaf) { s_leafw[k] = (uint16_t)tid; s_label[k] = (uint16_t)k; }
+        if (leaf) { s_leafw[k] = (uint8_t)tid; s_label[k] = (uint8_t)k; }
     }
     // ---- LDS layout --------------------------------------------------------------------------------------------------
     const uint32_t NLW = (NL + 31) >> 5, needmax = (maxlen + 63) >> 6;
-    uint32_t o = 2 * SJ_A16(C);
+    uint32_t o = SJ_A16(C);
     uint32_t *adj = reinterpret_cast<uint32_t *>(smem + o); o += SJ_A16(NL * NLW * 4);
-    uint64_t *peq = reinterpret_cast<uint64_t *>(smem + o); o += 4 * needmax * 128;
     uint8_t *bestc = smem + o; o += SJ_A16(maxlen + 1);
-    const uint32_t X = o;   // first the DFS table (first[a][d], NL x Ls bytes), then the vote (rows of the rare base codes: maxlen x 16 words; 4 KB of partial sums)
+    const uint32_t RS = (R + 15u) & ~15u;
+    uint8_t *M = smem + o; o += NL * RS;   // M[a][v] = longest common prefix of leaf a and word v
+    // one region for three uses that follow each other: the match vectors of the edit-distance rounds (four pattern leaves), the
+    // DFS table when clusters tie (T[a][b], NL x NL bytes, and a row of first words per wave), 3 KB of partial sums of the vote
+    const uint32_t X = o;
+    uint64_t *peq = reinterpret_cast<uint64_t *>(smem + X);
     {
-        const uint32_t x1 = SJ_A16(NL * NL) + 4 * maxlen * 4, x2 = maxlen * 64 + 4096;
-        o += x1 > x2 ? x1 : x2;
+        const uint32_t x1 = SJ_A16(NL * NL) + 4 * maxlen * 4, x2 = 3072 + 64, x3 = 4 * needmax * 128;
+        o += x1 > x2 ? (x1 > x3 ? x1 : x3) : (x2 > x3 ? x2 : x3);
     }
+#ifdef SJ_STAMP
+    if (tid == 0) atomicAdd(&g_sj_need[(o >> 12) < 39 ? (o >> 12) : 39], 1ull);
+#endif
     if (o > lds_bytes) SJ_FAIL(false);
     for (uint32_t i = tid; i < NL * NLW; i += SJ_THREADS) adj[i] = 0;
     __syncthreads();
@@ -1323,12 +1353,12 @@ __global__ __launch_bounds__(SJ_THREADS) void k_job_small(DevParams P, Words W, 
         if (wa == v) return (uint32_t)s_len[v];   // a leaf and its own word: every lane meets that once, each at another step
         return (uint32_t)d_lcp16(ch + ((uint32_t)s_loff[wa] << 4), (int)s_len[wa], ch + ((uint32_t)s_loff[v] << 4), (int)s_len[v]);
     };
-    // ---- DFS order ---------------------------------------------------------------------------------------------------
+    // ---- DFS order (only when two clusters tie, see below) ---------------------------------------------------------------
     // T[a][b] = first word that shares more than LCP(a, b) characters with leaf a (that word made the trie node where the
     // branch of a starts below the node where a and b part); b is visited before a iff T[b][a] < T[a][b] (children in
     // insertion order).  One wave per leaf: lanes over the words put their index at depth LCP - 1 (atomicMin), a suffix
     // minimum over the depths gives the first word for every prefix of the leaf.
-    {
+    auto dfs_ranks = [&]() {
         uint8_t *T = smem + X;
         uint32_t *tmin = reinterpret_cast<uint32_t *>(smem + X + SJ_A16(NL * NL)) + (uint32_t)wave * maxlen;
         for (uint32_t a = wave; a < NL; a += SJ_THREADS / 64) {
@@ -1357,14 +1387,14 @@ __global__ __launch_bounds__(SJ_THREADS) void k_job_small(DevParams P, Words W, 
         if ((uint32_t)tid < NL) {
             uint32_t rk = 0;
             for (uint32_t b = 0; b < NL; b++) if (b != (uint32_t)tid && T[b * NL + tid] < T[(uint32_t)tid * NL + b]) rk++;
-            s_rank[tid] = (uint16_t)rk;
+            s_rank[tid] = (uint8_t)rk;
         }
-    }
-    SJ_T(3);   // DFS order
+        __syncthreads();
+    };
     // ---- clusters ------------------------------------------------------------------------------------------------------
     // one round: up to 4 pattern leaves (plist[p0 ..] or p0 .. when plist is null) against the partners `mode` names
     uint32_t giant = 0, limb_steps = 0;
-    auto round = [&](const uint16_t *plist, uint32_t p0, uint32_t np, int mode) {
+    auto round = [&](const uint8_t *plist, uint32_t p0, uint32_t np, int mode) {
         __syncthreads();   // the previous round's readers are done with the match vectors
         if ((uint32_t)wave < np) {
             const uint32_t a = plist ? plist[p0 + wave] : p0 + wave, wa = s_leafw[a];
@@ -1406,7 +1436,7 @@ __global__ __launch_bounds__(SJ_THREADS) void k_job_small(DevParams P, Words W, 
                 }
                 const uint32_t ll = s_label[l];
                 if (ll < l) l = ll;
-                if (l < l0) { s_label[tid] = (uint16_t)l; s_changed = 1; }
+                if (l < l0) { s_label[tid] = (uint8_t)l; s_changed = 1; }
             }
             __syncthreads();
             if (!s_changed) break;
@@ -1436,7 +1466,7 @@ __global__ __launch_bounds__(SJ_THREADS) void k_job_small(DevParams P, Words W, 
         {
             const bool out = (uint32_t)tid < NL && s_label[tid] != giant;
             const uint32_t k = block_excl_scan(out ? 1u : 0u, s_red, &n_out);
-            if (out) s_list[k] = (uint16_t)tid;
+            if (out) s_list[k] = (uint8_t)tid;
         }
         if (n_out) {
             for (uint32_t p0 = 0; p0 < n_out; p0 += 4) round(s_list, p0, n_out - p0 < 4 ? n_out - p0 : 4, 1);
@@ -1456,130 +1486,229 @@ __global__ __launch_bounds__(SJ_THREADS) void k_job_small(DevParams P, Words W, 
         for (uint32_t x = 0; x < NLW; x++) if (adj[(uint32_t)tid * NLW + x]) { any = true; break; }
         s_hasm[tid] = any ? 1 : 0;
     }
-    // ---- vote, cluster by cluster; the best one so far is kept ------------------------------------------------------------
-    // The sub-trie of a cluster holds the node of v[:d+1] iff some member leaf shares more than d characters with word v:
-    // reach(v) = max over the members a of M[a][v].  Word v then votes with q_v[d] under v[d] at every depth d < reach(v)
-    // and is counted iff it ends inside (reach(v) == len(v)).  A thread adds up one depth (two when words are longer than
-    // 128) over one half of the words, eight words per step (their reach and offsets are read together, then the sixteen
-    // bytes): A, C, G, T in two 64-bit registers of four 16-bit fields (sum of qualities <= 256 x 255, words <= 256),
-    // any other base code in an LDS table; the thread of the second half hands its registers over through LDS.
-    uint32_t *hx = reinterpret_cast<uint32_t *>(smem + X);
-    unsigned long long *part = reinterpret_cast<unsigned long long *>(smem + X + maxlen * 64);   // the registers of the second half of the threads
-    for (uint32_t i = tid; i < maxlen * 16; i += SJ_THREADS) hx[i] = 0;
-    if (tid == 0) s_other = 0;
-    uint32_t npl = 0, npb = 0, best_key = 0;
-    unsigned long long best_hi = 0;
-    bool have = false;
-    const char codes[17] = "=ACMGRSVTWYHKDBN";
-    const uint32_t half = (uint32_t)tid >> 7, dl = (uint32_t)tid & 127u;
-    const uint32_t Rh = ((R >> 1) + 7u) & ~7u, vb = half ? Rh : 0u, ve = half ? R : (Rh < R ? Rh : R);
+    // ---- M[a][v] = LCP(leaf a, word v): one thread per word, four leaves per step (their signatures settle nearly every pair) ----
+    if ((uint32_t)tid < NL) s_usig[tid] = s_sig[s_leafw[tid]];
     __syncthreads();
-    for (uint32_t r = 0; r < NL; r++) {
-        if (s_label[r] != r) continue;   // block-uniform
-        const bool mem = (uint32_t)tid < NL && s_label[tid] == r;
-        uint32_t nmem;
-        {
-            const uint32_t k = block_excl_scan(mem ? 1u : 0u, s_red, &nmem);
-            if (mem) { const uint32_t wl = s_leafw[tid]; s_list[k] = (uint16_t)wl; s_usig[k] = s_sig[wl]; }   // the members' words and signatures
-        }
-        const uint32_t maxd = sj_block_max(mem ? (uint32_t)s_len[s_leafw[tid]] : 0u, s_red);
-        const uint32_t minrank = 0xFFFFu - sj_block_max(mem ? 0xFFFFu - (uint32_t)s_rank[tid] : 0u, s_red);
-        uint32_t ends = 0;
-        if ((uint32_t)tid < R) {
-            uint32_t rc = 0;
-            for (uint32_t i0 = 0; i0 < nmem; i0 += 4) {
-                const uint4 sg4 = *reinterpret_cast<const uint4 *>(&s_usig[i0]);
-                const uint32_t sg[4] = {sg4.x, sg4.y, sg4.z, sg4.w};
+    SJ_T(11);
+    if ((uint32_t)tid < R)
+        for (uint32_t a0 = 0; a0 < NL; a0 += 4) {
+            const uint4 sg4 = *reinterpret_cast<const uint4 *>(&s_usig[a0]);
+            const uint32_t lw4 = *reinterpret_cast<const uint32_t *>(&s_leafw[a0]);
+            const uint32_t sg[4] = {sg4.x, sg4.y, sg4.z, sg4.w}, lw[4] = {lw4 & 0xFFu, (lw4 >> 8) & 0xFFu, (lw4 >> 16) & 0xFFu, lw4 >> 24};
+            uint32_t l[4];
+            bool slow = false;
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const uint32_t x = sg[u] ^ sig;
+                const int k8 = (__builtin_ctz(x | 0x80000000u) >> 3) << 3;   // first reference the two leave at different positions
+                const uint32_t pa = (sg[u] >> k8) & 0xFFu, pv = (sig >> k8) & 0xFFu;
+                l[u] = pa < pv ? pa : pv;
+                if (!x && a0 + u < NL) { l[u] = (uint32_t)mylen; slow = slow || lw[u] != (uint32_t)tid; }   // same four positions: the leaf's own word, or (rarely) a look at the characters
+            }
+            if (slow) {
 #pragma unroll
                 for (int u = 0; u < 4; u++)
-                    if (i0 + u < nmem) { const uint32_t l = wlcp(sg[u], sg[u] == sig ? (uint32_t)s_list[i0 + u] : 0u, sig, (uint32_t)tid); if (l > rc) rc = l; }
+                    if (sg[u] == sig && a0 + u < NL && lw[u] != (uint32_t)tid)
+                        l[u] = (uint32_t)d_lcp16(ch + ((uint32_t)s_loff[lw[u]] << 4), (int)s_len[lw[u]], mych, mylen);
             }
-            s_wr[tid] = rc | ((uint32_t)s_loff[tid] << 8);
-            ends = rc == (uint32_t)mylen ? 1u : 0u;
+#pragma unroll
+            for (int u = 0; u < 4; u++) if (a0 + u < NL) M[(a0 + u) * RS + (uint32_t)tid] = (uint8_t)l[u];
+        }
+    SJ_T(6);
+    // the cluster representatives, in leaf order
+    uint32_t nrep;
+    {
+        const bool rep = (uint32_t)tid < NL && s_label[tid] == (uint32_t)tid;
+        const uint32_t k = block_excl_scan(rep ? 1u : 0u, s_red, &nrep);   // (its barriers also publish M)
+        if (rep) s_list[k] = (uint8_t)tid;
+    }
+    __syncthreads();
+    SJ_T(2);   // LCP matrix
+    // ---- every cluster's merged count and consensus length, without a vote -------------------------------------------------
+    // The sub-trie of a cluster holds the node of v[:d+1] iff some member leaf shares more than d characters with word v:
+    // reach(v) = max over the members a of M[a][v].  Word v votes at every depth d < reach(v) and is counted iff it ends
+    // inside (reach(v) == len(v), make_subtrie flanktrie.py:89-118).  The voters of depth d are the words with reach > d, a
+    // number that only falls with d, so the consensus stops (fewer than mcc voters, flanktrie.py:325-326) at the mcc-th largest
+    // reach: count and length of EVERY cluster follow from the reach values alone, and only the cluster that wins
+    // (findflanks.py:241-346) needs its characters voted.  One wave per cluster, lanes over the words (up to four each);
+    // the members of a cluster are the set bits of a ballot over the leaves' labels, which every wave holds in registers.
+    uint32_t lab[4], lenv[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const uint32_t v = (uint32_t)lane + 64u * i;
+        lab[i] = v < NL ? (uint32_t)s_label[v] : 0xFFFFFFFFu;
+        lenv[i] = v < R ? (uint32_t)s_len[v] : 0xFFFFFFFFu;     // no reach equals it: not counted
+    }
+    const uint32_t nI = (R + 63u) >> 6;   // 64-word groups in use
+    // reach of the wave's words (lane + 64 i) for the cluster with label r
+    auto reach4 = [&](uint32_t r, uint32_t *rc, uint32_t *mlen, int only) {   // only >= 0: just that group of 64 words
+        rc[0] = rc[1] = rc[2] = rc[3] = 0;
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+            if (64u * g >= NL) break;   // wave-uniform
+            unsigned long long mask = __ballot(lab[g] == r);
+            while (mask) {   // wave-uniform; two members per step, their rows read together
+                const uint32_t a1 = 64u * g + (uint32_t)__builtin_ctzll(mask);
+                mask &= mask - 1ull;
+                uint32_t a2 = a1;
+                if (mask) { a2 = 64u * g + (uint32_t)__builtin_ctzll(mask); mask &= mask - 1ull; }
+                const uint8_t *m1 = M + a1 * RS + lane, *m2 = M + a2 * RS + lane;
+                uint32_t x1[4], x2[4];
+#pragma unroll
+                for (int i = 0; i < 4; i++) { const bool in = (uint32_t)i < nI && (only < 0 || only == i); x1[i] = in ? (uint32_t)m1[in ? 64 * i : 0] : 0u; x2[i] = in ? (uint32_t)m2[in ? 64 * i : 0] : 0u; }
+#pragma unroll
+                for (int i = 0; i < 4; i++) { const uint32_t x = x1[i] > x2[i] ? x1[i] : x2[i]; if (x > rc[i]) rc[i] = x; }
+                if (mlen) { const uint32_t l1 = s_len[s_leafw[a1]], l2 = s_len[s_leafw[a2]]; const uint32_t lm = l1 > l2 ? l1 : l2; if (lm > *mlen) *mlen = lm; }
+            }
+        }
+    };
+    for (uint32_t ir = wave; ir < nrep; ir += SJ_THREADS / 64) {
+        const uint32_t r = s_list[ir];
+        uint32_t rc[4], mlen = 0;
+        reach4(r, rc, P.mcc <= 0 ? &mlen : nullptr, -1);
+        uint32_t words = 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) words += (uint32_t)__popcll(__ballot(rc[i] == lenv[i]));
+        uint32_t stop;
+        if (P.mcc <= 0) stop = mlen;
+        else if ((uint32_t)P.mcc > R) stop = 0;
+        else {   // the mcc-th largest reach: take the largest away mcc - 1 times (entries taken away or beyond R count as 0, the smallest value)
+            uint32_t t4[4] = {rc[0], (uint32_t)lane + 64u < R ? rc[1] : 0u, (uint32_t)lane + 128u < R ? rc[2] : 0u, (uint32_t)lane + 192u < R ? rc[3] : 0u};
+            if ((uint32_t)lane >= R) t4[0] = 0;
+            for (int k = 1; k < P.mcc; k++) {
+                uint32_t m = t4[0] > t4[1] ? t4[0] : t4[1]; { const uint32_t m2 = t4[2] > t4[3] ? t4[2] : t4[3]; if (m2 > m) m = m2; }
+                const uint32_t wm = d_wave_max(m);
+                if (wm == 0) break;
+                const unsigned long long holders = __ballot(m == wm);
+                if (lane == __builtin_ctzll(holders)) { if (t4[0] == wm) t4[0] = 0; else if (t4[1] == wm) t4[1] = 0; else if (t4[2] == wm) t4[2] = 0; else t4[3] = 0; }
+            }
+            uint32_t m = t4[0] > t4[1] ? t4[0] : t4[1]; { const uint32_t m2 = t4[2] > t4[3] ? t4[2] : t4[3]; if (m2 > m) m = m2; }
+            stop = d_wave_max(m);
+        }
+        if (lane == 0) s_wr[r] = (words << 16) | stop;
+    }
+    __syncthreads();
+    SJ_T(3);   // summaries of all clusters
+    // ---- filters and the best cluster (max by (count, length), ties: the last in list order = the largest key) ----------------
+    uint32_t npl, npb, win = 0xFFFFFFFFu, win_words = 0, win_stop = 0;
+    {
+        const bool rep = (uint32_t)tid < NL && s_label[tid] == (uint32_t)tid;
+        const uint32_t sm = rep ? s_wr[tid] : 0u, words = sm >> 16, stop = sm & 0xFFFFu;
+        const bool pl = rep && (int32_t)stop >= P.minlen, pb = pl && (int32_t)words >= P.mincount;
+        const uint32_t cnt = sj_block_sum((pl ? 1u : 0u) | (pb ? 1u << 12 : 0u), s_red);
+        npl = cnt & 0xFFFu; npb = cnt >> 12;
+        if (npb) {   // block-uniform
+            const uint32_t pack = pb ? ((words << 9) | (stop << 1) | (s_hasm[tid] ? 1u : 0u)) + 1u : 0u;
+            const uint32_t top = sj_block_max(pack, s_red);
+            const uint32_t ntop = sj_block_sum(pack == top ? 1u : 0u, s_red);
+            if (ntop > 1) {
+                // several clusters with the winning (count, length) and the same kind (singleton / component): the reference
+                // keeps the last of them in its list order, i.e. the one whose first leaf comes last in the DFS (quirk Q12)
+                __syncthreads();
+                if ((uint32_t)tid < NL) s_wr[tid] = 0xFFFFFFFFu;
+#ifdef SJ_STAMP
+                if (tid == 0) atomicAdd(&g_sj_cyc[15], 1ull);
+#endif
+                dfs_ranks();
+                if ((uint32_t)tid < NL) atomicMin(&s_wr[s_label[tid]], (uint32_t)s_rank[tid]);
+                __syncthreads();
+                win = sj_block_max(pack == top ? ((s_wr[tid] << 8) | (uint32_t)tid) + 1u : 0u, s_red);
+                win = (win - 1u) & 0xFFu;
+            } else win = sj_block_max(pack == top ? (uint32_t)tid + 1u : 0u, s_red) - 1u;
+            win_words = (top - 1u) >> 9; win_stop = ((top - 1u) >> 1) & 0xFFu;
+        }
+    }
+    SJ_T(9);   // the choice (with the DFS order when clusters tie)
+    // ---- vote of the winning cluster --------------------------------------------------------------------------------------
+    // Word v votes with q_v[d] under v[d] at every depth d < min(reach(v), length).  A thread adds up ONE depth over one part
+    // of the words (a consensus of up to 64 characters: four parts; up to 128: two), eight words per step: their reach and
+    // offsets come together from LDS, then the eight characters (LDS) and the eight qualities (memory: a wave reads 64
+    // consecutive bytes of a word) are all fetched whether they count or not.  A, C, G, T go into two 64-bit registers of four
+    // 16-bit fields (sum of qualities <= 256 x 255, words <= 256); the threads of the other parts hand their registers over
+    // through LDS.  Any other base code (N, IUPAC) is rare: the depths that met one add those codes up in a pass of their own.
+    const bool have = win != 0xFFFFFFFFu;
+    const unsigned long long best_hi = ((unsigned long long)win_words << 32) | (unsigned long long)win_stop;
+    if (have && win_stop) {   // block-uniform
+        const uint32_t maxd = win_stop;
+        unsigned long long *part = reinterpret_cast<unsigned long long *>(smem + X);
+        __syncthreads();   // the DFS table (if it was needed) and the summaries are done with
+        {
+            uint32_t rc[4];
+            reach4(win, rc, nullptr, wave);   // every wave the group of words it publishes
+            const uint32_t mine = wave == 0 ? rc[0] : (wave == 1 ? rc[1] : (wave == 2 ? rc[2] : rc[3]));
+            if ((uint32_t)tid < R) s_wr[tid] = mine | ((uint32_t)s_loff[tid] << 8);
         }
         if ((uint32_t)tid < 8) s_wr[R + tid] = 0;   // the eight-word steps may look past the last word
-        if (tid == 0) s_u[0] = maxd;
-        const uint32_t words = sj_block_sum(ends, s_red);   // (its barriers also publish s_wr and s_u[0])
-        unsigned long long qa[2] = {0, 0}, ca[2] = {0, 0};
-        for (int t = 0; t < 2; t++) {
-            const uint32_t d = dl + 128u * t;
-            if (t && maxd <= 128) break;   // block-uniform
-            unsigned long long qacc = 0, cacc = 0;
-            if (d < maxd)
-                for (uint32_t v0 = vb; v0 < ve; v0 += 8) {
-                    const uint4 w0 = *reinterpret_cast<const uint4 *>(&s_wr[v0]), w1 = *reinterpret_cast<const uint4 *>(&s_wr[v0 + 4]);
-                    const uint32_t wr[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
-                    uint32_t c[8], q[8];
+        if (tid == 0) s_other = 0;
+        const char codes[17] = "=ACMGRSVTWYHKDBN";
+        const uint32_t dsh = maxd <= 64 ? 6u : (maxd <= 128 ? 7u : 8u), D = 1u << dsh, nparts = SJ_THREADS >> dsh;
+        const uint32_t d = (uint32_t)tid & (D - 1u), pi = (uint32_t)tid >> dsh;
+        const uint32_t per = ((R + nparts - 1u) / nparts + 7u) & ~7u, vb = pi * per, ve = vb + per < R ? vb + per : R;
+        const uint8_t *gq = W.q + goff0;
+        __syncthreads();
+        SJ_T(10);   // reach of the winner
+        unsigned long long qacc = 0, cacc = 0;
+        uint32_t rare = 0;   // bit c: base code c (not A, C, G, T) met at this depth
+        if (d < maxd)
+            for (uint32_t v0 = vb; v0 < ve; v0 += 8) {
+                const uint4 w0 = *reinterpret_cast<const uint4 *>(&s_wr[v0]), w1 = *reinterpret_cast<const uint4 *>(&s_wr[v0 + 4]);
+                const uint32_t wr[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+                uint32_t c[8], q[8];
 #pragma unroll
-                    for (int u = 0; u < 8; u++) {
-                        const bool act = (wr[u] & 0xFFu) > d && v0 + u < ve;
-                        const uint32_t co = act ? ((wr[u] >> 8) << 4) + d : 0u;
-                        c[u] = act ? (uint32_t)ch[co] & 15u : 16u;   // 16 = nothing to add
-                        q[u] = qs[co];
-                    }
-#pragma unroll
-                    for (int u = 0; u < 8; u++) {
-                        const uint32_t cc = c[u];
-                        const bool pw2 = cc < 16u && cc && !(cc & (cc - 1));   // A C G T
-                        const int shf = (__builtin_ctz(cc | 16u) & 3) << 4;
-                        qacc += (unsigned long long)(pw2 ? q[u] : 0u) << shf;
-                        cacc += (unsigned long long)(pw2 ? 1u : 0u) << shf;
-                        if (cc < 16u && !pw2) { atomicAdd(&hx[d * 16 + cc], q[u] | 0x10000u); s_other = 1; }
-                    }
+                for (int u = 0; u < 8; u++) {
+                    uint32_t co = ((wr[u] >> 8) << 4) + d;
+                    co = co < C ? co : 0u;
+                    c[u] = ch[co]; q[u] = gq[co];
                 }
-            qa[t] = qacc; ca[t] = cacc;
-        }
-        if (half) { part[2 * tid - 256] = qa[0]; part[2 * tid - 255] = ca[0]; part[2 * tid] = qa[1]; part[2 * tid + 1] = ca[1]; }
-        __syncthreads();
-        const bool other = s_other != 0;
-        if (!half)
-            for (int t = 0; t < 2; t++) {
-                const uint32_t d = dl + 128u * t;
-                if (d >= maxd) break;
-                qa[t] += part[2 * tid + 256 * t]; ca[t] += part[2 * tid + 256 * t + 1];
-                uint32_t tot = (uint32_t)(ca[t] & 0xFFFF) + (uint32_t)((ca[t] >> 16) & 0xFFFF) + (uint32_t)((ca[t] >> 32) & 0xFFFF) + (uint32_t)(ca[t] >> 48);
-                if (other)
-                    for (int c = 0; c < 16; c++) tot += hx[d * 16 + c] >> 16;
-                if ((int64_t)tot < (int64_t)P.mcc) atomicMin(&s_u[0], d);
-            }
-        __syncthreads();
-        const uint32_t stop = s_u[0];
-        const uint32_t key = ((s_hasm[r] ? 1u : 0u) << 31) | (minrank & 0x7fffffffu);
-        if ((int32_t)stop >= P.minlen) {
-            npl++;
-            if ((int32_t)words >= P.mincount) {
-                npb++;
-                const unsigned long long cand = ((unsigned long long)words << 32) | (unsigned long long)stop;
-                if (!have || cand > best_hi || (cand == best_hi && key > best_key)) {   // max by (count, len); ties: the last in list order
-                    have = true; best_hi = cand; best_key = key;
-                    if (!half)
-                        for (int t = 0; t < 2; t++) {
-                            const uint32_t d = dl + 128u * t;
-                            if (d >= stop) break;
-                            int best = -1, nbest = 0;
-                            uint32_t bq = 0;
-                            for (int c = 0; c < 16; c++) {
-                                uint32_t xq, xc;
-                                if (c == 1 || c == 2 || c == 4 || c == 8) { const int shf = (__builtin_ctz((uint32_t)c) & 3) << 4; xq = (uint32_t)(qa[t] >> shf) & 0xFFFFu; xc = (uint32_t)(ca[t] >> shf) & 0xFFFFu; }
-                                else { const uint32_t x = other ? hx[d * 16 + c] : 0u; xq = x & 0xFFFFu; xc = x >> 16; }
-                                if (!xc) continue;
-                                if (best < 0 || xq > bq) { best = c; nbest = 1; bq = xq; }
-                                else if (xq == bq) nbest++;
-                            }
-                            bestc[d] = nbest > 1 ? 'N' : codes[best < 0 ? 15 : best];   // get_best_qual_chars flanktrie.py:344-353
-                        }
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    const bool act = (wr[u] & 0xFFu) > d && v0 + u < ve;
+                    const uint32_t cc = (c[u] & 15u) | (act ? 0u : 16u);   // 16 = nothing to add
+                    const bool pw2 = cc < 16u && cc && !(cc & (cc - 1));   // A C G T
+                    const int shf = (__builtin_ctz(cc | 16u) & 3) << 4;
+                    qacc += (unsigned long long)(pw2 ? q[u] : 0u) << shf;
+                    cacc += (unsigned long long)(pw2 ? 1u : 0u) << shf;
+                    rare |= (cc < 16u && !pw2) ? 1u << cc : 0u;
                 }
             }
-        }
+        if (rare) atomicOr(&s_other, (int)rare);
+        if (pi) { part[2 * ((pi - 1u) * D + d)] = qacc; part[2 * ((pi - 1u) * D + d) + 1] = cacc; }
         __syncthreads();
-        if (other) {   // block-uniform
-            for (uint32_t i = tid; i < maxd * 16; i += SJ_THREADS) hx[i] = 0;
-            if (tid == 0) s_other = 0;
+        const uint32_t other = (uint32_t)s_other;
+        if (!pi && d < maxd) {
+            for (uint32_t k = 1; k < nparts; k++) { qacc += part[2 * ((k - 1u) * D + d)]; cacc += part[2 * ((k - 1u) * D + d) + 1]; }
+            int best = -1, nbest = 0;
+            uint32_t bq = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const uint32_t xq = (uint32_t)(qacc >> (16 * k)) & 0xFFFFu, xc = (uint32_t)(cacc >> (16 * k)) & 0xFFFFu;
+                if (!xc) continue;
+                if (best < 0 || xq > bq) { best = 1 << k; nbest = 1; bq = xq; }
+                else if (xq == bq) nbest++;
+            }
+            for (uint32_t m = other; m; m &= m - 1u) {   // block-uniform list of the rare codes met anywhere in the job; nearly always empty
+                const uint32_t cx = (uint32_t)__builtin_ctz(m);
+                uint32_t xq = 0, xc = 0;
+                for (uint32_t v = 0; v < R; v++) {
+                    const uint32_t w = s_wr[v];
+                    if ((w & 0xFFu) <= d) continue;
+                    const uint32_t co = ((w >> 8) << 4) + d;
+                    if (((uint32_t)ch[co] & 15u) == cx) { xq += gq[co]; xc++; }
+                }
+                if (!xc) continue;
+                if (best < 0 || xq > bq) { best = (int)cx; nbest = 1; bq = xq; }
+                else if (xq == bq) nbest++;
+            }
+            bestc[d] = nbest > 1 ? 'N' : codes[best < 0 ? 15 : best];   // get_best_qual_chars flanktrie.py:344-353
         }
         __syncthreads();
     }
     SJ_T(8);   // vote over all clusters
 #ifdef SJ_STAMP
+    if (tid == 0) {
+#pragma unroll
+        for (int i = 0; i < 12; i++) if (sj_acc[i]) atomicAdd(&g_sj_cyc[i], sj_acc[i]);
+    }
     if (tid == 0) { atomicAdd(&g_sj_cyc[12], 1ull); atomicAdd(&g_sj_cyc[13], (unsigned long long)NL); atomicAdd(&g_sj_cyc[14], (unsigned long long)npl | ((unsigned long long)R << 32)); }
 #endif
     if (tid == 0) {
@@ -1666,8 +1795,17 @@ int run_consensus(mfk_ctx *ctx, const DevReads &R, const DevParams &P, Consensus
             hm.n_big = 1;
             HIPCHK(hipMemcpyAsync(J.Rbig, J.R, (size_t)J.n * 4, hipMemcpyDeviceToDevice, st));
         } else {
-            const uint32_t lds0 = 48 * 1024, lds1 = 128 * 1024;
-            if (!ctx->sj_attr) { HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_job_small), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1)); ctx->sj_attr = true; }
+            // first pass: four workgroups per CU (160 KB of LDS, 128 VGPRs per lane: four waves per SIMD): 40 KB each, static part
+            // included; nearly every site-side of a 200x sample needs 16-28 KB.  Second pass, for the few that need more: 128 KB.
+            const uint32_t lds1 = 128 * 1024;
+            if (!ctx->sj_attr) {
+                hipFuncAttributes fa;
+                HIPCHK(hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(&k_job_small)));
+                HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_job_small), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
+                ctx->sj_static = (uint32_t)fa.sharedSizeBytes;
+                ctx->sj_attr = true;
+            }
+            const uint32_t lds0 = ctx->sj_static + 8192 < 40960 ? ((40960 - ctx->sj_static) & ~255u) : 32 * 1024;
             PROF_LAUNCH(k_job_small, dim3(J.n), dim3(SJ_THREADS), lds0, st, P, W, J, io, meta, lds0, 0);
             KCHK();
             if (int rc = read_back(ctx, meta, &hm, sizeof hm)) return rc;

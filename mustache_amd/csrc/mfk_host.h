@@ -53,6 +53,7 @@ struct mfk_ctx {
     int64_t pstats[MFK_N_STATS];
     std::vector<int32_t> isq_f, isq_r;   // inferseq pairing result (mfk_inferseq_pairs)
     bool sj_attr;                   // k_job_small may use more than 64 KB of dynamic LDS on this device (attribute set)
+    uint32_t sj_static;             // its static LDS in bytes (the first pass sizes its dynamic part for four workgroups per CU)
     char *na_pinned;                // pinned staging of mfk_recall_noalloc (header | sites | counts), allocated by mfk_create
     std::vector<int32_t> ir_ov;     // external inverted-repeat table for the next pairflanks call: rows i5 i3 has a1s a1e a2s a2e, sorted
 };
