@@ -660,6 +660,7 @@ extern "C" int mfk_findflanks(mfk_ctx *ctx, const mfk_reads *reads, const mfk_pa
     if (n_flanks_out) *n_flanks_out = 0;
     if (seq_bytes_out) *seq_bytes_out = 0;
     if (stop_after < MFK_STAGE_PARSE) stop_after = MFK_STAGE_PARSE;
+    HostTimer ht("findflanks");
     arena_reset(ctx);
     DevReads R; DevParams P;
     if (int rc = upload_reads(ctx, reads, params, &R, &P)) return rc;
@@ -706,6 +707,7 @@ extern "C" int mfk_findflanks(mfk_ctx *ctx, const mfk_reads *reads, const mfk_pa
             if (bucketed) { h_bkt.resize(B); rb.add(bkt_count, h_bkt.data(), (size_t)B * 4); }
             if (int rc = rb.flush()) return rc;
         }
+        ht.lap("scan + events + read-back");
         uint64_t seg_max = 0, listed = 0, bmax = 0, bsum = 0;
         for (int sgi = 0; sgi < LIST_SEGS; sgi++) { uint64_t c = h_cnt[(size_t)SEG_PAD * (1 + sgi)]; listed += c; if (c > seg_max) seg_max = c; }
         if (bucketed) { for (uint32_t c : h_bkt) { bsum += c; if (c > bmax) bmax = c; } }
@@ -771,6 +773,7 @@ extern "C" int mfk_findflanks(mfk_ctx *ctx, const mfk_reads *reads, const mfk_pa
         // surviving sites -> dense active table
         if (int rc = dev_excl_scan32(ctx, alive, ascan, E)) return rc;
         if (int rc = read_back(ctx, ascan + E, &n_act, 4)) return rc;
+        ht.lap("sites + read-back");
     }
     ConsensusIO io; memset(&io, 0, sizeof io);
     if (n_act > 0) {
@@ -814,7 +817,9 @@ extern "C" int mfk_findflanks(mfk_ctx *ctx, const mfk_reads *reads, const mfk_pa
             io.n_act = n_act; io.act_site = A.site; io.act_st = A.st; io.act_cnt2 = A.cnt2;
             io.site_ev_begin = T.ev_begin; io.site_ev_mid = T.ev_mid; io.site_ev_end = T.ev_end;
             io.work = reinterpret_cast<unsigned long long *>(d_stats + 12);   // 8-byte aligned: d_stats is an arena block
+            ht.lap("classify .. enqueue");
             if (int rc = run_consensus(ctx, R, P, io)) return rc;
+            ht.lap("consensus");
             if (one_wg && stop_after >= MFK_STAGE_ALL) {
                 PROF_LAUNCH(k_consfilters_mindist, dim3(1), dim3(1024), 0, st, A, n_act, (const uint32_t *)io.n_pass_len, (const uint32_t *)io.n_pass_both, P.mindist, st2, d_stats);
                 KCHK();
@@ -854,6 +859,7 @@ extern "C" int mfk_findflanks(mfk_ctx *ctx, const mfk_reads *reads, const mfk_pa
         }
         if (int rc = rb.flush()) return rc;
     }
+    ht.lap("results read-back");
     for (int i = 0; i < 10; i++) ctx->stats[i] = h_stats[i];
     ctx->stats[12] = (int64_t)((uint64_t)h_stats[12] | ((uint64_t)h_stats[13] << 32));
     prof_collect(ctx);
@@ -864,6 +870,8 @@ extern "C" int mfk_findflanks(mfk_ctx *ctx, const mfk_reads *reads, const mfk_pa
         // contig_base on the host (same formula as upload_reads)
         std::vector<int64_t> base(reads->n_contigs);
         { int64_t pad = (int64_t)params->min_distance_to_mate + params->max_direct_repeat_length + 64; if (pad < 64) pad = 64; int64_t b = 0; for (int c = 0; c < reads->n_contigs; c++) { base[c] = b; b += (int64_t)reads->h_contig_len[c] + 2 + pad; } }
+        ctx->sites.reserve(n_act);
+        if (stop_after >= MFK_STAGE_ALL) { ctx->flanks.reserve(2 * (size_t)n_act); ctx->seqs.reserve((size_t)n_act * 128); }
         for (uint32_t k = 0; k < n_act; k++) {
             if (!(stv[k] & 4)) continue;
             mfk_site s; memset(&s, 0, sizeof s);
@@ -895,6 +903,7 @@ extern "C" int mfk_findflanks(mfk_ctx *ctx, const mfk_reads *reads, const mfk_pa
         }
     }
     ctx->stats[11] = (int64_t)ctx->flanks.size();
+    ht.lap("host table");
     if (n_sites_out) *n_sites_out = (int64_t)ctx->sites.size();
     if (n_flanks_out) *n_flanks_out = (int64_t)ctx->flanks.size();
     if (seq_bytes_out) *seq_bytes_out = (int64_t)ctx->seqs.size();

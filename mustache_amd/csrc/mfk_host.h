@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <string>
@@ -79,6 +80,19 @@ void prof_collect(mfk_ctx *ctx);               // call after the stream has been
         hipLaunchKernelGGL(kern, grid, block, lds, stream, __VA_ARGS__);      \
         prof_end(ctx, stream);                                                \
     } while (0)
+
+// host-side wall clock of the sections of a compute call, printed to stderr when MFK_HOST_TIMING is set (diagnostic)
+#include <chrono>
+struct HostTimer {
+    const char *what; bool on; std::chrono::steady_clock::time_point t0, last;
+    explicit HostTimer(const char *w) : what(w) { static const bool e = getenv("MFK_HOST_TIMING") != nullptr; on = e; if (on) t0 = last = std::chrono::steady_clock::now(); }
+    void lap(const char *name) {
+        if (!on) return;
+        const auto t = std::chrono::steady_clock::now();
+        fprintf(stderr, "[mfk host] %s: %-28s %8.1f us (at %8.1f)\n", what, name, std::chrono::duration<double, std::micro>(t - last).count(), std::chrono::duration<double, std::micro>(t - t0).count());
+        last = t;
+    }
+};
 
 // arena ----------------------------------------------------------------------------------------------------------
 void arena_reset(mfk_ctx *ctx);                       // frees nothing on the fast path; merges chunks after growth

@@ -65,9 +65,10 @@ __device__ __forceinline__ int d_ir_code(char ch) {
     switch (ch) { case 'A': case 'a': return 0; case 'C': case 'c': return 1; case 'G': case 'g': return 2; case 'T': case 't': return 3; default: return 4; }
 }
 
-// one wave per sequence.  s: LDS copy of the sequence codes; S: LDS L x L int16 score matrix.
+// one wave per sequence.  s: LDS copy of the sequence codes; S: LDS L x L score matrix, one byte per cell (a score is at most
+// 3 x 50 pairs of a 100-base sequence and never negative), so that eleven workgroups share a CU instead of six.
 // out[6]: has_ir, arm1 start/end, arm2 start/end (1-based inclusive), number of repeats reported
-__device__ void d_ir_detect(const uint8_t *code, int L, int16_t *S, uint8_t *mask, int32_t *rep /* 4*IR_MAXREP, LDS */, int32_t *out) {
+__device__ void d_ir_detect(const uint8_t *code, int L, uint8_t *S, uint8_t *mask, int32_t *rep /* 4*IR_MAXREP, LDS */, int32_t *out) {
     const int MATCH = 3, MISMATCH = -4, GAP = 12, THRESHOLD = 15;
     const int lane = threadIdx.x & 63;
     for (int i = lane; i < L; i += 64) mask[i] = 0;
@@ -93,8 +94,8 @@ __device__ void d_ir_detect(const uint8_t *code, int L, int16_t *S, uint8_t *mas
         unsigned pA = 0, pB = 0;               // S(i, i+d-1) | S(i, i+d-2) << 16
         int bestvA = 0, bestdA = 0, bestvB = 0, bestdB = 0;   // per row: highest score and the first diagonal that reached it (= smallest j)
         const int nB = L - 64;  // row B has cells only on diagonals d < L - 64
-        int16_t *sA = S + iA * L + iA;         // S(iA, iA + d) = sA[d]
-        int16_t *sB = S + iB * L + iB;         // rows beyond the matrix write behind it: S has IR_S entries
+        uint8_t *sA = S + iA * L + iA;         // S(iA, iA + d) = sA[d]
+        uint8_t *sB = S + iB * L + iB;         // rows beyond the matrix write behind it: S has IR_S entries
         for (int d = 1; d < L; d++) {
             unsigned nA = (unsigned)__builtin_amdgcn_update_dpp(0, (int)pA, 0x130 /* wave_shl:1: lane i <- lane i+1 */, 0xF, 0xF, false);
             const unsigned fromB = (unsigned)__builtin_amdgcn_readfirstlane((int)pB);
@@ -105,7 +106,7 @@ __device__ void d_ir_detect(const uint8_t *code, int L, int16_t *S, uint8_t *mas
             const int up = (int)(nA & 0xFFFF) - GAP, left = (int)(pA & 0xFFFF) - GAP;
             vA = max(max(vA, up), max(left, 0));
             if ((cA | cjA) & 8) vA = 0;
-            sA[d] = (int16_t)vA;
+            sA[d] = (uint8_t)vA;
             if (vA > bestvA) { bestvA = vA; bestdA = d; }
             pA = (pA << 16) | (unsigned)vA;
             cjA = ncjA;
@@ -117,7 +118,7 @@ __device__ void d_ir_detect(const uint8_t *code, int L, int16_t *S, uint8_t *mas
                 const int upb = (int)(nBv & 0xFFFF) - GAP, leftb = (int)(pB & 0xFFFF) - GAP;
                 vB = max(max(vB, upb), max(leftb, 0));
                 if ((cB | cjB) & 8) vB = 0;
-                sB[d] = (int16_t)vB;
+                sB[d] = (uint8_t)vB;
                 if (vB > bestvB) { bestvB = vB; bestdB = d; }
                 pB = (pB << 16) | (unsigned)vB;
                 cjB = ncjB;
@@ -175,7 +176,7 @@ __device__ void d_ir_detect(const uint8_t *code, int L, int16_t *S, uint8_t *mas
 
 // generic entry: sequences given explicitly (mfk_ir_detect)
 __global__ __launch_bounds__(64) void k_ir_seqs(const char *seqs, const int64_t *off, uint32_t n, int32_t *out) {
-    __shared__ int16_t S[IR_S];
+    __shared__ uint8_t S[IR_S];
     __shared__ uint8_t code[IR_MAXLEN + 4], mask[IR_MAXLEN + 4 + IR_CM];   // mask | cm (d_ir_detect)
     __shared__ int32_t rep[4 * IR_MAXREP + 8];
     uint32_t k = blockIdx.x;
@@ -198,7 +199,7 @@ __device__ __forceinline__ uint64_t d_assign_key(const FlankDev &F, uint32_t a, 
 
 // also writes the candidate's sort key for assign_pairs (stable order by IR_length desc, diffcount asc, difflength asc)
 __global__ __launch_bounds__(64) void k_inverted_repeat(FlankDev F, const uint32_t *c5, const uint32_t *c3, uint32_t n, int32_t *out, uint64_t *keys, uint32_t *vals) {
-    __shared__ int16_t S[IR_S];
+    __shared__ uint8_t S[IR_S];
     __shared__ uint8_t code[IR_MAXLEN + 4], mask[IR_MAXLEN + 4 + IR_CM];   // mask | cm (d_ir_detect)
     __shared__ int32_t rep[4 * IR_MAXREP + 8];
     uint32_t k = blockIdx.x;
@@ -437,6 +438,7 @@ __global__ void k_pair_final(const uint32_t *kept, const uint32_t *n_kept, const
 // ---- get_direct_repeats ---------------------------------------------------------------------------------------------------
 #define DR_WIN 50
 #define DR_SEGS 1536
+#define DR_SEGS_SMALL 384   // 256-thread workgroups
 #define DR_FLIGHT 4   // eight in flight were no faster at C2 and slower with a thousand pairs
 // per candidate pair c: dr_out[c*stride ...] = reference repeat, dr_out[c*stride + half ...] = reads consensus.
 // One block per CANDIDATE pair (like k_spanning, on the side stream next to the inverted-repeat alignment); the host
@@ -446,8 +448,8 @@ __global__ void k_pair_final(const uint32_t *kept, const uint32_t *n_kept, const
 // workgroups (MODE 1: pile-up of a share of the reads, flushed into per-pair accumulators in HBM by atomics) and a
 // second launch (MODE 2) reads the accumulators and writes the repeats.
 #define DR_ACC (DR_WIN * 17)
-template <int MODE>
-__global__ __launch_bounds__(1024) void k_direct_repeats(DevReads R, FlankDev F, uint32_t n_cand, const uint32_t *c5, const uint32_t *c3,
+template <int MODE, int SEGS>
+__global__ __launch_bounds__(SEGS == DR_SEGS ? 1024 : 256) void k_direct_repeats(DevReads R, FlankDev F, uint32_t n_cand, const uint32_t *c5, const uint32_t *c3,
                                                         const uint8_t *genome, const int64_t *goff, char *dr_out, uint32_t stride, int32_t *dr_meta /* 3 per pair: ref_len, reads_len, err */,
                                                         uint32_t *g_sum, uint32_t *g_first, uint32_t *g_err) {
     __shared__ uint32_t sum[DR_WIN][17];
@@ -455,9 +457,11 @@ __global__ __launch_bounds__(1024) void k_direct_repeats(DevReads R, FlankDev F,
     __shared__ uint8_t refch[DR_WIN];
     __shared__ int64_t range[2], prange[2];
     __shared__ int err;
-    __shared__ uint64_t seg_q[DR_SEGS];
-    __shared__ int32_t seg_lo[DR_SEGS], seg_hi[DR_SEGS];
-    __shared__ uint32_t seg_r[DR_SEGS], nseg;
+    // SEGS: room for the segments of one chunk of blockDim.x reads (a read has one aligned block, a few have two or three);
+    // with thousands of pairs the workgroups are 256 threads wide and the short list lets eight of them share a CU
+    __shared__ uint64_t seg_q[SEGS];
+    __shared__ int32_t seg_lo[SEGS], seg_hi[SEGS];
+    __shared__ uint32_t seg_r[SEGS], nseg;
     const char codes[17] = "=ACMGRSVTWYHKDBN";
     if (blockIdx.x >= n_cand) return;
     const uint32_t c = blockIdx.x, k = c;      // output row = candidate
@@ -526,7 +530,7 @@ __global__ __launch_bounds__(1024) void k_direct_repeats(DevReads R, FlankDev F,
                     if (lo < hi) {
                         const uint64_t q0 = o0 + (uint64_t)(qpos + (lo - bs));
                         uint32_t slot = atomicAdd(&nseg, 1u);
-                        if (slot < DR_SEGS) { seg_q[slot] = q0; seg_lo[slot] = lo; seg_hi[slot] = hi; seg_r[slot] = (uint32_t)r; }
+                        if (slot < SEGS) { seg_q[slot] = q0; seg_lo[slot] = lo; seg_hi[slot] = hi; seg_r[slot] = (uint32_t)r; }
                         else for (int32_t rp = lo; rp < hi; rp++) {   // segment list full: add it here (slow, rare)
                             const uint64_t qi = q0 + (uint64_t)(rp - lo);
                             const uint32_t code = d_pool_base(R, qi);
@@ -539,7 +543,7 @@ __global__ __launch_bounds__(1024) void k_direct_repeats(DevReads R, FlankDev F,
             }
         }
         __syncthreads();
-        const uint32_t ns = nseg < DR_SEGS ? nseg : DR_SEGS;
+        const uint32_t ns = nseg < SEGS ? nseg : SEGS;
         const int lane = threadIdx.x & 63;
         const uint32_t nw = blockDim.x >> 6;
         for (uint32_t sgi = threadIdx.x >> 6; sgi < ns; sgi += DR_FLIGHT * nw) {   // DR_FLIGHT segments in flight per wave
@@ -648,6 +652,7 @@ extern "C" int mfk_pairflanks(mfk_ctx *ctx, const mfk_reads *reads, const mfk_pa
     if (n_pairs_out) *n_pairs_out = 0;
     if (str_bytes_out) *str_bytes_out = 0;
     if (n_flanks == 0) return 0;
+    HostTimer ht("pairflanks");
     if (params->max_direct_repeat_length > 65000 || params->max_direct_repeat_length < 0) { snprintf(ctx->err, sizeof ctx->err, "max_direct_repeat_length out of range"); return 1; }
     arena_reset(ctx);
     DevReads R; DevParams P;
@@ -697,6 +702,7 @@ extern "C" int mfk_pairflanks(mfk_ctx *ctx, const mfk_reads *reads, const mfk_pa
         if (seq_total) memcpy(hp + o_seqs, flank_seqs, (size_t)seq_total);
         if (!host_c5.empty()) { memcpy(hp + o_c5, host_c5.data(), host_c5.size() * 4); memcpy(hp + o_c3, host_c3.data(), host_c3.size() * 4); }
     }
+    ht.lap("staging");
     if (int rc = upload_pinned(ctx, d_up, hp, up_bytes)) return rc;   // pinned bytes stay untouched until the final read-back, which is ordered behind this copy
     int32_t *d_tab = (int32_t *)(d_up + o_tab); int64_t *d_soff = (int64_t *)(d_up + o_soff); char *d_seqs = d_up + o_seqs;
     int32_t *d_rank = (int32_t *)(d_up + o_rank); int64_t *d_goff = (int64_t *)(d_up + o_goff);
@@ -717,6 +723,7 @@ extern "C" int mfk_pairflanks(mfk_ctx *ctx, const mfk_reads *reads, const mfk_pa
         if (int rc = read_back(ctx, coff + nF, &nP, 4)) return rc;
     }
     ctx->pstats[0] = nP;
+    ht.lap("candidates + read-back");
     uint32_t nK = 0, nFin = 0;
     uint32_t h_ps[MFK_N_STATS]; memset(h_ps, 0, sizeof h_ps);
     std::vector<uint32_t> h_fin, h_span, h_c5, h_c3; std::vector<int32_t> h_ir, h_meta; std::vector<char> h_dr; uint32_t stride = 0;
@@ -764,15 +771,28 @@ extern "C" int mfk_pairflanks(mfk_ctx *ctx, const mfk_reads *reads, const mfk_pa
         HIPCHK(hipStreamWaitEvent(sb, ctx->ev_fork, 0));
         HIPCHK(hipStreamWaitEvent(sc, ctx->ev_fork, 0));
         if (dr_split > 1) {
-            PROF_LAUNCH(k_direct_repeats<1>, dim3(nP, dr_split), dim3(1024), 0, sb, R, F, nP, (const uint32_t *)c5, (const uint32_t *)c3,
+            prof_begin(ctx, "k_direct_repeats<1>", sb);
+                hipLaunchKernelGGL((k_direct_repeats<1, DR_SEGS>), dim3(nP, dr_split), dim3(1024), 0, sb, R, F, nP, (const uint32_t *)c5, (const uint32_t *)c3,
                         genome, (const int64_t *)d_goff, dr, stride, meta, g_sum, g_first, g_err);
+                prof_end(ctx, sb);
             KCHK();
-            PROF_LAUNCH(k_direct_repeats<2>, dim3(nP), dim3(64), 0, sb, R, F, nP, (const uint32_t *)c5, (const uint32_t *)c3,
+            prof_begin(ctx, "k_direct_repeats<2>", sb);
+                hipLaunchKernelGGL((k_direct_repeats<2, DR_SEGS>), dim3(nP), dim3(64), 0, sb, R, F, nP, (const uint32_t *)c5, (const uint32_t *)c3,
                         genome, (const int64_t *)d_goff, dr, stride, meta, g_sum, g_first, g_err);
+                prof_end(ctx, sb);
             KCHK();
         } else {
-            PROF_LAUNCH(k_direct_repeats<0>, dim3(nP), dim3(nP >= 2048 ? 256 : 1024), 0, sb, R, F, nP, (const uint32_t *)c5, (const uint32_t *)c3,
-                        genome, (const int64_t *)d_goff, dr, stride, meta, (uint32_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr);
+            if (nP >= 2048) {
+                prof_begin(ctx, "k_direct_repeats<0>", sb);
+                hipLaunchKernelGGL((k_direct_repeats<0, DR_SEGS_SMALL>), dim3(nP), dim3(256), 0, sb, R, F, nP, (const uint32_t *)c5, (const uint32_t *)c3,
+                            genome, (const int64_t *)d_goff, dr, stride, meta, (uint32_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr);
+                prof_end(ctx, sb);
+            } else {
+                prof_begin(ctx, "k_direct_repeats<0>", sb);
+                hipLaunchKernelGGL((k_direct_repeats<0, DR_SEGS>), dim3(nP), dim3(1024), 0, sb, R, F, nP, (const uint32_t *)c5, (const uint32_t *)c3,
+                            genome, (const int64_t *)d_goff, dr, stride, meta, (uint32_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr);
+                prof_end(ctx, sb);
+            }
             KCHK();
         }
         HIPCHK(hipEventRecord(ctx->ev_join, sb));
@@ -826,7 +846,9 @@ extern "C" int mfk_pairflanks(mfk_ctx *ctx, const mfk_reads *reads, const mfk_pa
         rb.add(meta, h_meta.data(), 3 * (size_t)nP * 4); rb.add(dr, h_dr.data(), (size_t)nP * stride);
         rb.add(c5, h_c5.data(), nP * 4); rb.add(c3, h_c3.data(), nP * 4); rb.add(ir, h_ir.data(), 6 * (size_t)nP * 4);
         rb.add(d_pstats, h_ps, sizeof h_ps);
+        ht.lap("enqueue");
         if (int rc = rb.flush()) return rc;
+        ht.lap("results read-back");
     } else
         HIPCHK(hipEventRecord(ctx->ev1, st));
     ctx->pstats[1] = nK;
@@ -837,6 +859,8 @@ extern "C" int mfk_pairflanks(mfk_ctx *ctx, const mfk_reads *reads, const mfk_pa
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1) == hipSuccess) ctx->last_ms = ms;
     // ---- rows ------------------------------------------------------------------------------------------------------------
+    ctx->pairs.reserve(nFin);
+    ctx->strs.reserve((size_t)nFin * 64);
     for (uint32_t k = 0; k < nFin; k++) {
         uint32_t c = h_fin[k], a = h_c5[c], b = h_c3[c];
         const mfk_flank &f5 = flanks[a], &f3 = flanks[b];
@@ -851,11 +875,12 @@ extern "C" int mfk_pairflanks(mfk_ctx *ctx, const mfk_reads *reads, const mfk_pa
         o.has_ir = r[0]; o.ir5_len = o.ir3_len = -1; o.ir_length = 0;
         if (r[1]) {
             int n5 = f5.seq_len > 40 ? 40 : f5.seq_len, n3 = f3.seq_len > 40 ? 40 : f3.seq_len;
-            std::string comb(flank_seqs + f5.seq_off, (size_t)n5);
-            comb.append(20, 'N');
-            comb.append(flank_seqs + f3.seq_off + (f3.seq_len - n3), (size_t)n3);
-            o.ir3_len = r[2] - r[1] + 1; o.ir3_off = (int64_t)ctx->strs.size(); ctx->strs.append(comb, (size_t)r[1] - 1, (size_t)o.ir3_len);   // IR_3p = ir1.seq
-            o.ir5_len = r[4] - r[3] + 1; o.ir5_off = (int64_t)ctx->strs.size(); ctx->strs.append(comb, (size_t)r[3] - 1, (size_t)o.ir5_len);   // IR_5p = ir2.seq
+            char comb[IR_MAXLEN + 4];                      // seq5[:40] + 'N' * 20 + seq3[-40:] (pairflanks.py:183-186)
+            memcpy(comb, flank_seqs + f5.seq_off, (size_t)n5);
+            memset(comb + n5, 'N', 20);
+            memcpy(comb + n5 + 20, flank_seqs + f3.seq_off + (f3.seq_len - n3), (size_t)n3);
+            o.ir3_len = r[2] - r[1] + 1; o.ir3_off = (int64_t)ctx->strs.size(); ctx->strs.append(comb + r[1] - 1, (size_t)o.ir3_len);   // IR_3p = ir1.seq
+            o.ir5_len = r[4] - r[3] + 1; o.ir5_off = (int64_t)ctx->strs.size(); ctx->strs.append(comb + r[3] - 1, (size_t)o.ir5_len);   // IR_5p = ir2.seq
             o.ir_length = o.ir5_len;
         }
         o.dr_ref_len = m[0]; o.dr_len = m[1];
@@ -863,6 +888,7 @@ extern "C" int mfk_pairflanks(mfk_ctx *ctx, const mfk_reads *reads, const mfk_pa
         o.dr_reads_off = (int64_t)ctx->strs.size(); ctx->strs.append(h_dr.data() + (size_t)c * stride + stride / 2, (size_t)m[1]);
         ctx->pairs.push_back(o);
     }
+    ht.lap("host table");
     if (n_pairs_out) *n_pairs_out = (int64_t)ctx->pairs.size();
     if (str_bytes_out) *str_bytes_out = (int64_t)ctx->strs.size();
     return 0;
