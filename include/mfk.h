@@ -243,6 +243,17 @@ int mfk_inferseq_pairs(mfk_ctx *ctx, const mfk_aln *alns, int64_t n, double min_
                        int64_t max_inferseq_size, int64_t min_inferseq_size, int64_t *n_pairs);
 int mfk_inferseq_pairs_fetch(mfk_ctx *ctx, int32_t *forward, int32_t *reverse);
 
+/* inferseq-database: the pairing of flank alignments against a database of known elements (replaces what
+ * infer_sequences_database does after the aligner has run, inferseqdatabase.py:116-139: prefilter_reads 142-180, get_pairs
+ * 183-208 with reads_mapped_both_ends 211-232, match_pairs 269-300 and pair_mapped_both_ends 234-266,
+ * keep_best_alignment_score 303-318).  Same records as mfk_inferseq_pairs (mate = 1 for flank id '1', else 2).
+ * *n_pairs = surviving couples; mfk_inferseq_pairs_fetch gives (forward-strand read, reverse-strand read) indices into alns,
+ * ordered by group, inside a group by the contig's first kept alignment, then in the order match_pairs takes couples
+ * (distance of the positions descending, flank-1 read, flank-2 read).  An alignment with aln_len == 0 or qlen == 0 is the
+ * reference's ZeroDivisionError: return code 7. */
+int mfk_inferseq_db_pairs(mfk_ctx *ctx, const mfk_aln *alns, int64_t n, double min_perc_identity, double max_internal_softclip_prop,
+                          int64_t max_edge_distance, int64_t *n_pairs);
+
 /* time spent in device work of the last compute call, milliseconds (HIP events on the ctx stream) */
 double mfk_last_device_ms(mfk_ctx *ctx);
 

@@ -87,6 +87,12 @@ typedef struct mfkio_pack mfkio_pack;
  * passes). */
 int mfkio_pack_bam(const char *path, int pool_mode, const mfkio_region *regions, int64_t n_regions, int n_threads,
                    int64_t chunk_bytes, mfkio_pack **out);
+/* The same with a FLAG filter: records that have any bit of exclude_flags set are skipped, as `samtools view -F` does.
+ * 0x900 (secondary | supplementary) is what the reference's formatbam removes before findflanks ever sees the file
+ * (mustache/samtools.py:9-18, formatbam.py:63-66): with it a BAM straight from the aligner does not trip the
+ * "more than two reads of one query name" abort of findflanks.py:971-978. */
+int mfkio_pack_bam_filtered(const char *path, int pool_mode, const mfkio_region *regions, int64_t n_regions, int n_threads,
+                            int64_t chunk_bytes, uint32_t exclude_flags, mfkio_pack **out);
 const mfkio_arrays *mfkio_pack_arrays(const mfkio_pack *p);
 const char *mfkio_pack_error(const mfkio_pack *p);
 void mfkio_pack_free(mfkio_pack *p);

@@ -103,6 +103,7 @@ struct IvSet {
 
 struct Shared {
     int pool_mode = 0;
+    uint32_t exclude_flags = 0;   // records with any of these FLAG bits are skipped like `samtools view -F` (formatbam: 0x900)
     int32_t n_contigs = 0;
     std::vector<IvSet> near_, win_;
 };
@@ -206,6 +207,7 @@ bool parse_record(const Shared &sh, const uint8_t *p, uint32_t bs, Local &L) {
     size_t fixed = 32 + (size_t)l_name + 4 * (size_t)n_cig + ((size_t)l_seq + 1) / 2 + (size_t)l_seq;
     if (fixed > bs) { L.err = "truncated alignment record"; L.format_err = true; return false; }
     if (n_cig == 0 || (flag & 4) || ref_id < 0) return true;  // unmapped: never reaches the CIGAR (quirk Q17)
+    if (flag & sh.exclude_flags) return true;                 // e.g. secondary / supplementary alignments (samtools.py:9-18)
     if (ref_id >= sh.n_contigs) { L.err = "alignment on a contig that is not in the header"; return false; }
     const uint8_t *cig = p + 32 + l_name;
     auto op_of = [&](unsigned k) { return le32(cig + 4 * k) & 15u; };
@@ -485,7 +487,7 @@ bool chain_plausible(const Shared &sh, const uint8_t *buf, size_t q, size_t len)
 }
 
 int run(mfkio_pack *P, const char *path, int pool_mode, const mfkio_region *regions, int64_t n_regions, int T,
-        int64_t chunk_bytes) {
+        int64_t chunk_bytes, uint32_t exclude_flags) {
     double t_begin = now_s(), t_inflate = 0, t_parse = 0, t_par = 0, t_merge = 0;
     if (pool_mode < MFKIO_POOL_NONE || pool_mode > MFKIO_POOL_REGIONS) return fail(P, MFKIO_ERR_ARG, "bad pool_mode");
     if (pool_mode == MFKIO_POOL_REGIONS && n_regions > 0 && !regions) return fail(P, MFKIO_ERR_ARG, "regions is NULL");
@@ -531,6 +533,7 @@ int run(mfkio_pack *P, const char *path, int pool_mode, const mfkio_region *regi
 
     Shared sh;
     sh.pool_mode = pool_mode;
+    sh.exclude_flags = exclude_flags;
     const LibDeflate &ld = libdeflate();
     std::vector<Local> locals((size_t)T);
     std::vector<uint64_t> uoff;
@@ -792,6 +795,11 @@ extern "C" {
 
 int mfkio_pack_bam(const char *path, int pool_mode, const mfkio_region *regions, int64_t n_regions, int n_threads,
                    int64_t chunk_bytes, mfkio_pack **out) {
+    return mfkio_pack_bam_filtered(path, pool_mode, regions, n_regions, n_threads, chunk_bytes, 0u, out);
+}
+
+int mfkio_pack_bam_filtered(const char *path, int pool_mode, const mfkio_region *regions, int64_t n_regions, int n_threads,
+                            int64_t chunk_bytes, uint32_t exclude_flags, mfkio_pack **out) {
     if (!out) return MFKIO_ERR_ARG;
     mfkio_pack *P = new (std::nothrow) mfkio_pack();
     *out = P;
@@ -807,7 +815,7 @@ int mfkio_pack_bam(const char *path, int pool_mode, const mfkio_region *regions,
     T = std::min(T, 256);
     if (chunk_bytes <= 0) chunk_bytes = (int64_t)256 << 20;
     try {
-        return run(P, path, pool_mode, regions, n_regions, T, chunk_bytes);
+        return run(P, path, pool_mode, regions, n_regions, T, chunk_bytes, exclude_flags);
     } catch (const std::bad_alloc &) {
         return fail(P, MFKIO_ERR_IO, "out of memory while packing");
     } catch (const std::exception &e) {

@@ -82,9 +82,12 @@ def findflanks_packed(binding, reads_struct, contig_names, params, sample_id, ou
 
 def _findflanks(bamfile, min_softclip_length, min_softclip_count, min_alignment_quality, min_alignment_inner_length,
                 min_distance_to_mate, min_softclip_ratio, max_indel_ratio, large_insertion_cutoff,
-                min_count_consensus, sample_id, output_file=None, device="cuda:0", verbose=True, decoder="native"):
+                min_count_consensus, sample_id, output_file=None, device="cuda:0", verbose=True, decoder="native",
+                exclude_flags=0):
     """Drop-in for reference findflanks.py:18-59 (same positional arguments).  ``decoder``: "native" (libmfkio.so) or
-    "python" (bamio.BamReader + pack_reads, the readable statement of the same packing rules)."""
+    "python" (bamio.BamReader + pack_reads, the readable statement of the same packing rules).  ``exclude_flags``: skip
+    records with any of these FLAG bits (0x900 = what the reference's formatbam step removes, samtools.py:9-18), for BAM
+    files that did not go through formatbam; 0 = every mapped record, like the reference."""
     binding = _lib.load(int(str(device).split(":")[1]) if ":" in str(device) else 0)
     params = _lib.make_params(min_softclip_length=min_softclip_length, min_softclip_count=min_softclip_count,
                               min_alignment_quality=min_alignment_quality,
@@ -95,11 +98,11 @@ def _findflanks(bamfile, min_softclip_length, min_softclip_count, min_alignment_
     if verbose:
         log("Parsing softclipped sites from provided BAM file...")
     if decoder == "native":
-        packed = pack_bam(bamfile, pool="clipped")
+        packed = pack_bam(bamfile, pool="clipped", exclude_flags=exclude_flags)
     elif decoder == "python":
         from .bamio import BamReader
         with BamReader(bamfile) as bam:
-            packed = pack_reads(bam.contigs, bam, pool="clipped")
+            packed = pack_reads(bam.contigs, bam, pool="clipped", exclude_flags=exclude_flags)
     else:
         raise ValueError("decoder must be 'native' or 'python', not %r" % (decoder,))
     if verbose:

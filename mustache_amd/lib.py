@@ -126,6 +126,7 @@ class Binding:
         f("pairflanks_set_ir", C.c_int, [_p, C.c_int64, _p, _p, _p])
         f("inferseq_pairs", C.c_int, [_p, _p, C.c_int64, C.c_double, C.c_double, C.c_int64, C.c_int64, C.POINTER(C.c_int64)])
         f("inferseq_pairs_fetch", C.c_int, [_p, _p, _p])
+        f("inferseq_db_pairs", C.c_int, [_p, _p, C.c_int64, C.c_double, C.c_double, C.c_int64, C.POINTER(C.c_int64)])
         if hasattr(self.so, prefix + "profile_enable"):
             f("profile_enable", C.c_int, [_p, C.c_int])
             f("profile_fetch", C.c_int, [_p, _p, C.c_int64, _p, _p, C.c_int64, C.POINTER(C.c_int64)])
@@ -287,6 +288,16 @@ class Binding:
         self._check(self.inferseq_pairs(self.ctx, a.ctypes.data, a.shape[0], float(min_perc_identity),
                                         float(max_internal_softclip_prop), int(max_inferseq_size), int(min_inferseq_size),
                                         C.byref(n)))
+        fwd, rev = np.zeros(max(n.value, 1), dtype=np.int32), np.zeros(max(n.value, 1), dtype=np.int32)
+        self._check(self.inferseq_pairs_fetch(self.ctx, fwd.ctypes.data, rev.ctypes.data))
+        return fwd[:n.value], rev[:n.value]
+
+    def run_inferseq_db_pairs(self, alns, min_perc_identity, max_internal_softclip_prop, max_edge_distance):
+        """inferseq-database pairing: alns (ALN_DTYPE, BAM order) -> (forward-strand, reverse-strand) index arrays."""
+        a = np.ascontiguousarray(alns, dtype=ALN_DTYPE)
+        n = C.c_int64(0)
+        self._check(self.inferseq_db_pairs(self.ctx, a.ctypes.data, a.shape[0], float(min_perc_identity),
+                                           float(max_internal_softclip_prop), int(max_edge_distance), C.byref(n)))
         fwd, rev = np.zeros(max(n.value, 1), dtype=np.int32), np.zeros(max(n.value, 1), dtype=np.int32)
         self._check(self.inferseq_pairs_fetch(self.ctx, fwd.ctypes.data, rev.ctypes.data))
         return fwd[:n.value], rev[:n.value]

@@ -6,7 +6,7 @@ commands; the CLI defaults are authoritative, not the class defaults or the help
 
 The Snakemake workflow of the reference calls exactly these two commands (workflow/Snakefile:82-87, 105-109); every flag
 it passes is accepted here.  Beside them the SURVEY.md section 8(f) "next" rows are registered: ``recall`` (main.py:272-284),
-``inferseq-overlap`` (167-182), ``inferseq-reference`` (143-164).  The rest of the toolbox is outside the hot path.
+``inferseq-overlap`` (167-182), ``inferseq-reference`` (143-164), ``inferseq-database`` (201-214), ``formatbam`` (262-269).  The rest of the toolbox is outside the hot path.
 """
 from __future__ import annotations
 
@@ -38,10 +38,11 @@ def cli():
 @click.option("--min_count_consensus", "-mcc", default=2)
 @click.option("--sample_id", "-id", default=None)
 @click.option("--output_file", "-o", default="mustache.findflanks.tsv")
+@click.option("--exclude-flags", "exclude_flags", default="0", help="Skip records with any of these FLAG bits, e.g. 0x900 for a BAM that did not go through formatbam (not in the reference).")
 @click.option("--device", default="cuda:0", help="GPU to run on (not in the reference).")
 def findflanks(bamfile, min_softclip_length, min_softclip_count, min_alignment_quality, min_alignment_inner_length,
                min_distance_to_mate, min_softclip_ratio, max_indel_ratio, large_insertion_cutoff,
-               min_count_consensus, sample_id, output_file, device):
+               min_count_consensus, sample_id, output_file, exclude_flags, device):
     from .findflanks import _findflanks
     if sample_id is None:
         sample_id = abspath(output_file)           # reference main.py:84-85
@@ -53,7 +54,7 @@ def findflanks(bamfile, min_softclip_length, min_softclip_count, min_alignment_q
                sample_id=sample_id, output_file=output_file)
     _findflanks(bamfile, min_softclip_length, min_softclip_count, min_alignment_quality, min_alignment_inner_length,
                 min_distance_to_mate, min_softclip_ratio, max_indel_ratio, large_insertion_cutoff,
-                min_count_consensus, sample_id, output_file, device=device)
+                min_count_consensus, sample_id, output_file, device=device, exclude_flags=int(str(exclude_flags), 0))
 
 
 @cli.command(short_help="Pair identified flanks with each other to represent 5' and 3' ends of inserted sequence.")
@@ -66,12 +67,13 @@ def findflanks(bamfile, min_softclip_length, min_softclip_count, min_alignment_q
 @click.option("--max_junction_spanning_prop", "-maxjsp", default=0.15)
 @click.option("--large_insertion_cutoff", "-lins", default=30)
 @click.option("--output_file", "-o", default="mustache.pairflanks.tsv")
+@click.option("--exclude-flags", "exclude_flags", default="0", help="Skip records with any of these FLAG bits, e.g. 0x900 for a BAM that did not go through formatbam (not in the reference).")
 @click.option("--device", default="cuda:0", help="GPU to run on (not in the reference).")
 @click.option("--ir-backend", "ir_backend", type=click.Choice(["builtin", "einverted"]), default="builtin",
               help="Inverted-repeat detector: the library's own (default) or EMBOSS einverted as the reference runs it "
                    "(needs the executable on PATH; not in the reference).")
 def pairflanks(flanksfile, bamfile, genome, max_direct_repeat_length, min_alignment_quality,
-               min_alignment_inner_length, max_junction_spanning_prop, large_insertion_cutoff, output_file, device,
+               min_alignment_inner_length, max_junction_spanning_prop, large_insertion_cutoff, output_file, exclude_flags, device,
                ir_backend):
     from .pairflanks import _pairflanks
     log_params(command="pairflanks", flanksfile=flanksfile, bamfile=bamfile, genome=genome,
@@ -81,7 +83,19 @@ def pairflanks(flanksfile, bamfile, genome, max_direct_repeat_length, min_alignm
                output_file=output_file)
     _pairflanks(flanksfile, bamfile, genome, max_direct_repeat_length, min_alignment_quality,
                 min_alignment_inner_length, max_junction_spanning_prop, large_insertion_cutoff, output_file,
-                device=device, ir_backend=ir_backend)
+                device=device, ir_backend=ir_backend, exclude_flags=int(str(exclude_flags), 0))
+
+
+@cli.command(short_help="Formats a BAM file for use with mustache. Usually not necessary, unless using the experimental extendpairs command.")
+@click.argument("in_sam", type=click.Path(exists=True))
+@click.argument("out_bam")
+@click.option("--single-end", is_flag=True, default=False, help="Add this flag for single-end files. default=False")
+@click.option("--keep-tmp-files", is_flag=True, default=False, help="Add this flag if you want to keep intermediate temporary files. default=False")
+def formatbam(in_sam, out_bam, single_end, keep_tmp_files):
+    """Reference main.py:262-269: secondary / supplementary alignments out, mate tags, coordinate sort, index."""
+    from .formatbam import _formatbam
+    log_params(command="formatbam", in_sam=in_sam, out_bam=out_bam, single_end=single_end, keep_tmp_files=keep_tmp_files)
+    _formatbam(in_sam, out_bam, single_end, keep_tmp_files)
 
 
 @cli.command(short_help="Recall softclip counts and runthrough counts from BAM file at specified pairflank insertions.")
@@ -141,6 +155,28 @@ def inferseq_reference(pairsfile, inferseq_reference, min_perc_identity, max_int
                keep_intermediate=keep_intermediate, output_file=output_file)
     _inferseq_reference(pairsfile, inferseq_reference, min_perc_identity, max_internal_softclip_prop, max_inferseq_size,
                         min_inferseq_size, keep_intermediate, output_file, device=device, alignments_bam=alignments_bam)
+
+
+@cli.command(name="inferseq-database", short_help="Infers the identity of an inserted sequence by aligning flank pairs to an database of known inserted elements.")
+@click.argument("pairsfile", type=click.Path(exists=True))
+@click.argument("inferseq_database", type=click.Path(exists=True))
+@click.option("--min_perc_identity", "-minident", default=0.90)
+@click.option("--max_internal_softclip_prop", "-maxclip", default=0.05)
+@click.option("--max_edge_distance", "-maxedgedist", default=10)
+@click.option("--output_file", "-o", default="mustache.inferseq_database.tsv")
+@click.option("--keep-intermediate/--no-keep-intermediate", default=False)
+@click.option("--device", default="cuda:0", help="GPU to run on (not in the reference).")
+@click.option("--alignments-bam", "alignments_bam", type=click.Path(exists=True), default=None,
+              help="Flank alignments made beforehand (BAM with NM and AS tags) instead of running bowtie2 here (not in the reference).")
+def inferseq_database(pairsfile, inferseq_database, min_perc_identity, max_internal_softclip_prop, max_edge_distance, output_file,
+                      keep_intermediate, device, alignments_bam):
+    """Reference main.py:201-214."""
+    from .inferseqdatabase import _inferseq_database
+    log_params(command="inferseq_database", pairsfile=pairsfile, inferseq_database=inferseq_database, min_perc_identity=min_perc_identity,
+               max_internal_softclip_prop=max_internal_softclip_prop, max_edge_distance=max_edge_distance, output_file=output_file,
+               keep_intermediate=keep_intermediate)
+    _inferseq_database(pairsfile, inferseq_database, min_perc_identity, max_internal_softclip_prop, max_edge_distance, output_file,
+                       keep_intermediate, device=device, alignments_bam=alignments_bam)
 
 
 if __name__ == "__main__":

@@ -215,11 +215,12 @@ class PackedReads:
         return out
 
 
-def pack_reads(contigs, reads, pool="clipped", keep_names=False):
+def pack_reads(contigs, reads, pool="clipped", keep_names=False, exclude_flags=0):
     """Pack mapped reads (an iterable of ``AlignedRead``-like objects in BAM order).
 
     contigs: list of (name, length) from the BAM header.
     pool:    'clipped' (findflanks), 'all', 'none', or a callable(read, contig_id) -> bool (pairflanks windows).
+    exclude_flags: records with any of these FLAG bits are skipped (0x900 = what the reference's formatbam removes).
     """
     contig_index = {n: i for i, (n, _) in enumerate(contigs)}
     if len(contigs) > 65535:
@@ -233,6 +234,8 @@ def pack_reads(contigs, reads, pool="clipped", keep_names=False):
         ct = read.cigartuples
         if ct is None or len(ct) == 0 or (getattr(read, "flag", 0) & 4):
             continue  # unmapped: mapping quality 0 in the reference, never reaches the CIGAR (quirk Q17)
+        if getattr(read, "flag", 0) & exclude_flags:
+            continue
         cid = contig_index[read.reference_name]
         key = (cid, read.reference_start)
         if key < prev_key:
@@ -372,6 +375,8 @@ def io_lib():
         so = _C.CDLL(IO_LIB_PATH)
         so.mfkio_pack_bam.restype = _C.c_int
         so.mfkio_pack_bam.argtypes = [_C.c_char_p, _C.c_int, _vp, _C.c_int64, _C.c_int, _C.c_int64, _C.POINTER(_vp)]
+        so.mfkio_pack_bam_filtered.restype = _C.c_int
+        so.mfkio_pack_bam_filtered.argtypes = [_C.c_char_p, _C.c_int, _vp, _C.c_int64, _C.c_int, _C.c_int64, _C.c_uint32, _C.POINTER(_vp)]
         so.mfkio_pack_arrays.restype = _C.POINTER(_IoArrays)
         so.mfkio_pack_arrays.argtypes = [_vp]
         so.mfkio_pack_error.restype = _C.c_char_p
@@ -395,12 +400,13 @@ class _IoOwner:
             self.handle = None
 
 
-def pack_bam(path, pool="clipped", regions=None, threads=0, chunk_bytes=0):
+def pack_bam(path, pool="clipped", regions=None, threads=0, chunk_bytes=0, exclude_flags=0):
     """Native counterpart of ``pack_reads(BamReader(path))``: same arrays, bit for bit.
 
     pool:    'clipped' | 'all' | 'none' | 'regions'.
     regions: for pool='regions' (pairflanks), rows (contig_id, lo, hi, es, ee) as ``candidate_regions`` returns them:
              only reads over [lo, hi) are packed, those over [es, ee) carry their bases.
+    exclude_flags: skip records with any of these FLAG bits (0x900: secondary / supplementary, as formatbam does).
     The returned PackedReads views the library's memory (no copy); ``.io_stats`` says what the run did.
     """
     so = io_lib()
@@ -413,8 +419,8 @@ def pack_bam(path, pool="clipped", regions=None, threads=0, chunk_bytes=0):
         for k, r in enumerate(regs):
             reg_arr[k] = _IoRegion(*[int(x) for x in r])
     handle = _vp()
-    rc = so.mfkio_pack_bam(_os.fsencode(path), mode, _C.cast(reg_arr, _vp) if reg_arr is not None else None, n_reg,
-                           int(threads), int(chunk_bytes), _C.byref(handle))
+    rc = so.mfkio_pack_bam_filtered(_os.fsencode(path), mode, _C.cast(reg_arr, _vp) if reg_arr is not None else None, n_reg,
+                                    int(threads), int(chunk_bytes), int(exclude_flags), _C.byref(handle))
     owner = _IoOwner(so, handle.value)
     if rc != 0:
         msg = so.mfkio_pack_error(handle).decode("utf-8", "replace") if handle.value else "out of memory"

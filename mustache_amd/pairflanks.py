@@ -146,7 +146,7 @@ def pairflanks_packed(binding, reads_struct, contig_names, params, flanks: pd.Da
     return flank_pairs
 
 
-def _pack_regions_python(bam, contig_names, regions):
+def _pack_regions_python(bam, contig_names, regions, exclude_flags=0):
     """The region filter + pool rule of pack_bam(pool='regions') spelled out on ``AlignedRead`` objects."""
     by_contig = {}
     for cid, lo, hi, es, ee in regions:
@@ -165,12 +165,12 @@ def _pack_regions_python(bam, contig_names, regions):
         return False
     index = {n: i for i, n in enumerate(contig_names)}
     reads = (r for r in bam if r.cigartuples is not None and near(r, index[r.reference_name]))
-    return pack_reads(bam.contigs, reads, pool=in_window)
+    return pack_reads(bam.contigs, reads, pool=in_window, exclude_flags=exclude_flags)
 
 
 def _pairflanks(flanksfile, bamfile, genome, max_direct_repeat_length, min_alignment_quality,
                 min_alignment_inner_length, max_junction_spanning_prop=0.15, large_insertion_cutoff=30,
-                output_file=None, device="cuda:0", verbose=True, ir_backend="builtin", decoder="native"):
+                output_file=None, device="cuda:0", verbose=True, ir_backend="builtin", decoder="native", exclude_flags=0):
     """Drop-in for reference pairflanks.py:18-51 (same positional arguments).  ``decoder`` as in ``_findflanks``."""
     if ir_backend == "einverted":
         from . import einverted
@@ -195,9 +195,9 @@ def _pairflanks(flanksfile, bamfile, genome, max_direct_repeat_length, min_align
         regions = candidate_regions(tab, max_direct_repeat_length, glen)
         # only reads that can overlap a candidate region are packed; reads over a direct-repeat window carry bases
         if decoder == "native":
-            packed = pack_bam(bamfile, pool="regions", regions=regions)
+            packed = pack_bam(bamfile, pool="regions", regions=regions, exclude_flags=exclude_flags)
         elif decoder == "python":
-            packed = _pack_regions_python(bam, contig_names, regions)
+            packed = _pack_regions_python(bam, contig_names, regions, exclude_flags)
         else:
             raise ValueError("decoder must be 'native' or 'python', not %r" % (decoder,))
     rs = device_reads(binding, packed, device)

@@ -77,6 +77,14 @@ class AlignedRead:
         return bool(self.flag & 16)
 
     @property
+    def is_read2(self):
+        return bool(self.flag & 0x80)
+
+    @property
+    def is_unmapped(self):
+        return bool(self.flag & 4)
+
+    @property
     def query_alignment_length(self):
         """Query bases inside the alignment: the sequence without its soft-clipped ends (pysam semantics)."""
         n = len(self.query_sequence or "")

@@ -1069,6 +1069,113 @@ int mfko_inferseq_pairs_fetch(void *c, int32_t *forward, int32_t *reverse) {
     return 0;
 }
 
+/* ---- inferseq-database pairing: inferseqdatabase.py:116-322 restated with the reference's lists, sort and greedy loop ---- */
+typedef struct { int32_t i, j; int64_t d; int32_t seq; } couple_t;
+static int cmp_couple(const void *a, const void *b) {   /* sorted(key=dist, reverse=True) is stable: ties keep the order of creation */
+    const couple_t *x = (const couple_t *)a, *y = (const couple_t *)b;
+    if (x->d != y->d) return x->d > y->d ? -1 : 1;
+    return (x->seq > y->seq) - (x->seq < y->seq);
+}
+static int db_keep_read(const mfk_aln *x, double min_ident, double max_prop, int64_t L) {   /* prefilter_reads 142-180 */
+    double identity = (double)(x->aln_len - x->nm) / (double)x->aln_len;
+    if (identity < min_ident) return 0;
+    if (!x->is_reverse) {
+        if (x->right_clip > 0 && x->ref_end < x->contig_len && (double)x->right_clip / (double)x->qlen > max_prop) return 0;
+        else if (x->ref_start > L) return 0;
+        else if (x->left_clip > 0 && llabs(0 - ((long long)x->ref_start - x->left_clip)) > L) return 0;
+    }
+    if (x->is_reverse) {
+        if (x->left_clip > 0 && x->ref_start - 1 >= 0 && (double)x->left_clip / (double)x->qlen > max_prop) return 0;
+        else if ((int64_t)x->contig_len - x->ref_end > L) return 0;
+        else if (x->right_clip > 0 && llabs(0 - ((long long)x->contig_len - ((long long)x->ref_end + x->right_clip))) > L) return 0;
+    }
+    return 1;
+}
+int mfko_inferseq_db_pairs(void *c, const mfk_aln *A, int64_t n, double min_perc_identity, double max_internal_softclip_prop,
+                           int64_t max_edge_distance, int64_t *n_pairs) {
+    octx *C = (octx *)c;
+    if (!C || n < 0 || !n_pairs) return 1;
+    C->err[0] = 0;
+    free(C->isq_f); free(C->isq_r); C->isq_f = C->isq_r = NULL; C->n_isq = 0;
+    *n_pairs = 0;
+    if (n == 0) return 0;
+    const int64_t L = max_edge_distance;
+    int32_t n_groups = 0;
+    for (int64_t i = 0; i < n; i++) {
+        if (A[i].aln_len == 0) { snprintf(C->err, sizeof C->err, "ZeroDivisionError: alignment %lld has query_alignment_length 0 (pysamtools.py:176)", (long long)i); return 7; }
+        if (A[i].qlen == 0) { snprintf(C->err, sizeof C->err, "ZeroDivisionError: alignment %lld has an empty query sequence (sctools.py:182-186)", (long long)i); return 7; }
+        if (A[i].group + 1 > n_groups) n_groups = A[i].group + 1;
+    }
+    char *keep = (char *)calloc((size_t)n, 1);
+    for (int64_t i = 0; i < n; i++) keep[i] = (char)db_keep_read(&A[i], min_perc_identity, max_internal_softclip_prop, L);
+    C->isq_f = (int32_t *)malloc((size_t)(n + 1) * sizeof(int32_t)); C->isq_r = (int32_t *)malloc((size_t)(n + 1) * sizeof(int32_t));
+    for (int32_t g = 0; g < n_groups; g++) {
+        ivec contigs = {0};   /* in the order the kept reads of the pair id first name them */
+        for (int64_t i = 0; i < n; i++) {
+            if (A[i].group != g || !keep[i]) continue;
+            int seen = 0;
+            for (int64_t k = 0; k < contigs.n; k++) if (contigs.v[k] == A[i].contig_id) seen = 1;
+            if (!seen) iv_push(&contigs, A[i].contig_id);
+        }
+        ivec kf = {0}, kr = {0};   /* keep_reads[pair]: (forward-strand read, reverse-strand read) */
+        for (int64_t ci = 0; ci < contigs.n; ci++) {
+            ivec r1 = {0}, r2 = {0};
+            for (int64_t i = 0; i < n; i++) if (A[i].group == g && keep[i] && A[i].contig_id == contigs.v[ci]) iv_push(A[i].mate == 1 ? &r1 : &r2, (int32_t)i);
+            int go = r1.n > 0 && r2.n > 0;
+            if (go) {   /* reads_mapped_both_ends 211-232 */
+                int f1 = 0, f2 = 0, t1 = 0, t2 = 0;
+                for (int pass = 0; pass < 2; pass++) {
+                    const ivec *l = pass ? &r2 : &r1;
+                    for (int64_t k = 0; k < l->n; k++) {
+                        const mfk_aln *x = &A[l->v[k]];
+                        if (x->is_reverse && (int64_t)x->contig_len - x->ref_end <= L) { if (x->mate == 1) t1++; else t2++; }
+                        else if (!x->is_reverse && x->ref_start <= L) { if (x->mate == 1) f1++; else f2++; }
+                    }
+                }
+                go = (f1 > 0 && t2 > 0) || (t1 > 0 && f2 > 0);
+            }
+            if (go) {   /* match_pairs 269-300 */
+                couple_t *cp = (couple_t *)malloc((size_t)(r1.n * r2.n + 1) * sizeof(couple_t));
+                int64_t nc = 0;
+                for (int64_t i = 0; i < r1.n; i++) {
+                    const mfk_aln *x = &A[r1.v[i]];
+                    int64_t p1 = x->is_reverse ? x->ref_end : x->ref_start;
+                    for (int64_t j = 0; j < r2.n; j++) {
+                        const mfk_aln *y = &A[r2.v[j]];
+                        int64_t p2 = y->is_reverse ? y->ref_end : x->ref_start;   /* line 284 reads read1.reference_start */
+                        cp[nc].i = (int32_t)i; cp[nc].j = (int32_t)j; cp[nc].d = llabs((long long)(p1 - p2)); cp[nc].seq = (int32_t)nc; nc++;
+                    }
+                }
+                qsort(cp, (size_t)nc, sizeof(couple_t), cmp_couple);
+                char *u1 = (char *)calloc((size_t)r1.n + 1, 1), *u2 = (char *)calloc((size_t)r2.n + 1, 1);
+                for (int64_t k = 0; k < nc; k++) {
+                    if (u1[cp[k].i] || u2[cp[k].j]) continue;
+                    u1[cp[k].i] = 1; u2[cp[k].j] = 1;
+                    const mfk_aln *a = &A[r1.v[cp[k].i]], *b = &A[r2.v[cp[k].j]];
+                    /* pair_mapped_both_ends 234-266 */
+                    int f1 = 0, t1 = 0, f2 = 0, t2 = 0;
+                    if (a->is_reverse && (int64_t)a->contig_len - a->ref_end <= L) t1 = 1; else if (!a->is_reverse && a->ref_start <= L) f1 = 1;
+                    if (b->is_reverse && (int64_t)b->contig_len - b->ref_end <= L) t2 = 1; else if (!b->is_reverse && b->ref_start <= L) f2 = 1;
+                    if (!((f1 && t2) || (t1 && f2))) continue;
+                    if (a->is_reverse && !b->is_reverse) { iv_push(&kf, r2.v[cp[k].j]); iv_push(&kr, r1.v[cp[k].i]); }
+                    else if (!a->is_reverse && b->is_reverse) { iv_push(&kf, r1.v[cp[k].i]); iv_push(&kr, r2.v[cp[k].j]); }
+                }
+                free(u1); free(u2); free(cp);
+            }
+            free(r1.v); free(r2.v);
+        }
+        /* keep_best_alignment_score 303-318 */
+        int64_t best = 0;
+        for (int64_t k = 0; k < kf.n; k++) { int64_t sc = (int64_t)A[kf.v[k]].as + A[kr.v[k]].as; if (sc > best) best = sc; }
+        for (int64_t k = 0; k < kf.n; k++)
+            if ((int64_t)A[kf.v[k]].as + A[kr.v[k]].as == best) { C->isq_f[C->n_isq] = kf.v[k]; C->isq_r[C->n_isq] = kr.v[k]; C->n_isq++; }
+        free(kf.v); free(kr.v); free(contigs.v);
+    }
+    free(keep);
+    *n_pairs = C->n_isq;
+    return 0;
+}
+
 /* external inverted-repeat results for the next mfko_pairflanks call (see mfk_pairflanks_set_ir) */
 int mfko_pairflanks_set_ir(void *c, int64_t n, const int32_t *index_5p, const int32_t *index_3p, const int32_t *ir) {
     octx *C = (octx *)c;

@@ -258,3 +258,26 @@ def run_inferseq(pairs, genome, reads, min_perc_identity=0.95, max_internal_soft
         if shuffle_seed is not None:
             _m.AlignedPair.__hash__ = object.__hash__
     return df.to_csv(sep="\t", index=False)
+
+
+def run_inferseq_database(database, reads, min_perc_identity=0.95, max_internal_softclip_prop=0.05, max_edge_distance=10):
+    """Run the reference's infer_sequences_database (inferseqdatabase.py:116-139) on given flank alignments -- what
+    _inferseq_database does AFTER the external aligner -- followed by the table steps of _inferseq_database lines 56-64
+    (make_dataframe, sort_values, pair_id as text, inferred_seq_length > 0), spelled out here because the function itself
+    starts with bowtie2.  ``reads`` stand in for the aligner's BAM.  Returns the TSV text (without the sample column)."""
+    install_stubs()
+    import contextlib
+    import io
+    from mustache import inferseqdatabase as m
+    key = "__aln_%d.bam" % id(reads)
+    _registry["bam"][key] = list(reads)
+    try:
+        with contextlib.redirect_stdout(io.StringIO()):            # "TOTAL PAIRS AFTER FILTER ..." prints
+            seqs = m.infer_sequences_database(key, database, min_perc_identity, max_internal_softclip_prop, max_edge_distance)
+    finally:
+        del _registry["bam"][key]
+    df = m.make_dataframe(seqs, method="inferred_database")
+    df = df.sort_values(by=["pair_id", "method"])
+    df.loc[:, "pair_id"] = list(map(str, map(int, list(df["pair_id"]))))
+    df = df.query("inferred_seq_length > 0")
+    return df.to_csv(sep="\t", index=False)
