@@ -19,7 +19,7 @@ mfk_ctx *mfk_create(int device_id) {
     ctx->hdr_dev = nullptr; ctx->hdr_cap = 0;
     ctx->gather_flag = nullptr; ctx->gather_flag_dev = nullptr;
     ctx->gather_seq = 0;
-    ctx->scan_state = nullptr;
+    ctx->scan_state = nullptr; ctx->scan_err = nullptr; ctx->call_ok = true;
     { const char *e0 = getenv("MFK_SCAN_EPOCH0"); ctx->scan_epoch = e0 ? (uint32_t)atoi(e0) & 0xFFFFu : 0u; }   // test hook: start near the wrap
     ctx->fill_stream = nullptr;
     ctx->na_pinned = nullptr;
@@ -31,7 +31,8 @@ mfk_ctx *mfk_create(int device_id) {
     memset(ctx->stats, 0, sizeof ctx->stats);
     memset(ctx->pstats, 0, sizeof ctx->pstats);
     if (hipMalloc((void **)&ctx->gather_count, 256) != hipSuccess || hipMemset(ctx->gather_count, 0, 256) != hipSuccess) { delete ctx; return nullptr; }
-    if (hipMalloc((void **)&ctx->scan_state, SCAN_CHAIN_TILES * 8) != hipSuccess || hipMemset(ctx->scan_state, 0, SCAN_CHAIN_TILES * 8) != hipSuccess) { delete ctx; return nullptr; }
+    if (hipMalloc((void **)&ctx->scan_state, SCAN_CHAIN_TILES * 8 + 256) != hipSuccess || hipMemset(ctx->scan_state, 0, SCAN_CHAIN_TILES * 8 + 256) != hipSuccess) { delete ctx; return nullptr; }
+    ctx->scan_err = reinterpret_cast<uint32_t *>(ctx->scan_state + SCAN_CHAIN_TILES);
     if (hipHostMalloc((void **)&ctx->gather_flag, 256, hipHostMallocMapped) != hipSuccess || hipHostGetDevicePointer((void **)&ctx->gather_flag_dev, ctx->gather_flag, 0) != hipSuccess) { delete ctx; return nullptr; }
     ctx->gather_flag[0] = 0;
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return nullptr; }
@@ -160,6 +161,14 @@ void prof_collect(mfk_ctx *ctx) {
 void arena_reset(mfk_ctx *ctx) {
     ctx->prof_names.clear();   // a call that failed half-way leaves its launches behind
     ctx->prof_used = 0;
+    if (!ctx->call_ok) {
+        // the previous call returned early (an error, or an entry point that does not mark its end): kernels or fills it had
+        // queued on the side streams may still be running and would write into the arena blocks handed out again below
+        (void)hipStreamSynchronize(ctx->stream2);
+        (void)hipStreamSynchronize(ctx->stream3);
+        (void)hipStreamSynchronize(ctx->stream);
+    }
+    ctx->call_ok = false;
     if (ctx->chunks.size() > 1) {
         // the previous call had to grow: replace the pieces by one chunk of the total size
         (void)hipStreamSynchronize(ctx->stream);
@@ -249,6 +258,13 @@ int upload_pinned(mfk_ctx *ctx, void *dev, const void *pinned_host, size_t bytes
     }
     HIPCHK(hipMemcpyAsync(dev, pinned_host, bytes, hipMemcpyHostToDevice, ctx->stream));
     return 0;
+}
+
+int check_scan_error(mfk_ctx *ctx, uint32_t h_scan_err) {
+    if (!h_scan_err) return 0;
+    (void)hipMemsetAsync(ctx->scan_err, 0, 4, ctx->stream);
+    snprintf(ctx->err, sizeof ctx->err, "a prefix scan gave up waiting for an earlier tile (k_scan_chain): results of this call are not valid; set MFK_NO_SCAN_CHAIN=1 to use the two-launch scan");
+    return 10;
 }
 
 int ReadBatch::flush() {
@@ -486,7 +502,7 @@ __global__ __launch_bounds__(1024) void k_scan_small(const uint32_t *in, TOut *o
 // lower-numbered ones, which are dispatched before it.  The epoch changes with every call, so the state array is never
 // cleared (the host clears it when the 16-bit epoch wraps).  Sums stay below 2^48 (inputs are 32-bit, n <= 2^21).
 template <typename TOut>
-__global__ __launch_bounds__(1024) void k_scan_chain(const uint32_t *in, TOut *out, uint32_t n, unsigned long long *state, uint32_t epoch) {
+__global__ __launch_bounds__(1024) void k_scan_chain(const uint32_t *in, TOut *out, uint32_t n, unsigned long long *state, uint32_t epoch, uint32_t *err) {
     __shared__ unsigned long long wsum[16];
     __shared__ unsigned long long s_prefix;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -522,8 +538,10 @@ __global__ __launch_bounds__(1024) void k_scan_chain(const uint32_t *in, TOut *o
                 do {
                     e = __hip_atomic_load(&state[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 } while ((uint32_t)(e >> 48) != epoch && ++spins < (1u << 24));
-                if ((uint32_t)(e >> 48) != epoch) __builtin_trap();   // a predecessor never ran: fail loudly, never hang
-                acc += e & 0xFFFFFFFFFFFFull;
+                // a predecessor never ran: never hang, never kill the process: its sum counts as 0 (every offset stays inside
+                // the arrays sized by the true total) and the error word fails the call at its next read-back
+                if ((uint32_t)(e >> 48) != epoch) atomicOr(err, 1u);
+                else acc += e & 0xFFFFFFFFFFFFull;
             }
         }
 #pragma unroll
@@ -562,7 +580,7 @@ static int dev_excl_scan(mfk_ctx *ctx, const uint32_t *in, TOut *out, size_t n) 
         }
         const unsigned tiles = (unsigned)((n + 1024 * SCAN_ITEMS - 1) / (1024 * SCAN_ITEMS));
         prof_begin(ctx, "k_scan_chain");
-        hipLaunchKernelGGL(k_scan_chain<TOut>, dim3(tiles), dim3(1024), 0, ctx->stream, in, out, (uint32_t)n, ctx->scan_state, ctx->scan_epoch);
+        hipLaunchKernelGGL(k_scan_chain<TOut>, dim3(tiles), dim3(1024), 0, ctx->stream, in, out, (uint32_t)n, ctx->scan_state, ctx->scan_epoch, ctx->scan_err);
         prof_end(ctx);
         KCHK();
         return 0;

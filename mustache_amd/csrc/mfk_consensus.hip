@@ -1724,6 +1724,23 @@ __global__ __launch_bounds__(SJ_THREADS) void k_job_small(DevParams P, Words W, 
 #undef SJ_FAIL
 }
 
+// A launch whose static + dynamic LDS passes the default 64 KB per workgroup needs the kernel's limit raised first; what the
+// device cannot give (160 KB per CU on gfx950) is an error of the call with a message, not a failed launch.
+static int ensure_lds(mfk_ctx *ctx, const void *func, size_t dynamic_bytes, const char *name) {
+    hipFuncAttributes fa;
+    HIPCHK(hipFuncGetAttributes(&fa, func));
+    const size_t need = fa.sharedSizeBytes + dynamic_bytes;
+    if (need <= 64 * 1024) return 0;
+    int optin = 0;
+    if (hipDeviceGetAttribute(&optin, hipDeviceAttributeSharedMemPerBlockOptin, ctx->device) != hipSuccess || optin <= 0) optin = 160 * 1024;
+    if (need > (size_t)optin || hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dynamic_bytes) != hipSuccess) {
+        (void)hipGetLastError();
+        snprintf(ctx->err, sizeof ctx->err, "%s needs %zu bytes of LDS per workgroup (%zu static + %zu for the longest soft clip): more than this device allows", name, need, (size_t)fa.sharedSizeBytes, dynamic_bytes);
+        return 6;
+    }
+    return 0;
+}
+
 // =====================================================================================================================
 int run_consensus(mfk_ctx *ctx, const DevReads &R, const DevParams &P, ConsensusIO &io) {
     hipStream_t st = ctx->stream;
@@ -1885,7 +1902,8 @@ int run_consensus(mfk_ctx *ctx, const DevReads &R, const DevParams &P, Consensus
     KCHK();
     HIPCHK(hipEventRecord(ctx->ev_join3, sc));
     {
-        const size_t ns_lds = (size_t)max_len * NS_SLOTS * 16;   // <= 64 KB with MAX_WORD_LEN 512
+        const size_t ns_lds = (size_t)max_len * NS_SLOTS * 16;   // 64 KB with MAX_WORD_LEN 512
+        if (int rc = ensure_lds(ctx, reinterpret_cast<const void *>(&k_node_sums), ns_lds, "k_node_sums")) return rc;
         PROF_LAUNCH(k_node_sums, dim3(nblocks(Wn, NS_WORDS)), dim3(1024), ns_lds, st, W, J, max_len);
         KCHK();
     }
@@ -1893,7 +1911,7 @@ int run_consensus(mfk_ctx *ctx, const DevReads &R, const DevParams &P, Consensus
     HIPCHK(hipStreamWaitEvent(st, ctx->ev_join, 0));
     HIPCHK(hipStreamWaitEvent(st, ctx->ev_join3, 0));
     size_t lds = (size_t)max_len * 16 * 8;
-    if (lds > 64 * 1024) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_cluster_vote), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    if (int rc = ensure_lds(ctx, reinterpret_cast<const void *>(&k_cluster_vote), lds, "k_cluster_vote")) return rc;   // 64 KB + 4 KB static at 512 bases
     char *cl_chars = aalloc<char>(ctx, (size_t)Wn * io.cons_stride);
     if (!cl_chars) return 1;
     PROF_LAUNCH(k_leaf_share, dim3(g_leaf4), dim3(256), 0, st, W, J, (const uint16_t *)lcpm);

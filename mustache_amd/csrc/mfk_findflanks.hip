@@ -837,7 +837,7 @@ extern "C" int mfk_findflanks(mfk_ctx *ctx, const mfk_reads *reads, const mfk_pa
     }
     HIPCHK(hipEventRecord(ctx->ev1, st));
     // ---- results to the host -------------------------------------------------------------------------------------
-    uint32_t h_stats[MFK_N_STATS];
+    uint32_t h_stats[MFK_N_STATS], h_scan_err = 0;
     std::vector<uint32_t> gpos(n_act), cnt2(2 * (size_t)n_act), stv(n_act), counts(8 * (size_t)n_act);
     std::vector<int32_t> contig(n_act);
     std::vector<int32_t> ccount, clen; std::vector<char> cchars;
@@ -845,6 +845,7 @@ extern "C" int mfk_findflanks(mfk_ctx *ctx, const mfk_reads *reads, const mfk_pa
     {
         ReadBatch rb(ctx);
         rb.add(d_stats, h_stats, sizeof h_stats);
+        rb.add(ctx->scan_err, &h_scan_err, 4);
         if (io.err_dev) rb.add(io.err_dev, &io.err_flags, 4);
         if (n_act > 0) {
             rb.add(A.gpos, gpos.data(), n_act * 4); rb.add(A.contig, contig.data(), n_act * 4);
@@ -860,6 +861,7 @@ extern "C" int mfk_findflanks(mfk_ctx *ctx, const mfk_reads *reads, const mfk_pa
         if (int rc = rb.flush()) return rc;
     }
     ht.lap("results read-back");
+    if (int rc = check_scan_error(ctx, h_scan_err)) return rc;
     for (int i = 0; i < 10; i++) ctx->stats[i] = h_stats[i];
     ctx->stats[12] = (int64_t)((uint64_t)h_stats[12] | ((uint64_t)h_stats[13] << 32));
     prof_collect(ctx);
@@ -904,6 +906,7 @@ extern "C" int mfk_findflanks(mfk_ctx *ctx, const mfk_reads *reads, const mfk_pa
     }
     ctx->stats[11] = (int64_t)ctx->flanks.size();
     ht.lap("host table");
+    ctx->call_ok = true;
     if (n_sites_out) *n_sites_out = (int64_t)ctx->sites.size();
     if (n_flanks_out) *n_flanks_out = (int64_t)ctx->flanks.size();
     if (seq_bytes_out) *seq_bytes_out = (int64_t)ctx->seqs.size();

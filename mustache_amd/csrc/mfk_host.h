@@ -24,6 +24,8 @@ struct mfk_ctx {
     hipEvent_t ev_fork, ev_join, ev_join3, ev_fork3, ev_fill;
     hipStream_t fill_stream;   // while set, FillGroup launches go to this stream instead of `stream` (fills that overlap the kernels before their first consumer)
     unsigned long long *scan_state; uint32_t scan_epoch;   // tile aggregates of k_scan_chain, tagged with the call's epoch (never cleared between calls)
+    uint32_t *scan_err;             // device word behind the aggregates: set when a workgroup of k_scan_chain gave up waiting for a predecessor
+    bool call_ok;                   // the previous compute call ran to its end: its side streams are joined (else arena_reset drains them)
     double last_ms;
     std::vector<Chunk> chunks;      // device arena
     void *pinned; size_t pinned_cap;
@@ -125,6 +127,7 @@ size_t upload_reads_pinned_bytes(int n_contigs);
 int upload_reads(mfk_ctx *ctx, const mfk_reads *reads, const mfk_params *params, DevReads *R, DevParams *P);
 int prepare_reads(mfk_ctx *ctx, const mfk_reads *reads, const mfk_params *params, DevReads *R, DevParams *P, char *h, size_t *used);   // validation, R / P, header bytes into h
 void set_header_ptrs(DevReads *R, char *d_hdr);
+int check_scan_error(mfk_ctx *ctx, uint32_t h_scan_err);   // after the read-back that carried scan_err: non-zero fails the call
 int noalloc_setup(mfk_ctx *ctx);     // mfk_findflanks.hip: device address of the no-allocation scratch array + pinned staging, once per ctx (mfk_create)
 void noalloc_teardown(mfk_ctx *ctx);
 

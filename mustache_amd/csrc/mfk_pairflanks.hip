@@ -725,7 +725,7 @@ extern "C" int mfk_pairflanks(mfk_ctx *ctx, const mfk_reads *reads, const mfk_pa
     ctx->pstats[0] = nP;
     ht.lap("candidates + read-back");
     uint32_t nK = 0, nFin = 0;
-    uint32_t h_ps[MFK_N_STATS]; memset(h_ps, 0, sizeof h_ps);
+    uint32_t h_ps[MFK_N_STATS], h_scan_err = 0; memset(h_ps, 0, sizeof h_ps);
     std::vector<uint32_t> h_fin, h_span, h_c5, h_c3; std::vector<int32_t> h_ir, h_meta; std::vector<char> h_dr; uint32_t stride = 0;
     if (nP > 0) {
         // everything downstream is sized by the candidate count; the kept / final counts stay on the device
@@ -846,11 +846,13 @@ extern "C" int mfk_pairflanks(mfk_ctx *ctx, const mfk_reads *reads, const mfk_pa
         rb.add(meta, h_meta.data(), 3 * (size_t)nP * 4); rb.add(dr, h_dr.data(), (size_t)nP * stride);
         rb.add(c5, h_c5.data(), nP * 4); rb.add(c3, h_c3.data(), nP * 4); rb.add(ir, h_ir.data(), 6 * (size_t)nP * 4);
         rb.add(d_pstats, h_ps, sizeof h_ps);
+        rb.add(ctx->scan_err, &h_scan_err, 4);
         ht.lap("enqueue");
         if (int rc = rb.flush()) return rc;
         ht.lap("results read-back");
     } else
         HIPCHK(hipEventRecord(ctx->ev1, st));
+    if (int rc = check_scan_error(ctx, h_scan_err)) return rc;
     ctx->pstats[1] = nK;
     const bool had_table = !ir_tab.empty();
     if (had_table && h_ps[15]) { snprintf(ctx->err, sizeof ctx->err, "a candidate pair has no entry in the inverted-repeat table given to mfk_pairflanks_set_ir"); return 8; }
@@ -889,6 +891,7 @@ extern "C" int mfk_pairflanks(mfk_ctx *ctx, const mfk_reads *reads, const mfk_pa
         ctx->pairs.push_back(o);
     }
     ht.lap("host table");
+    ctx->call_ok = true;
     if (n_pairs_out) *n_pairs_out = (int64_t)ctx->pairs.size();
     if (str_bytes_out) *str_bytes_out = (int64_t)ctx->strs.size();
     return 0;

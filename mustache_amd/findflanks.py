@@ -65,7 +65,14 @@ def flank_frame(result, contig_names):
 
 def findflanks_packed(binding, reads_struct, contig_names, params, sample_id, output_file=None, verbose=True):
     """The part of ``_findflanks`` after the BAM has been packed and moved to the device."""
-    res = binding.run_findflanks(reads_struct, params)
+    try:
+        res = binding.run_findflanks(reads_struct, params)
+    except _lib.MfkError as e:
+        if "READ NUMBER ERROR" in str(e):
+            # the reference's fatal invariant (findflanks.py:971-978, 1025-1027): message on stdout, then sys.exit()
+            print("READ NUMBER ERROR - ZERO OR MORE THAN TWO READS ASSOCIATED WITH QUERY NAME")
+            sys.exit()
+        raise
     if verbose:
         pd_ = {k: getattr(params, k) for k, _ in params._fields_}
         for idx, msg in _STAT_MESSAGES:

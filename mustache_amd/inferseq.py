@@ -111,10 +111,16 @@ def align_flanks(fasta, genome_path, out_bam):
     if not os.path.exists(genome_path + ".1.bt2"):                # bowtie2tools.genome_is_indexed / index_genome
         subprocess.check_call(["bowtie2-build", "-o", "3", "-q", genome_path, genome_path])
     sam = out_bam + ".sam"
-    cmd = ("bowtie2 --all --score-min G,1,9 --local -x {g} -p 1 -f -U {f} -S {s} 2> /dev/null; "
-           "samtools view -h -q 1 {s} 2> /dev/null 1> {s}.tmp; samtools sort {s}.tmp 2> /dev/null 1> {b}; "
-           "rm -f {s} {s}.tmp").format(g=genome_path, f=fasta, s=sam, b=out_bam)
-    subprocess.check_call(cmd, shell=True)
+    # the reference's pipeline (bowtie2tools.py:46-60) as argument lists: no shell, so paths with spaces or shell characters
+    # are safe, and a failing step raises here instead of leaving a broken BAM for the reader
+    with open(os.devnull, "w") as null:
+        subprocess.check_call(["bowtie2", "--all", "--score-min", "G,1,9", "--local", "-x", genome_path, "-p", "1", "-f", "-U", fasta, "-S", sam], stderr=null)
+        with open(sam + ".tmp", "w") as fh:
+            subprocess.check_call(["samtools", "view", "-h", "-q", "1", sam], stdout=fh, stderr=null)
+        with open(out_bam, "wb") as fh:
+            subprocess.check_call(["samtools", "sort", sam + ".tmp"], stdout=fh, stderr=null)
+    os.remove(sam)
+    os.remove(sam + ".tmp")
     return out_bam
 
 

@@ -217,8 +217,12 @@ def test_supplementary_alignments_abort_findflanks_unless_filtered(tmp_path, hip
     p.update(case["findflanks_params"])
     args = (p["min_softclip_length"], p["min_softclip_count"], p["min_alignment_quality"], p["min_alignment_inner_length"],
             p["min_distance_to_mate"], p["min_softclip_ratio"], p["max_indel_ratio"], p["large_insertion_cutoff"], p["min_count_consensus"], "sample1")
-    with pytest.raises(lib.MfkError, match="READ NUMBER ERROR"):
+    with pytest.raises(SystemExit):                      # the reference prints the message and calls sys.exit() (findflanks.py:976-978)
         _findflanks(bam, *args, output_file=None, verbose=False)
+    from mustache_amd.findflanks import device_reads
+    from mustache_amd.pack import pack_bam
+    with pytest.raises(lib.MfkError, match="READ NUMBER ERROR"):   # the C-ABI itself reports error 3
+        hip.run_findflanks(device_reads(hip, pack_bam(bam, pool="clipped"), "cuda:0"), lib.make_params(**p))
     out = os.path.join(tmp_path, "ff.tsv")
     _findflanks(bam, *args, output_file=out, verbose=False, exclude_flags=0x900)
     assert open(out).read() == case["findflanks_tsv"]

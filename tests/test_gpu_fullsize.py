@@ -120,3 +120,38 @@ def test_small_job_kernel_and_device_wide_kernels_agree(hip, oracle, monkeypatch
     want = oracle.run_findflanks(oracle.reads(packed), params)
     assert a["seqs"] == want["seqs"] and a["flanks"].tobytes() == want["flanks"].tobytes() and len(a["flanks"]) > 0
     assert list(a["stats"][:12]) == list(want["stats"][:12])
+
+
+@pytest.mark.parametrize("read_len,expect", [(320, "ok"), (531, "ok"), (532, "ok"), (560, "too long")])
+def test_long_soft_clips(hip, oracle, read_len, expect):
+    """Soft clips of 300, ~510 and exactly 512 bases (250-300 bp and longer libraries; the device-wide consensus kernels then
+    ask for up to 64 KB of dynamic LDS on top of their static part) against the oracle; beyond 512 bases the call fails
+    with error 6 and a message instead of a launch failure."""
+    packed, genome, _ = synth_packed(contig_lens=(60_000,), coverage=60, n_insertions=4, read_len=read_len, frag_mean=read_len + 100, seed=3)
+    f = packed.flags
+    longest = int(max(np.where((f & 3) == 1, packed.first_op_len, 0).max(), np.where(((f >> 2) & 3) == 1, packed.last_op_len, 0).max()))
+    rd = device_reads(hip, packed, "cuda:0")
+    params = lib.make_params()
+    if expect == "too long":
+        assert longest > 512
+        with pytest.raises(lib.MfkError, match="error 6.*longer than 512"):
+            hip.run_findflanks(rd, params)
+        # the call failed half-way, with a fill still queued on a side stream: the next call on the same ctx is unharmed
+        small, sg, _ = synth_packed(**CONFIGS["tiny"], seed=21)
+        ff, pf, off, opf = _both(hip, oracle, small, sg)
+        assert ff["flanks"].tobytes() == off["flanks"].tobytes() and ff["seqs"] == off["seqs"] and pf["strs"] == opf["strs"] and len(ff["flanks"]) > 0
+        return
+    assert {320: 300, 531: 508, 532: 512}[read_len] <= longest <= 512
+    ff, pf, off, opf = _both(hip, oracle, packed, genome)
+    _same(ff["flanks"], off["flanks"], lib.FLANK_DTYPE)
+    assert ff["seqs"] == off["seqs"] and len(ff["flanks"]) > 0 and int(ff["flanks"]["seq_len"].max()) >= longest - 8
+    _same(pf["pairs"], opf["pairs"], lib.PAIR_DTYPE)
+    assert pf["strs"] == opf["strs"]
+    # and through the device-wide kernels alone (the small-job kernel takes words up to 255 characters only)
+    import os
+    os.environ["MFK_NO_SMALL_JOBS"] = "1"
+    try:
+        b = hip.run_findflanks(rd, params)
+    finally:
+        del os.environ["MFK_NO_SMALL_JOBS"]
+    assert b["seqs"] == off["seqs"] and b["flanks"].tobytes() == off["flanks"].tobytes()

@@ -98,6 +98,56 @@ def test_ir_detect_matches_oracle(hip, oracle):
     assert want[:, 0].sum() > 50
 
 
+def _ir_seqs(seed, n=300):
+    rng = np.random.default_rng(seed)
+    comp = {"A": "T", "C": "G", "G": "C", "T": "A"}
+    seqs = []
+    for k in range(n):
+        n5, n3 = int(rng.integers(8, 41)), int(rng.integers(8, 41))
+        a = "".join("ACGT"[i] for i in rng.integers(0, 4, n5))
+        if k % 3:
+            arm = "".join(comp[c] for c in reversed(a[:int(rng.integers(6, n5 + 1))]))
+            b = list("".join("ACGT"[i] for i in rng.integers(0, 4, max(0, n3 - len(arm)))) + arm)
+            for _ in range(int(rng.integers(0, 3))):
+                b[int(rng.integers(0, len(b)))] = "ACGTN"[int(rng.integers(0, 5))]
+            b = "".join(b)[-40:]
+        else:
+            b = "".join("ACGT"[i] for i in rng.integers(0, 4, n3))
+        seqs.append(a + "N" * 20 + b)
+    return seqs
+
+
+def test_reported_inverted_repeats_are_self_consistent(hip):
+    """The IR columns have no reference output to be pinned against (EMBOSS einverted is in neither tree nor image), so
+    beside the comparison with the oracle's model this checks what any einverted-like detector must satisfy, with no
+    oracle involved: the two arms are disjoint and ordered, they lie where mustache accepts them (arm 1 starts within
+    15 bases of the start, arm 2 ends within 15 of the end, pairflanks.py:253-266), and arm 1 aligned against the
+    reverse complement of arm 2 scores at least the threshold 15 under match +3 / mismatch -4 / gap -12
+    (embosstools.py:8-14)."""
+    comp = {"A": "T", "C": "G", "G": "C", "T": "A"}
+    seqs = _ir_seqs(19)
+    got = hip.run_ir_detect(seqs)
+    n_ir = 0
+    for s, (has, a1s, a1e, a2s, a2e, nrep) in zip(seqs, got):
+        if not has:
+            continue
+        n_ir += 1
+        L = len(s)
+        assert 1 <= a1s <= a1e < a2s <= a2e <= L
+        assert a1s <= 15 and a2e >= L - 15
+        x, y = s[a1s - 1:a1e], s[a2s - 1:a2e][::-1]
+        best = np.full((len(x) + 1, len(y) + 1), -10 ** 6, dtype=np.int64)    # global alignment of the two arms
+        best[0, :] = -12 * np.arange(len(y) + 1)
+        best[:, 0] = -12 * np.arange(len(x) + 1)
+        for i in range(1, len(x) + 1):
+            for j in range(1, len(y) + 1):
+                m = 3 if comp.get(x[i - 1]) == y[j - 1] else -4
+                best[i, j] = max(best[i - 1, j - 1] + m, best[i - 1, j] - 12, best[i, j - 1] - 12)
+        assert best[len(x), len(y)] >= 15, (s, a1s, a1e, a2s, a2e)
+        assert comp.get(x[0]) == y[0] and comp.get(x[-1]) == y[-1]          # a local alignment starts and ends on a pair
+    assert n_ir > 50
+
+
 def test_empty_and_tiny_inputs(hip, oracle):
     from mustache_amd.records import AlignedRead, ReadSet
     reads = [AlignedRead("a", "c1", 10, 60, [(0, 50)], "A" * 50, [30] * 50, md="50")]
