@@ -647,6 +647,71 @@ __global__ __launch_bounds__(1024) void k_consfilters_mindist(ActTab A, uint32_t
     if (threadIdx.x == 0 && c2) atomicAdd(&stats[9], (uint32_t)c2);
 }
 
+// ---- result rows on the device (thousands of sites): make_dataframe findflanks.py:631-670 ---------------------------------------
+// With tens of thousands of sites the host loop that builds the site and flank rows from nine read-back arrays (and the
+// read-back of a fixed-stride block of consensus characters) costs more than a millisecond.  Then the rows are laid out
+// here: k_rows_count gives every active site its number of site rows (0/1), flank rows (0..2) and consensus bytes, two
+// scans place them, k_rows_fill writes mfk_site / mfk_flank records and the consensus characters back to back, and the host
+// copies three finished arrays.
+__global__ void k_rows_count(ActTab A, uint32_t n_act, const int32_t *cons_len, uint32_t *c_rows, uint32_t *c_bytes) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_act) return;
+    const uint32_t st = A.st[k];
+    uint32_t rows = 0, bytes = 0;
+    if (st & 4) {
+        rows = 1u;                                                  // site rows in the low 24 bits, flank rows above
+        if (st & 1) { rows += 1u << 24; bytes += (uint32_t)cons_len[2 * k]; }
+        if (st & 2) { rows += 1u << 24; bytes += (uint32_t)cons_len[2 * k + 1]; }
+    }
+    c_rows[k] = rows; c_bytes[k] = bytes;
+}
+
+// one wave per active site
+__global__ __launch_bounds__(256) void k_rows_fill(DevReads R, ActTab A, uint32_t n_act, const int32_t *cons_count, const int32_t *cons_len, const char *cons_chars, uint32_t cons_stride,
+                                                   const uint64_t *o_rows, const uint64_t *o_bytes, mfk_site *sites, mfk_flank *flanks, char *seqs) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t k = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (k >= n_act) return;
+    const uint32_t st = A.st[k];
+    if (!(st & 4)) return;
+    const uint64_t orow = o_rows[k];
+    const uint32_t so = (uint32_t)(orow & 0xFFFFFFull);
+    uint32_t fo = (uint32_t)(orow >> 24);
+    uint64_t bo = o_bytes[k];
+    const int32_t contig = A.contig[k];
+    const int32_t pos = (int32_t)((int64_t)A.gpos[k] - (int64_t)R.contig_base[contig] - 1);
+    const uint32_t *c = A.counts + 8 * (size_t)k;
+    mfk_site s;
+    s.contig_id = contig; s.pos = pos;
+    s.softclip_count_5p = (int32_t)A.cnt2[2 * k]; s.softclip_count_3p = (int32_t)A.cnt2[2 * k + 1];
+    s.runthrough_count = (int32_t)c[0]; s.small_insertion_count_5p = (int32_t)c[1]; s.small_insertion_count_3p = (int32_t)c[2];
+    s.large_insertion_count_5p = (int32_t)c[3]; s.large_insertion_count_3p = (int32_t)c[4]; s.deletion_count = (int32_t)c[5];
+    s.upstream_deletion_count = (int32_t)c[6]; s.downstream_deletion_count = (int32_t)c[7];
+    s.keep_5p = (int32_t)(st & 1); s.keep_3p = (int32_t)((st >> 1) & 1);
+    if (lane == 0) sites[so] = s;
+    for (int side = 0; side < 2; side++) {
+        if (!(st & (1u << side))) continue;   // wave-uniform
+        const size_t job = 2 * (size_t)k + side;
+        const int32_t len = cons_len[job];
+        if (lane == 0) {
+            mfk_flank f;
+            f.contig_id = contig; f.pos = pos; f.orient = side == 0 ? 5 : 3;
+            f.softclip_count_5p = s.softclip_count_5p; f.softclip_count_3p = s.softclip_count_3p; f.runthrough_count = s.runthrough_count;
+            f.small_insertion_count_5p = s.small_insertion_count_5p; f.small_insertion_count_3p = s.small_insertion_count_3p;
+            f.large_insertion_count_5p = s.large_insertion_count_5p; f.large_insertion_count_3p = s.large_insertion_count_3p;
+            f.deletion_count = s.deletion_count; f.upstream_deletion_count = s.upstream_deletion_count; f.downstream_deletion_count = s.downstream_deletion_count;
+            f.total_count = s.softclip_count_5p + s.softclip_count_3p + s.runthrough_count + s.small_insertion_count_5p + s.small_insertion_count_3p +
+                            s.large_insertion_count_5p + s.large_insertion_count_3p + s.deletion_count;   // get_total_count findflanks.py:789-795
+            f.consensus_softclip_count = cons_count[job];
+            f.seq_len = len; f.seq_off = (int64_t)bo;
+            flanks[fo] = f;
+        }
+        const char *src = cons_chars + job * cons_stride;
+        for (int d = lane; d < len; d += 64) seqs[bo + d] = src[d];
+        fo++; bo += (uint64_t)len;
+    }
+}
+
 // =====================================================================================================================
 static const char BASE_ASCII[] = "=ACMGRSVTWYHKDBN";
 
@@ -835,9 +900,53 @@ extern "C" int mfk_findflanks(mfk_ctx *ctx, const mfk_reads *reads, const mfk_pa
             uint32_t *t = A.st; A.st = st2; st2 = t;
         }
     }
+    // thousands of sites: the rows are assembled on the device
+    const bool dev_rows = stop_after >= MFK_STAGE_ALL && n_act > 2048 && n_act < (1u << 24) && io.cons_chars != nullptr;   // 24 bits of site rows in the packed scan
+    uint64_t *o_rows = nullptr, *o_bytes = nullptr; mfk_site *d_sites = nullptr; mfk_flank *d_flanks = nullptr; char *d_seqs = nullptr;
+    if (dev_rows) {
+        uint32_t *c_rows = aalloc<uint32_t>(ctx, n_act), *c_bytes = aalloc<uint32_t>(ctx, n_act);
+        o_rows = aalloc<uint64_t>(ctx, (size_t)n_act + 1); o_bytes = aalloc<uint64_t>(ctx, (size_t)n_act + 1);
+        d_sites = aalloc<mfk_site>(ctx, n_act); d_flanks = aalloc<mfk_flank>(ctx, 2 * (size_t)n_act);
+        d_seqs = aalloc<char>(ctx, 2 * (size_t)n_act * io.cons_stride + 16);
+        if (!c_rows || !c_bytes || !o_rows || !o_bytes || !d_sites || !d_flanks || !d_seqs) return 1;
+        PROF_LAUNCH(k_rows_count, dim3(nblocks(n_act, 256)), dim3(256), 0, st, A, n_act, (const int32_t *)io.cons_len, c_rows, c_bytes);
+        KCHK();
+        if (int rc = dev_excl_scan64(ctx, c_rows, o_rows, n_act)) return rc;
+        if (int rc = dev_excl_scan64(ctx, c_bytes, o_bytes, n_act)) return rc;
+        PROF_LAUNCH(k_rows_fill, dim3(nblocks(n_act, 4)), dim3(256), 0, st, R, A, n_act, (const int32_t *)io.cons_count, (const int32_t *)io.cons_len, (const char *)io.cons_chars, io.cons_stride,
+                    (const uint64_t *)o_rows, (const uint64_t *)o_bytes, d_sites, d_flanks, d_seqs);
+        KCHK();
+    }
     HIPCHK(hipEventRecord(ctx->ev1, st));
     // ---- results to the host -------------------------------------------------------------------------------------
     uint32_t h_stats[MFK_N_STATS], h_scan_err = 0;
+    if (dev_rows) {
+        uint64_t t_rows = 0, t_bytes = 0;
+        {
+            ReadBatch rb(ctx);
+            rb.add(d_stats, h_stats, sizeof h_stats);
+            rb.add(ctx->scan_err, &h_scan_err, 4);
+            if (io.err_dev) rb.add(io.err_dev, &io.err_flags, 4);
+            rb.add(o_rows + n_act, &t_rows, 8); rb.add(o_bytes + n_act, &t_bytes, 8);
+            if (int rc = rb.flush()) return rc;
+        }
+        if (int rc = check_scan_error(ctx, h_scan_err)) return rc;
+        if (io.err_flags & 2u) { snprintf(ctx->err, sizeof ctx->err, "a clipped read at a surviving site has no sequence in the pool (pack with pool='clipped')"); return 2; }
+        const size_t ns = (size_t)(t_rows & 0xFFFFFFull), nf = (size_t)(t_rows >> 24);
+        ctx->sites.resize(ns); ctx->flanks.resize(nf); ctx->seqs.resize((size_t)t_bytes);
+        {
+            ReadBatch rb(ctx);
+            rb.add(d_sites, ctx->sites.data(), ns * sizeof(mfk_site)); rb.add(d_flanks, ctx->flanks.data(), nf * sizeof(mfk_flank));
+            rb.add(d_seqs, &ctx->seqs[0], (size_t)t_bytes);
+            if (int rc = rb.flush()) return rc;
+        }
+        ht.lap("results read-back (rows made on the device)");
+        for (int i = 0; i < 10; i++) ctx->stats[i] = h_stats[i];
+        ctx->stats[12] = (int64_t)((uint64_t)h_stats[12] | ((uint64_t)h_stats[13] << 32));
+        prof_collect(ctx);
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1) == hipSuccess) ctx->last_ms = ms;
+    } else {
     std::vector<uint32_t> gpos(n_act), cnt2(2 * (size_t)n_act), stv(n_act), counts(8 * (size_t)n_act);
     std::vector<int32_t> contig(n_act);
     std::vector<int32_t> ccount, clen; std::vector<char> cchars;
@@ -903,6 +1012,7 @@ extern "C" int mfk_findflanks(mfk_ctx *ctx, const mfk_reads *reads, const mfk_pa
                 ctx->flanks.push_back(f);
             }
         }
+    }
     }
     ctx->stats[11] = (int64_t)ctx->flanks.size();
     ht.lap("host table");
