@@ -232,36 +232,42 @@ __global__ __launch_bounds__(256) void k_word_reads(DevReads R, DevParams P, Con
 
 // one thread per word: length, and where its characters are (a binary search of the pool per read: thousands of
 // independent searches in flight instead of one latency chain per wave in k_word_fill)
-__global__ void k_word_len(DevReads R, Words W, const uint32_t *n_words, CMeta *meta) {
-    uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
-    if (w >= *n_words) return;
-    int side = (int)(W.job[w] & 1);
-    int64_t r1 = W.first[w], r2 = W.second[w];
-    if (W.nextra[w] > 1) atomicOr(&meta->err, ERR_READ_NUMBER);      // findflanks.py:976-978 / 1025-1027
-    uint8_t f1 = R.flags[r1];
-    int l1 = side == 0 ? d_rlen(R, r1, f1) : d_llen(R, r1, f1), l2 = 0;
-    const int64_t p1 = d_pool_index(R, r1);
-    int64_t p2 = -1;
-    WordSrc src;
-    src.o1 = p1 >= 0 ? R.pool_off[p1] : 0; src.o2 = 0;
-    src.q1len = R.qlen[r1]; src.q2len = 0;
-    if (r2 >= 0) {
-        uint8_t f2 = R.flags[r2];
-        l2 = side == 0 ? d_rlen(R, r2, f2) : d_llen(R, r2, f2);
-        p2 = d_pool_index(R, r2);
-        src.o2 = p2 >= 0 ? R.pool_off[p2] : 0;
-        src.q2len = R.qlen[r2];
+__global__ __launch_bounds__(256) void k_word_len(DevReads R, Words W, const uint32_t *n_words, CMeta *meta) {
+    __shared__ uint32_t s_max;   // longest word of the workgroup: one atomic on meta->max_len per workgroup, not one per wave
+    if (threadIdx.x == 0) s_max = 0;
+    __syncthreads();
+    const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (w < *n_words) {
+        int side = (int)(W.job[w] & 1);
+        int64_t r1 = W.first[w], r2 = W.second[w];
+        if (W.nextra[w] > 1) atomicOr(&meta->err, ERR_READ_NUMBER);      // findflanks.py:976-978 / 1025-1027
+        uint8_t f1 = R.flags[r1];
+        int l1 = side == 0 ? d_rlen(R, r1, f1) : d_llen(R, r1, f1), l2 = 0;
+        const int64_t p1 = d_pool_index(R, r1);
+        int64_t p2 = -1;
+        WordSrc src;
+        src.o1 = p1 >= 0 ? R.pool_off[p1] : 0; src.o2 = 0;
+        src.q1len = R.qlen[r1]; src.q2len = 0;
+        if (r2 >= 0) {
+            uint8_t f2 = R.flags[r2];
+            l2 = side == 0 ? d_rlen(R, r2, f2) : d_llen(R, r2, f2);
+            p2 = d_pool_index(R, r2);
+            src.o2 = p2 >= 0 ? R.pool_off[p2] : 0;
+            src.q2len = R.qlen[r2];
+        }
+        int len = l1 > l2 ? l1 : l2;
+        if (len > MAX_WORD_LEN) { atomicOr(&meta->err, ERR_WORD_TOO_LONG); len = MAX_WORD_LEN; }
+        if (l1 > MAX_WORD_LEN) l1 = MAX_WORD_LEN;
+        if (l2 > MAX_WORD_LEN) l2 = MAX_WORD_LEN;
+        if (p1 < 0 || (r2 >= 0 && p2 < 0) || l1 > (int)src.q1len || l2 > (int)src.q2len) { atomicOr(&meta->err, ERR_NO_SEQUENCE); l1 = 0; l2 = 0; }
+        src.l1 = (uint16_t)l1; src.l2 = (uint16_t)l2;
+        W.src[w] = src;
+        W.len[w] = (uint32_t)len;
+        W.plen[w] = (uint32_t)((len + 15) & ~15);
+        atomicMax(&s_max, (uint32_t)len);
     }
-    int len = l1 > l2 ? l1 : l2;
-    if (len > MAX_WORD_LEN) { atomicOr(&meta->err, ERR_WORD_TOO_LONG); len = MAX_WORD_LEN; }
-    if (l1 > MAX_WORD_LEN) l1 = MAX_WORD_LEN;
-    if (l2 > MAX_WORD_LEN) l2 = MAX_WORD_LEN;
-    if (p1 < 0 || (r2 >= 0 && p2 < 0) || l1 > (int)src.q1len || l2 > (int)src.q2len) { atomicOr(&meta->err, ERR_NO_SEQUENCE); l1 = 0; l2 = 0; }
-    src.l1 = (uint16_t)l1; src.l2 = (uint16_t)l2;
-    W.src[w] = src;
-    W.len[w] = (uint32_t)len;
-    W.plen[w] = (uint32_t)((len + 15) & ~15);
-    atomicMax(&meta->max_len, (uint32_t)len);
+    __syncthreads();
+    if (threadIdx.x == 0 && s_max) atomicMax(&meta->max_len, s_max);
 }
 
 // clipped base / quality p of read r in trie orientation: 5p = right clip as is, 3p = left clip reversed (Q14)
@@ -286,47 +292,92 @@ __device__ __forceinline__ void d_word_char(const DevReads &R, const WordSrc &sr
     *c_out = c; *q_out = q;
 }
 
-// One wave per WF_WORDS consecutive words, lane = character.  A word is a few dozen characters: one word per wave would
-// leave the wave waiting on two dependent load round trips for 150 bytes of work.  So lane u resolves the header of the
-// wave's u-th word, and the first 128 characters of all WF_WORDS words are loaded before anything is stored.
-#define WF_WORDS 4
+// 16 bytes at [p, p + 16) of which only those inside [vlo, vhi) are known to be readable.  The two aligned 16-byte blocks
+// around the window are each loaded only if they hold a readable byte (an aligned block never leaves the allocation its
+// readable byte is in), and the window is cut out of them in registers; the bytes outside [vlo, vhi) are unspecified.
+__device__ __forceinline__ uint4 d_window16(const uint8_t *p, const uint8_t *vlo, const uint8_t *vhi) {
+    const uintptr_t a = reinterpret_cast<uintptr_t>(p), a0 = a & ~(uintptr_t)15, lo = reinterpret_cast<uintptr_t>(vlo), hi = reinterpret_cast<uintptr_t>(vhi);
+    uint4 A = make_uint4(0, 0, 0, 0), B = make_uint4(0, 0, 0, 0);
+    if (a0 + 16 > lo && a0 < hi) A = *reinterpret_cast<const uint4 *>(a0);
+    if (a0 + 32 > lo && a0 + 16 < hi) B = *reinterpret_cast<const uint4 *>(a0 + 16);
+    const uint32_t sh = (uint32_t)(a & 15), sb = sh & 3u;
+    const bool s1 = sh & 4u, s2 = sh & 8u;
+    const uint32_t d[8] = {A.x, A.y, A.z, A.w, B.x, B.y, B.z, B.w};
+    uint32_t t[7], e[5];
+#pragma unroll
+    for (int i = 0; i < 7; i++) t[i] = s1 ? d[i + 1] : d[i];
+#pragma unroll
+    for (int i = 0; i < 5; i++) e[i] = s2 ? t[i + 2] : t[i];
+    return make_uint4(__builtin_amdgcn_alignbyte(e[1], e[0], sb), __builtin_amdgcn_alignbyte(e[2], e[1], sb),
+                      __builtin_amdgcn_alignbyte(e[3], e[2], sb), __builtin_amdgcn_alignbyte(e[4], e[3], sb));
+}
+// four packed bytes (two base codes each, the first in the high nibble) -> eight characters, one code per byte
+__device__ __forceinline__ void d_unpack8(uint32_t pk, uint32_t *c0, uint32_t *c1) {
+    const uint32_t l = pk & 0xFFFFu, h = pk >> 16;
+    const uint32_t x = (l | (l << 8)) & 0x00FF00FFu, y = (h | (h << 8)) & 0x00FF00FFu;
+    *c0 = ((x >> 4) & 0x000F000Fu) | ((x & 0x000F000Fu) << 8);
+    *c1 = ((y >> 4) & 0x000F000Fu) | ((y & 0x000F000Fu) << 8);
+}
+__device__ __forceinline__ uint32_t d_bswap(uint32_t x) { return __builtin_amdgcn_perm(x, x, 0x00010203u); }
+
+// A lane fills 16 characters (and their qualities) of a word; a wave takes WF_WORDS consecutive words, four lanes each
+// (chunks c, c + 4, ...: words of up to 64 characters in one step).  The source of a chunk is 16 consecutive quality bytes
+// and 16 consecutive 4-bit base codes of ONE read (the usual word: one read clipped here; 3p words are read backwards), so
+// the lane fetches them with aligned 16-byte loads, i.e. a wave has 64 x 4 such loads in flight instead of byte loads.
+// A word merged from both mates of a pair (both clipped at this site, findflanks.py:932-1027) goes character by character.
+#define WF_WORDS 16
 __global__ __launch_bounds__(256) void k_word_fill(DevReads R, Words W) {
-    const uint32_t wbase = (blockIdx.x * 4 + (threadIdx.x >> 6)) * WF_WORDS;
-    const int lane = threadIdx.x & 63;
-    if (wbase >= W.n) return;
-    WordSrc m_src; m_src.o1 = 0; m_src.o2 = 0; m_src.l1 = 0; m_src.l2 = 0; m_src.q1len = 0; m_src.q2len = 0;
-    uint32_t m_off = 0, m_len = 0, m_plen = 0, m_side = 0;
-    if (lane < WF_WORDS && wbase + lane < W.n) {
-        const uint32_t w = wbase + lane;
-        m_src = W.src[w]; m_off = (uint32_t)W.off[w]; m_len = W.len[w]; m_plen = W.plen[w]; m_side = W.job[w] & 1u;
-    }
-    WordSrc src[WF_WORDS];
-    uint32_t off[WF_WORDS]; int len[WF_WORDS], plen[WF_WORDS], side[WF_WORDS];
-    uint8_t c[WF_WORDS][2], q[WF_WORDS][2];
+    const uint32_t w = (blockIdx.x * 4 + (threadIdx.x >> 6)) * WF_WORDS + ((threadIdx.x & 63) >> 2);
+    if (w >= W.n) return;
+    const WordSrc src = W.src[w];
+    const uint32_t off = (uint32_t)W.off[w];
+    const int len = (int)W.len[w], plen = (int)W.plen[w], side = (int)(W.job[w] & 1u);
+    uint4 *ch = reinterpret_cast<uint4 *>(W.ch + off), *qo = reinterpret_cast<uint4 *>(W.q + off);
+    for (int ck = (int)(threadIdx.x & 3); 16 * ck < plen; ck += 4) {
+        const int p0 = 16 * ck;
+        uint32_t c[4], q[4];
+        if (src.l2 == 0 && len > 0) {
+            const int l1 = (int)src.l1;   // = len
+            // window of the read, in read coordinates: 5p = right clip as is, 3p = left clip backwards (Q14)
+            const int64_t s = side == 0 ? (int64_t)src.q1len - l1 + p0 : (int64_t)l1 - 16 - p0;
+            const uint8_t *qbase = R.pool_quals + src.o1, *bbase = R.pool_bases + (src.o1 >> 1);   // pool offsets are even
+            const uint4 qw = d_window16(qbase + s, qbase, qbase + src.q1len);
+            const int64_t bs = s >> 1;    // floor: s is negative when a 3p word ends inside this chunk
+            const uint4 bw = d_window16(bbase + bs, bbase, bbase + ((src.q1len + 1) >> 1));
+            uint32_t p0w = bw.x, p1w = bw.y;
+            if (s & 1) {   // the window starts at the low nibble of its first byte: move the nibble stream up by one
+                p0w = ((bw.x << 4) & 0xF0F0F0F0u) | ((__builtin_amdgcn_alignbyte(bw.y, bw.x, 1) >> 4) & 0x0F0F0F0Fu);
+                p1w = ((bw.y << 4) & 0xF0F0F0F0u) | ((__builtin_amdgcn_alignbyte(bw.z, bw.y, 1) >> 4) & 0x0F0F0F0Fu);
+            }
+            d_unpack8(p0w, &c[0], &c[1]);
+            d_unpack8(p1w, &c[2], &c[3]);
+            q[0] = qw.x; q[1] = qw.y; q[2] = qw.z; q[3] = qw.w;
+            if (side) {
+                const uint32_t c0 = d_bswap(c[3]), c1 = d_bswap(c[2]), c2 = d_bswap(c[1]), c3 = d_bswap(c[0]);
+                c[0] = c0; c[1] = c1; c[2] = c2; c[3] = c3;
+                const uint32_t q0 = d_bswap(q[3]), q1 = d_bswap(q[2]), q2 = d_bswap(q[1]), q3 = d_bswap(q[0]);
+                q[0] = q0; q[1] = q1; q[2] = q2; q[3] = q3;
+            }
+            const int n = len - p0;   // characters of the word in this chunk (>= 1); the rest is padding: 0xFF / quality 0
 #pragma unroll
-    for (int u = 0; u < WF_WORDS; u++) {
-        src[u].o1 = ((uint64_t)__shfl((uint32_t)(m_src.o1 >> 32), u, 64) << 32) | (uint64_t)__shfl((uint32_t)m_src.o1, u, 64);
-        src[u].o2 = ((uint64_t)__shfl((uint32_t)(m_src.o2 >> 32), u, 64) << 32) | (uint64_t)__shfl((uint32_t)m_src.o2, u, 64);
-        const uint32_t ll = __shfl((uint32_t)m_src.l1 | ((uint32_t)m_src.l2 << 16), u, 64), qq = __shfl((uint32_t)m_src.q1len | ((uint32_t)m_src.q2len << 16), u, 64);
-        src[u].l1 = (uint16_t)ll; src[u].l2 = (uint16_t)(ll >> 16); src[u].q1len = (uint16_t)qq; src[u].q2len = (uint16_t)(qq >> 16);
-        off[u] = __shfl(m_off, u, 64); len[u] = (int)__shfl(m_len, u, 64); plen[u] = (int)__shfl(m_plen, u, 64); side[u] = (int)__shfl(m_side, u, 64);
+            for (int i = 0; i < 4; i++) {
+                const int vb = n - 4 * i;
+                const uint32_t m = vb >= 4 ? 0xFFFFFFFFu : (vb <= 0 ? 0u : (1u << (8 * vb)) - 1u);
+                c[i] = (c[i] & m) | ~m; q[i] &= m;
+            }
+        } else {
 #pragma unroll
-        for (int h = 0; h < 2; h++) {
-            const int p = lane + 64 * h;
-            c[u][h] = 0xFF; q[u][h] = 0;
-            if (p < plen[u]) d_word_char(R, src[u], side[u], len[u], p, &c[u][h], &q[u][h]);
+            for (int i = 0; i < 4; i++) {
+                c[i] = 0; q[i] = 0;
+                for (int b = 0; b < 4; b++) {
+                    uint8_t cc, qv;
+                    d_word_char(R, src, side, len, p0 + 4 * i + b, &cc, &qv);
+                    c[i] |= (uint32_t)cc << (8 * b); q[i] |= (uint32_t)qv << (8 * b);
+                }
+            }
         }
-    }
-#pragma unroll
-    for (int u = 0; u < WF_WORDS; u++) {
-        uint8_t *ch = W.ch + off[u], *qo = W.q + off[u];
-#pragma unroll
-        for (int h = 0; h < 2; h++) { const int p = lane + 64 * h; if (p < plen[u]) { ch[p] = c[u][h]; qo[p] = q[u][h]; } }
-        for (int p = lane + 128; p < plen[u]; p += 64) {   // clips longer than 128 bases
-            uint8_t cc, qv;
-            d_word_char(R, src[u], side[u], len[u], p, &cc, &qv);
-            ch[p] = cc; qo[p] = qv;
-        }
+        ch[ck] = make_uint4(c[0], c[1], c[2], c[3]);
+        qo[ck] = make_uint4(q[0], q[1], q[2], q[3]);
     }
 }
 
@@ -1477,9 +1528,9 @@ __global__ __launch_bounds__(SJ_THREADS) void k_job_small(DevParams P, Words W, 
         }
     }
     __syncthreads();
-    if (io.work) {
-        for (int o2 = 32; o2 > 0; o2 >>= 1) limb_steps += __shfl_xor(limb_steps, o2, 64);
-        if (lane == 0 && limb_steps) atomicAdd(io.work, (unsigned long long)limb_steps);
+    if (io.work) {   // one atomic per job (and none for a job without an edit distance), not one per wave
+        const uint32_t all = sj_block_sum(limb_steps, s_red);
+        if (tid == 0 && all) atomicAdd(io.work, (unsigned long long)all);
     }
     if ((uint32_t)tid < NL) {
         bool any = false;
@@ -1789,7 +1840,7 @@ int run_consensus(mfk_ctx *ctx, const DevReads &R, const DevParams &P, Consensus
     { ReadBatch rb(ctx); rb.add(n_words_p, &Wn, 4); rb.add(J.adj_off + J.n, &adj_total, 8); rb.add(meta, &hm, sizeof hm); rb.add(W.off + E, &total_chars, 8); if (int rc = rb.flush()) return rc; }
     if (Wn == 0) return 0;
     W.n = Wn;
-    const unsigned ww = nblocks(Wn, 4 * WF_WORDS);
+    const unsigned ww = nblocks(Wn, 4 * WF_WORDS);   // four waves of WF_WORDS words
     if (hm.err & ERR_READ_NUMBER) { snprintf(ctx->err, sizeof ctx->err, "READ NUMBER ERROR - ZERO OR MORE THAN TWO READS ASSOCIATED WITH QUERY NAME"); return 3; }
     if (hm.err & ERR_NO_SEQUENCE) { snprintf(ctx->err, sizeof ctx->err, "a clipped read at a surviving site has no sequence in the pool (pack with pool='clipped')"); return 2; }
     if (hm.err & ERR_WORD_TOO_LONG) { snprintf(ctx->err, sizeof ctx->err, "soft clip longer than %d bases: not supported by this build", MAX_WORD_LEN); return 6; }
