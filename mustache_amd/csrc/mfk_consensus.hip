@@ -18,6 +18,7 @@
 // All pairwise work (LCP, bit-parallel Myers edit distance) is spread over the whole GPU; words live in an 8-byte
 // aligned byte pool so LCPs are 64-bit XOR + count-trailing-zeros.
 #include "mfk_host.h"
+#include <type_traits>
 #include <stdlib.h>
 
 #define MAX_WORD_LEN 512
@@ -1265,7 +1266,10 @@ extern "C" int mfk_debug_sj(unsigned long long *out) {
 #else
 #define SJ_T(i) do { } while (0)
 #endif
-__global__ __launch_bounds__(SJ_THREADS) void k_job_small(DevParams P, Words W, Jobs J, ConsensusIO io, CMeta *meta, uint32_t lds_bytes, int pass) {
+#ifndef SJ_WAVES
+#define SJ_WAVES 4
+#endif
+__global__ __launch_bounds__(SJ_THREADS) __attribute__((amdgpu_waves_per_eu(SJ_WAVES, SJ_WAVES))) void k_job_small(DevParams P, Words W, Jobs J, ConsensusIO io, CMeta *meta, uint32_t lds_bytes, int pass) {
     extern __shared__ __align__(16) unsigned char smem[];
     // static LDS is part of every workgroup's footprint (four workgroups per CU: 40 KB each): indices and lengths are bytes
     // (at most SJ_MAX_R = 256 words of at most SJ_MAX_LEN = 255 characters)
@@ -1290,7 +1294,7 @@ __global__ __launch_bounds__(SJ_THREADS) void k_job_small(DevParams P, Words W, 
 #define SJ_FAIL(permanent)                                                                                          \
     do {                                                                                                            \
         if (tid == 0) {                                                                                             \
-            if ((permanent) || pass != 0) { J.Rbig[job] = R; atomicAdd(&meta->n_big, 1u); }                         \
+            if ((permanent) || pass == 2) { J.Rbig[job] = R; atomicAdd(&meta->n_big, 1u); }                         \
             else { J.Rbig[job] = R | 0x80000000u; atomicAdd(&meta->n_retry, 1u); }                                  \
         }                                                                                                           \
         return;                                                                                                     \
@@ -1695,12 +1699,21 @@ __global__ __launch_bounds__(SJ_THREADS) void k_job_small(DevParams P, Words W, 
         const uint32_t dsh = maxd <= 64 ? 6u : (maxd <= 128 ? 7u : 8u), D = 1u << dsh, nparts = SJ_THREADS >> dsh;
         const uint32_t d = (uint32_t)tid & (D - 1u), pi = (uint32_t)tid >> dsh;
         const uint32_t per = ((R + nparts - 1u) / nparts + 7u) & ~7u, vb = pi * per, ve = vb + per < R ? vb + per : R;
+        // the qualities of the job's words: into LDS behind the tables when there is room (one round of 16-byte loads for the
+        // whole workgroup; the loop below then waits for LDS only), else every step fetches its eight bytes from memory
         const uint8_t *gq = W.q + goff0;
+        const bool q_lds = o + C <= lds_bytes;   // block-uniform
+        if (q_lds) {
+            uint4 *ql = reinterpret_cast<uint4 *>(smem + o);
+            const uint4 *qsrc = reinterpret_cast<const uint4 *>(gq);
+            for (uint32_t i = tid; i < (C >> 4); i += SJ_THREADS) ql[i] = qsrc[i];
+        }
+        const uint32_t qo = o;
         __syncthreads();
         SJ_T(10);   // reach of the winner
         unsigned long long qacc = 0, cacc = 0;
         uint32_t rare = 0;   // bit c: base code c (not A, C, G, T) met at this depth
-        if (d < maxd)
+        auto sums = [&](auto in_lds) {
             for (uint32_t v0 = vb; v0 < ve; v0 += 8) {
                 const uint4 w0 = *reinterpret_cast<const uint4 *>(&s_wr[v0]), w1 = *reinterpret_cast<const uint4 *>(&s_wr[v0 + 4]);
                 const uint32_t wr[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
@@ -1709,7 +1722,8 @@ __global__ __launch_bounds__(SJ_THREADS) void k_job_small(DevParams P, Words W, 
                 for (int u = 0; u < 8; u++) {
                     uint32_t co = ((wr[u] >> 8) << 4) + d;
                     co = co < C ? co : 0u;
-                    c[u] = ch[co]; q[u] = gq[co];
+                    c[u] = ch[co];
+                    if constexpr (decltype(in_lds)::value) q[u] = smem[qo + co]; else q[u] = gq[co];
                 }
 #pragma unroll
                 for (int u = 0; u < 8; u++) {
@@ -1722,6 +1736,8 @@ __global__ __launch_bounds__(SJ_THREADS) void k_job_small(DevParams P, Words W, 
                     rare |= (cc < 16u && !pw2) ? 1u << cc : 0u;
                 }
             }
+        };
+        if (d < maxd) { if (q_lds) sums(std::true_type{}); else sums(std::false_type{}); }
         if (rare) atomicOr(&s_other, (int)rare);
         if (pi) { part[2 * ((pi - 1u) * D + d)] = qacc; part[2 * ((pi - 1u) * D + d) + 1] = cacc; }
         __syncthreads();
@@ -1744,7 +1760,7 @@ __global__ __launch_bounds__(SJ_THREADS) void k_job_small(DevParams P, Words W, 
                     const uint32_t w = s_wr[v];
                     if ((w & 0xFFu) <= d) continue;
                     const uint32_t co = ((w >> 8) << 4) + d;
-                    if (((uint32_t)ch[co] & 15u) == cx) { xq += gq[co]; xc++; }
+                    if (((uint32_t)ch[co] & 15u) == cx) { xq += q_lds ? (uint32_t)smem[qo + co] : (uint32_t)gq[co]; xc++; }
                 }
                 if (!xc) continue;
                 if (best < 0 || xq > bq) { best = (int)cx; nbest = 1; bq = xq; }
@@ -1873,12 +1889,19 @@ int run_consensus(mfk_ctx *ctx, const DevReads &R, const DevParams &P, Consensus
                 ctx->sj_static = (uint32_t)fa.sharedSizeBytes;
                 ctx->sj_attr = true;
             }
-            const uint32_t lds0 = ctx->sj_static + 8192 < 40960 ? ((40960 - ctx->sj_static) & ~255u) : 32 * 1024;
-            PROF_LAUNCH(k_job_small, dim3(J.n), dim3(SJ_THREADS), lds0, st, P, W, J, io, meta, lds0, 0);
-            KCHK();
-            if (int rc = read_back(ctx, meta, &hm, sizeof hm)) return rc;
-            if (hm.n_retry) {
-                PROF_LAUNCH(k_job_small, dim3(J.n), dim3(SJ_THREADS), lds1, st, P, W, J, io, meta, lds1, 1);
+            // Three rungs: SJ_WAVES workgroups per CU (nearly every site-side of a 200x sample fits), then four per CU for the
+            // few that need up to 40 KB, then one per CU with 128 KB.  A job that fails on a rung for want of LDS is marked in
+            // J.Rbig (bit 31) and counted in n_retry; the next rung runs only those.
+            const uint32_t per_wg = (160u * 1024u / SJ_WAVES) & ~255u;
+            const uint32_t rung[3] = {ctx->sj_static + 8192 < per_wg ? ((per_wg - ctx->sj_static) & ~255u) : 32 * 1024,
+                                      ctx->sj_static + 8192 < 40960 ? ((40960 - ctx->sj_static) & ~255u) : 32 * 1024, lds1};
+            for (int pass = 0; pass < 3; pass++) {
+                if (pass == 1 && rung[1] <= rung[0]) continue;   // the first rung already is four per CU
+                if (pass > 0) {
+                    if (!hm.n_retry) break;
+                    HIPCHK(hipMemsetAsync(&meta->n_retry, 0, 4, st));
+                }
+                PROF_LAUNCH(k_job_small, dim3(J.n), dim3(SJ_THREADS), rung[pass], st, P, W, J, io, meta, rung[pass], pass);
                 KCHK();
                 if (int rc = read_back(ctx, meta, &hm, sizeof hm)) return rc;
             }
