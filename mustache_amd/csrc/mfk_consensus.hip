@@ -28,7 +28,7 @@
 
 struct CMeta {          // small device struct the host reads back once
     uint32_t err, max_len, max_R, n_big;   // n_big: jobs k_job_small left to the device-wide kernels
-    uint32_t n_retry, pad[3];              // jobs that did not fit the first LDS budget of k_job_small
+    uint32_t n_retry, n_small, pad[2];     // n_retry: jobs that did not fit an LDS rung of k_job_small; n_small: jobs of 1..SJ_MAX_R words
 };
 
 // per trie node: quality sum (low 40 bits) and #words through the node (high 24 bits) in ONE 64-bit word, so that a node
@@ -122,6 +122,7 @@ __device__ __forceinline__ int d_hamming16(const uint8_t *a, const uint8_t *b, i
     return hd;
 }
 
+#define SJ_MAX_R 256
 // ---- words ------------------------------------------------------------------------------------------------------
 // words of a job = the first reads of the distinct query names of its site-side, i.e. the events with info bit 2: their
 // number is the site's distinct-name count (k_site_accumulate), so the word ranges come from a scan over the job slots
@@ -136,6 +137,7 @@ __global__ void k_job_meta(ConsensusIO io, Jobs J, CMeta *meta) {
     J.R[j] = R; J.nl[j] = 0; J.best[j] = 0xFFFFFFFFu;
     J.adj_words[j] = R * ((R + 31) >> 5);
     if (R) atomicMax(&meta->max_R, R);
+    if (R && R <= SJ_MAX_R) atomicAdd(&meta->n_small, 1u);
 }
 
 // k_job_meta and the two scans over the job slots (first word, first adjacency word) in ONE launch of one workgroup: up to
@@ -144,7 +146,7 @@ __global__ void k_job_meta(ConsensusIO io, Jobs J, CMeta *meta) {
 __global__ __launch_bounds__(1024) void k_job_meta_scan(ConsensusIO io, Jobs J, CMeta *meta) {
     __shared__ uint32_t sh[16];
     __shared__ unsigned long long sh64[16];
-    uint32_t run32 = 0, maxR = 0;
+    uint32_t run32 = 0, maxR = 0, nsmall = 0;
     unsigned long long run64 = 0;
     for (uint32_t base = 0; base < J.n; base += blockDim.x) {   // block-uniform
         const uint32_t j = base + threadIdx.x;
@@ -161,11 +163,13 @@ __global__ __launch_bounds__(1024) void k_job_meta_scan(ConsensusIO io, Jobs J, 
             J.R[j] = R; J.nl[j] = 0; J.best[j] = 0xFFFFFFFFu; J.adj_words[j] = aw;
             J.w0[j] = run32 + o32; J.adj_off[j] = run64 + o64;
             if (R > maxR) maxR = R;
+            if (R && R <= SJ_MAX_R) nsmall++;
         }
         run32 += tot32; run64 += tot64;
         __syncthreads();
     }
     if (maxR) atomicMax(&meta->max_R, maxR);
+    if (nsmall) atomicAdd(&meta->n_small, nsmall);
     if (threadIdx.x == 0) { J.w0[J.n] = run32; J.adj_off[J.n] = run64; }
 }
 
@@ -1186,7 +1190,6 @@ __global__ __launch_bounds__(256) void k_job_best(DevParams P, Words W, Jobs J, 
 // than SJ_MAX_LEN, tables beyond the LDS budget of the launch) is left to a second launch with a larger budget or to the
 // device-wide kernels: J.Rbig says which.
 #define SJ_THREADS 256
-#define SJ_MAX_R 256
 #define SJ_MAX_LEN 255
 
 __device__ __forceinline__ int d_lcp16(const uint8_t *a, int la, const uint8_t *b, int lb) {
@@ -1875,9 +1878,9 @@ int run_consensus(mfk_ctx *ctx, const DevReads &R, const DevParams &P, Consensus
     {
         const char *ns_env = getenv("MFK_NO_SMALL_JOBS");   // test hook: everything through the device-wide kernels
         const bool no_small = ns_env && *ns_env && *ns_env != '0';
-        if (no_small) {
+        if (no_small || !hm.n_small) {   // (no job of 1..SJ_MAX_R words, e.g. a deep isolate: no launch, no read-back)
             hm.n_big = 1;
-            HIPCHK(hipMemcpyAsync(J.Rbig, J.R, (size_t)J.n * 4, hipMemcpyDeviceToDevice, st));
+            J.Rbig = J.R;   // every job goes to the device-wide kernels
         } else {
             // first pass: four workgroups per CU (160 KB of LDS, 128 VGPRs per lane: four waves per SIMD): 40 KB each, static part
             // included; nearly every site-side of a 200x sample needs 16-28 KB.  Second pass, for the few that need more: 128 KB.

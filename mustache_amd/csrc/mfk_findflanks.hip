@@ -232,7 +232,14 @@ __global__ __launch_bounds__(256) void k_clip_events_bkt(DevReads R, DevParams P
 #define DEEP_MAX 60
 struct DeepBuckets { uint16_t n, last; uint16_t id[DEEP_MAX]; };
 #define BSORT_THREADS 512
-__global__ __launch_bounds__(BSORT_THREADS) void k_bucket_sort(const uint64_t *bkt, const uint32_t *bkt_count, uint32_t B, uint64_t *out, DeepBuckets D) {
+// With the sorted keys of a whole position range in LDS the per-event information (k_event_info below, which the list +
+// device-wide sort path still uses) costs almost no memory traffic here: an event is the first of its query name at its
+// site-side unless an EARLIER event of the same site-side belongs to a read of its link chain, and "same site-side" is a
+// run of neighbours in this bucket.  So an event with no such neighbour before it (every stray one-read clip, two thirds of
+// all events of a deep isolate) fetches nothing but its CIGAR-end length, and the others look their chain reads up by binary
+// search in LDS instead of gathering six per-read arrays of the mate.
+__global__ __launch_bounds__(BSORT_THREADS) void k_bucket_sort(const uint64_t *bkt, const uint32_t *bkt_count, uint32_t B, uint64_t *out, DeepBuckets D,
+                                                               DevReads R, DevParams P, uint8_t *info, uint32_t *head) {
     __shared__ uint64_t keys[BKT_CAP];
     __shared__ uint32_t red[BSORT_THREADS / 64];
     const bool listed = blockIdx.x < D.n;
@@ -275,7 +282,32 @@ __global__ __launch_bounds__(BSORT_THREADS) void k_bucket_sort(const uint64_t *b
             }
         __syncthreads();
     }
-    for (uint32_t i = threadIdx.x; i < n; i += BSORT_THREADS) out[base + i] = keys[i];
+    for (uint32_t i = threadIdx.x; i < n; i += BSORT_THREADS) {
+        const uint64_t key = keys[i];
+        out[base + i] = key;
+        // info bits as in k_event_info.  All events of a position are in this bucket, so the bucket's first key starts a site.
+        const uint32_t gpos = (uint32_t)(key >> 32);
+        const int side = (int)((key >> 31) & 1);
+        const int64_t r = (int64_t)(key & 0x7fffffffu);
+        const bool h = i == 0 || (uint32_t)(keys[i - 1] >> 32) != gpos;
+        bool first = true;
+        if (i > 0 && (keys[i - 1] >> 31) == (key >> 31)) {   // there are earlier events of this site-side
+            const uint64_t run_key = key & ~(uint64_t)0x7fffffffu;
+            uint32_t lb = 0;
+            { uint32_t hi = i; while (lb < hi) { const uint32_t m = (lb + hi) >> 1; if (keys[m] < run_key) lb = m + 1; else hi = m; } }
+            int64_t prev = r;
+            for (int64_t q = R.link[r]; q >= 0 && q < prev; prev = q, q = R.link[q]) {   // strictly decreasing chain
+                // read q has a clip event here (d_clip_event true at this gpos) iff its key is in the run
+                const uint64_t want = run_key | (uint64_t)q;
+                uint32_t a = lb, b = i;
+                while (a < b) { const uint32_t m = (a + b) >> 1; if (keys[m] < want) a = m + 1; else b = m; }
+                if (a < i && keys[a] == want) { first = false; break; }
+            }
+        }
+        const bool meets = side == 0 ? ((int)R.last_op_len[r] >= P.minlen) : ((int)R.first_op_len[r] >= P.minlen);
+        info[base + i] = (uint8_t)((h ? 1 : 0) | (first ? 2 : 0) | (meets ? 4 : 0) | (side ? 8 : 0));
+        head[base + i] = h ? 1u : 0u;
+    }
 }
 
 // ---- K2: per-event information ---------------------------------------------------------------------------------
@@ -813,12 +845,14 @@ extern "C" int mfk_findflanks(mfk_ctx *ctx, const mfk_reads *reads, const mfk_pa
         if (bucketed) {
             DeepBuckets D; D.n = 0; D.last = 0;
             for (uint32_t b = 0; b < B && D.n < DEEP_MAX; b++) if (h_bkt[b] > DEEP_MIN) { D.id[D.n++] = (uint16_t)b; D.last = (uint16_t)b; }
-            PROF_LAUNCH(k_bucket_sort, dim3(B + D.n), dim3(BSORT_THREADS), 0, st, (const uint64_t *)bkt, (const uint32_t *)bkt_count, B, ev_sorted, D);
+            PROF_LAUNCH(k_bucket_sort, dim3(B + D.n), dim3(BSORT_THREADS), 0, st, (const uint64_t *)bkt, (const uint32_t *)bkt_count, B, ev_sorted, D, R, P, ev_info, head);
             KCHK();
         } else if (int rc = dev_sort_keys64(ctx, ev, ev_sorted, E, 0, 64)) return rc;
         const unsigned eb = nblocks(E, 256);
-        PROF_LAUNCH(k_event_info, dim3(eb), dim3(256), 0, st, R, P, (const uint64_t *)ev_sorted, E, ev_info, head);
-        KCHK();
+        if (!bucketed) {   // (the bucket sort has written the per-event information itself)
+            PROF_LAUNCH(k_event_info, dim3(eb), dim3(256), 0, st, R, P, (const uint64_t *)ev_sorted, E, ev_info, head);
+            KCHK();
+        }
         if (int rc = dev_excl_scan32(ctx, head, head_scan, E)) return rc;
         n_sites_p = head_scan + E;
         HIPCHK(hipStreamWaitEvent(st, ctx->ev_fill, 0));
