@@ -300,6 +300,7 @@ def main():
     ap.add_argument("--pool", default="all", choices=["all", "near"], help="'near' picks the pooled reads with the simulated truth (quicker to generate; not for reported numbers)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-insertions", type=int, default=20)
+    ap.add_argument("--merge", choices=["library", "torch"], default="library", help="N > 1: all-gather of the tables inside libmfk.so (RCCL) or through torch.distributed")
     ap.add_argument("--dump-profile", default=None, help="write the per-kernel table to this file")
     ap.add_argument("--isolates", type=int, default=12, help="isolates per GPU of --config C4_ecoli_batch (96 over 8 GPUs)")
     ap.add_argument("--table-configs", default="C1_ecoli_100x,C3_klebsiella,C4_ecoli_batch,C5_meta_50mb",
@@ -348,6 +349,17 @@ def main():
     from mustache_amd import cohort, dist as mdist
     from mustache_amd.findflanks import device_reads
     hip = lib.load(local_rank)
+    merge = "none (one rank)"
+    lib_merge = None
+    if world > 1:
+        merge = "torch.distributed all_gather (host-staged)"
+        if args.merge == "library":
+            try:                                  # the same outcome on every rank: same image, same library
+                mdist.init_library_comm(hip)
+                lib_merge = hip
+                merge = "mfk_allgather_sites (RCCL inside libmfk.so, one ncclAllGather per table)"
+            except Exception as e:                # noqa: BLE001 -- reported in the JSON line, the run goes on with torch.distributed
+                merge += "; library communicator failed: %s" % e
     plan = None
     if sharded:
         h = mdist.halo(params.min_distance_to_mate, params.max_direct_repeat_length)
@@ -370,9 +382,9 @@ def main():
         if batch is not None:
             per_sample = cohort.split_flanks(batch, ff)          # per-isolate tables, as the per-sample runs give them
             if world > 1:
-                cohort.cohort_table(per_sample, sample_numbers=[rank * args.isolates + i for i in range(args.isolates)], device=device)
+                cohort.cohort_table(per_sample, sample_numbers=[rank * args.isolates + i for i in range(args.isolates)], device=device, binding=lib_merge)
         elif world > 1:
-            mdist.allgather_flanks(ff["flanks"], ff["seqs"], device)
+            mdist.allgather_flanks(ff["flanks"], ff["seqs"], device, binding=lib_merge)
         return ff, pf
 
     for _ in range(args.warmup):
@@ -465,7 +477,7 @@ def main():
                           "isolates_per_gpu": args.isolates if batch is not None else 1,
                           "coverage": cfg["coverage"], "read_length": 150, "insertions": n_insertions,
                           "flank_rows": int(len(ff["flanks"])), "pairs": int(len(pf["pairs"])),
-                          "sharding": {"sample": "sample per GPU", "coordinate": "coordinate ranges of one data set, halo 69", "contig": "whole contigs of one data set"}[args.sharding],
+                          "sharding": {"sample": "sample per GPU", "coordinate": "coordinate ranges of one data set, halo 69", "contig": "whole contigs of one data set"}[args.sharding], "merge": merge,
                           "pool": "every read carries its bases (no use of the simulated truth)" if args.pool == "all" else "clipped reads + reads near the simulated insertions (uses the truth)",
                           "device_ms_per_step": round(dev_ms, 4) if dev_ms else None, "generate_s": round(gen_s, 1)},
                "roofline": roofline, "cpu_baseline": cpu}

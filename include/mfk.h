@@ -254,6 +254,29 @@ int mfk_inferseq_pairs_fetch(mfk_ctx *ctx, int32_t *forward, int32_t *reverse);
 int mfk_inferseq_db_pairs(mfk_ctx *ctx, const mfk_aln *alns, int64_t n, double min_perc_identity, double max_internal_softclip_prop,
                           int64_t max_edge_distance, int64_t *n_pairs);
 
+/* multi-GPU merge: all-gather of one table per rank over RCCL (xGMI inside a node).  NO COUNTERPART IN THE REFERENCE: its
+ * processes never communicate (the Snakemake workflow schedules independent jobs, workflow/Snakefile); this is the one
+ * exchange step of the sharded path: the flank tables of the coordinate / contig shards before
+ * pairflanks, the pair tables after it, or the per-sample site tables of a cohort.  RCCL is bound at run time (dlopen; a copy
+ * already in the process, e.g. PyTorch's, is reused), so libmfk.so has no link-time dependency on it.
+ *   mfk_comm_unique_id: rank 0 makes the 128-byte id; the caller hands it to every rank by its own means
+ *                       (torch.distributed broadcast, MPI, a file).
+ *   mfk_comm_init:      collective; one communicator per ctx, on the ctx's device and stream.  world = 1 is allowed.
+ *   mfk_allgather_sites: collective.  rows: n_rows records of row_bytes bytes (any fixed-width table: mfk_site, mfk_flank,
+ *                       mfk_pair), blob: their string bytes; both HOST buffers (the tables of this ABI are host tables).
+ *                       Every rank sends a 16-byte header + rows + blob padded to pad_bytes (<= 0: 256 KB) in ONE
+ *                       ncclAllGather; a second one with the true maximum follows only if some table did not fit.
+ *                       counts (2 x world, may be NULL): rows and blob bytes of every rank.
+ *   mfk_allgather_fetch: copies rank r's rows / blob of the last gather (either pointer may be NULL).
+ * Return code 101 = an RCCL call failed, 102 = librccl.so could not be loaded (message in mfk_last_error). */
+#define MFK_COMM_ID_BYTES 128
+int mfk_comm_unique_id(mfk_ctx *ctx, void *id128);
+int mfk_comm_init(mfk_ctx *ctx, const void *id128, int rank, int world);
+int mfk_comm_free(mfk_ctx *ctx);
+int mfk_allgather_sites(mfk_ctx *ctx, const void *rows, int64_t n_rows, int32_t row_bytes, const void *blob, int64_t blob_bytes,
+                        int64_t pad_bytes, int64_t *counts);
+int mfk_allgather_fetch(mfk_ctx *ctx, int rank, void *rows, void *blob);
+
 /* time spent in device work of the last compute call, milliseconds (HIP events on the ctx stream) */
 double mfk_last_device_ms(mfk_ctx *ctx);
 

@@ -180,10 +180,11 @@ def pairflanks_batch(binding, batch, reads_struct, params, per_sample_flanks, ge
     return split_pairs(batch, res, first_row)
 
 
-def cohort_table(per_sample, sample_numbers=None, device=None):
+def cohort_table(per_sample, sample_numbers=None, device=None, binding=None):
     """All-gather of the candidate sites of every rank's samples: rows carry ``sample << 16 | contig`` in contig_id
     (sample = global sample number, ``sample_numbers[k]`` for this rank's k-th table; default 0, 1, ...).  Returns
-    (rows, seqs) in rank order; without torch.distributed it is this rank's table."""
+    (rows, seqs) in rank order; without torch.distributed it is this rank's table.  With `binding` (a library context whose
+    communicator is up, dist.init_library_comm) the gather is mfk_allgather_sites inside libmfk.so."""
     from .dist import allgather_flanks
     rows, blobs, off = [], [], 0
     for s, t in enumerate(per_sample):
@@ -199,4 +200,4 @@ def cohort_table(per_sample, sample_numbers=None, device=None):
         blobs.append(bytes(t["seqs"]))
         off += len(t["seqs"])
     mine = np.concatenate(rows) if rows else np.zeros(0, dtype=_lib.FLANK_DTYPE)
-    return allgather_flanks(mine, b"".join(blobs), device)
+    return allgather_flanks(mine, b"".join(blobs), device, binding=binding)

@@ -59,6 +59,9 @@ struct mfk_ctx {
     uint32_t sj_static;             // its static LDS in bytes (the first pass sizes its dynamic part for four workgroups per CU)
     char *na_pinned;                // pinned staging of mfk_recall_noalloc (header | sites | counts), allocated by mfk_create
     std::vector<int32_t> ir_ov;     // external inverted-repeat table for the next pairflanks call: rows i5 i3 has a1s a1e a2s a2e, sorted
+    // multi-GPU merge (mfk_comm.hip): RCCL communicator of this ctx and the result of the last mfk_allgather_sites
+    void *comm; int comm_rank, comm_world;
+    std::vector<uint8_t> gat; size_t gat_msg; std::vector<int64_t> gat_counts; int32_t gat_row_bytes;
 };
 
 #define HIPCHK(call)                                                                                         \

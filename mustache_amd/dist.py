@@ -313,7 +313,20 @@ def _all_gather_bytes(mine, ws):
     return torch.stack(parts)
 
 
-def allgather_records(rows, blob, device=None, cap=GATHER_CAP):
+def init_library_comm(binding):
+    """One RCCL communicator inside libmfk.so for the ranks of the initialised torch.distributed group: rank 0 makes the
+    128-byte id, torch.distributed broadcasts it (the library has no bootstrap of its own), every rank joins.  After it
+    allgather_records(..., binding=binding) runs the merge inside the library (mfk_allgather_sites).  Collective."""
+    import torch
+    import torch.distributed as dist
+    ws, rank = dist.get_world_size(), dist.get_rank()
+    dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+    cid = torch.from_numpy(binding.make_comm_id() if rank == 0 else np.zeros(128, dtype=np.uint8)).to(dev)
+    dist.broadcast(cid, src=0)
+    binding.init_comm(cid.cpu().numpy(), rank, ws)
+
+
+def allgather_records(rows, blob, device=None, cap=GATHER_CAP, binding=None):
     """All-gather of one table per rank (fixed-width rows + their string bytes) -> list over ranks of (rows, blob).
     Without torch.distributed initialised (or with one rank) it is [(rows, blob)].
 
@@ -322,6 +335,8 @@ def allgather_records(rows, blob, device=None, cap=GATHER_CAP):
     with the true maximum follow (all ranks see the same headers, so they agree on that without talking)."""
     import torch
     import torch.distributed as dist
+    if binding is not None and getattr(binding, "comm_world", 0) > 0:
+        return binding.run_allgather(rows, blob, cap)     # inside the library: one ncclAllGather on the ctx stream
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return [(rows, blob)]
     ws = dist.get_world_size()
@@ -350,10 +365,10 @@ def allgather_records(rows, blob, device=None, cap=GATHER_CAP):
     return parts
 
 
-def allgather_flanks(flanks, seqs, device=None, cap=GATHER_CAP):
+def allgather_flanks(flanks, seqs, device=None, cap=GATHER_CAP, binding=None):
     """Merge per-rank flank tables (FLANK_DTYPE rows + their sequence bytes).  Returns (rows, seqs) with seq_off
     rebased, ranks concatenated in rank order.  Works without torch.distributed initialised (single process)."""
-    parts = allgather_records(flanks, seqs, device, cap)
+    parts = allgather_records(flanks, seqs, device, cap, binding)
     if len(parts) == 1:
         return parts[0]
     rows, blobs, off = [], [], 0
@@ -368,11 +383,11 @@ def allgather_flanks(flanks, seqs, device=None, cap=GATHER_CAP):
 def findflanks_sharded(binding, reads_struct, plan, params, device=None, cap=GATHER_CAP):
     """Stage 1 of the calling rank + the all-gather of the owned rows -> the merged flank table on every rank."""
     rows, seqs = shard_findflanks(binding, reads_struct, plan, params)
-    return merge_flanks(allgather_records(rows, seqs, device, cap))
+    return merge_flanks(allgather_records(rows, seqs, device, cap, binding if getattr(binding, "comm_world", 0) else None))
 
 
 def pairflanks_sharded(binding, reads_struct, plan, params, tab, seqs, contig_rank, genome, genome_off, device=None,
                        cap=GATHER_CAP):
     """Stage 2 of the calling rank + the all-gather of its pairs -> the merged pair table on every rank."""
     rows, strs = shard_pairflanks(binding, reads_struct, plan, params, tab, seqs, contig_rank, genome, genome_off)
-    return merge_pairs(allgather_records(rows, strs, device, cap), contig_rank)
+    return merge_pairs(allgather_records(rows, strs, device, cap, binding if getattr(binding, "comm_world", 0) else None), contig_rank)

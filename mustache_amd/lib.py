@@ -127,6 +127,13 @@ class Binding:
         f("inferseq_pairs", C.c_int, [_p, _p, C.c_int64, C.c_double, C.c_double, C.c_int64, C.c_int64, C.POINTER(C.c_int64)])
         f("inferseq_pairs_fetch", C.c_int, [_p, _p, _p])
         f("inferseq_db_pairs", C.c_int, [_p, _p, C.c_int64, C.c_double, C.c_double, C.c_int64, C.POINTER(C.c_int64)])
+        self.comm_world = 0
+        if hasattr(self.so, prefix + "comm_init"):
+            f("comm_unique_id", C.c_int, [_p, _p])
+            f("comm_init", C.c_int, [_p, _p, C.c_int, C.c_int])
+            f("comm_free", C.c_int, [_p])
+            f("allgather_sites", C.c_int, [_p, _p, C.c_int64, C.c_int32, _p, C.c_int64, C.c_int64, _p])
+            f("allgather_fetch", C.c_int, [_p, C.c_int, _p, _p])
         if hasattr(self.so, prefix + "profile_enable"):
             f("profile_enable", C.c_int, [_p, C.c_int])
             f("profile_fetch", C.c_int, [_p, _p, C.c_int64, _p, _p, C.c_int64, C.POINTER(C.c_int64)])
@@ -177,6 +184,34 @@ class Binding:
         r.n_pool = int(host_hdr["n_pool"])
         r._keep = (arrays, clen, crs)
         return r
+
+    # ---- multi-GPU merge inside the library (RCCL; include/mfk.h mfk_comm_* / mfk_allgather_sites) ----------------------
+    def make_comm_id(self):
+        buf = np.zeros(128, dtype=np.uint8)
+        self._check(self.comm_unique_id(self.ctx, buf.ctypes.data))
+        return buf
+
+    def init_comm(self, comm_id, rank, world):
+        """Collective over the `world` ranks that hold the same id (made by rank 0's make_comm_id)."""
+        cid = np.ascontiguousarray(comm_id, dtype=np.uint8)
+        assert cid.shape[0] == 128
+        self._check(self.comm_init(self.ctx, cid.ctypes.data, int(rank), int(world)))
+        self.comm_world = int(world)
+
+    def run_allgather(self, rows, blob, pad_bytes=0):
+        """All-gather of one table per rank: rows = structured numpy array, blob = bytes.  -> [(rows, blob)] per rank."""
+        rows = np.ascontiguousarray(rows)
+        b = np.frombuffer(bytes(blob) + b"\0", dtype=np.uint8)
+        counts = np.zeros(2 * self.comm_world, dtype=np.int64)
+        self._check(self.allgather_sites(self.ctx, rows.ctypes.data, rows.shape[0], rows.dtype.itemsize, b.ctypes.data, len(blob),
+                                         int(pad_bytes), counts.ctypes.data))
+        parts = []
+        for r in range(self.comm_world):
+            pr = np.zeros(int(counts[2 * r]), dtype=rows.dtype)
+            pb = np.zeros(max(int(counts[2 * r + 1]), 1), dtype=np.uint8)
+            self._check(self.allgather_fetch(self.ctx, r, pr.ctypes.data, pb.ctypes.data))
+            parts.append((pr, pb[:int(counts[2 * r + 1])].tobytes()))
+        return parts
 
     def run_findflanks(self, reads, params, stop_after=STAGE_ALL):
         ns, nf, sb = C.c_int64(0), C.c_int64(0), C.c_int64(0)
