@@ -325,21 +325,33 @@ __device__ __forceinline__ void d_unpack8(uint32_t pk, uint32_t *c0, uint32_t *c
 }
 __device__ __forceinline__ uint32_t d_bswap(uint32_t x) { return __builtin_amdgcn_perm(x, x, 0x00010203u); }
 
-// A lane fills 16 characters (and their qualities) of a word; a wave takes WF_WORDS consecutive words, four lanes each
-// (chunks c, c + 4, ...: words of up to 64 characters in one step).  The source of a chunk is 16 consecutive quality bytes
-// and 16 consecutive 4-bit base codes of ONE read (the usual word: one read clipped here; 3p words are read backwards), so
-// the lane fetches them with aligned 16-byte loads, i.e. a wave has 64 x 4 such loads in flight instead of byte loads.
-// A word merged from both mates of a pair (both clipped at this site, findflanks.py:932-1027) goes character by character.
+// A lane fills 16 characters (and their qualities) at a time; a wave takes WF_WORDS consecutive words.  The characters of
+// consecutive words are neighbours in memory (every word padded to 16), so the wave walks the 16-byte chunks of its words'
+// whole region, lane = chunk: every store instruction of the wave writes one contiguous kilobyte (chunks handed out word by
+// word made pieces of 64 bytes at odd offsets, and the counters showed four times the bytes going to memory).  The word of
+// a chunk is a four-step search over the wave's 17 offsets in LDS.  The source of a chunk is 16 consecutive quality bytes
+// and 16 consecutive 4-bit base codes of ONE read (the usual word: one read clipped here; 3p words are read backwards),
+// fetched with aligned 16-byte loads.  A word merged from both mates of a pair (both clipped at this site,
+// findflanks.py:932-1027) goes character by character.
 #define WF_WORDS 16
 __global__ __launch_bounds__(256) void k_word_fill(DevReads R, Words W) {
-    const uint32_t w = (blockIdx.x * 4 + (threadIdx.x >> 6)) * WF_WORDS + ((threadIdx.x & 63) >> 2);
-    if (w >= W.n) return;
-    const WordSrc src = W.src[w];
-    const uint32_t off = (uint32_t)W.off[w];
-    const int len = (int)W.len[w], plen = (int)W.plen[w], side = (int)(W.job[w] & 1u);
-    uint4 *ch = reinterpret_cast<uint4 *>(W.ch + off), *qo = reinterpret_cast<uint4 *>(W.q + off);
-    for (int ck = (int)(threadIdx.x & 3); 16 * ck < plen; ck += 4) {
-        const int p0 = 16 * ck;
+    __shared__ uint32_t s_off[4][WF_WORDS + 1], s_meta[4][WF_WORDS];   // s_meta: length | side << 16
+    __shared__ WordSrc s_src[4][WF_WORDS];
+    const int wave = (int)(threadIdx.x >> 6), lane = (int)(threadIdx.x & 63);
+    const uint32_t w0 = (blockIdx.x * 4 + (uint32_t)wave) * WF_WORDS;
+    const uint32_t nw = w0 < W.n ? (W.n - w0 < WF_WORDS ? W.n - w0 : WF_WORDS) : 0u;
+    if ((uint32_t)lane <= nw && nw) s_off[wave][lane] = (uint32_t)W.off[w0 + lane];   // off[] has an entry behind the last word
+    if ((uint32_t)lane < nw) { s_src[wave][lane] = W.src[w0 + lane]; s_meta[wave][lane] = W.len[w0 + lane] | ((W.job[w0 + lane] & 1u) << 16); }
+    __syncthreads();
+    if (!nw) return;
+    const uint32_t b_end = s_off[wave][nw];
+    for (uint32_t b = s_off[wave][0] + 16u * (uint32_t)lane; b < b_end; b += 16u * 64u) {
+        uint32_t u = 0;   // the word of this chunk: the last one that starts at or before it (empty words start where the next one does)
+#pragma unroll
+        for (uint32_t step = WF_WORDS / 2; step; step >>= 1) if (u + step < nw && s_off[wave][u + step] <= b) u += step;
+        const WordSrc src = s_src[wave][u];
+        const int len = (int)(s_meta[wave][u] & 0xFFFFu), side = (int)(s_meta[wave][u] >> 16);
+        const int p0 = (int)(b - s_off[wave][u]);
         uint32_t c[4], q[4];
         if (src.l2 == 0 && len > 0) {
             const int l1 = (int)src.l1;   // = len
@@ -374,15 +386,15 @@ __global__ __launch_bounds__(256) void k_word_fill(DevReads R, Words W) {
 #pragma unroll
             for (int i = 0; i < 4; i++) {
                 c[i] = 0; q[i] = 0;
-                for (int b = 0; b < 4; b++) {
+                for (int k = 0; k < 4; k++) {
                     uint8_t cc, qv;
-                    d_word_char(R, src, side, len, p0 + 4 * i + b, &cc, &qv);
-                    c[i] |= (uint32_t)cc << (8 * b); q[i] |= (uint32_t)qv << (8 * b);
+                    d_word_char(R, src, side, len, p0 + 4 * i + k, &cc, &qv);
+                    c[i] |= (uint32_t)cc << (8 * k); q[i] |= (uint32_t)qv << (8 * k);
                 }
             }
         }
-        ch[ck] = make_uint4(c[0], c[1], c[2], c[3]);
-        qo[ck] = make_uint4(q[0], q[1], q[2], q[3]);
+        *reinterpret_cast<uint4 *>(W.ch + b) = make_uint4(c[0], c[1], c[2], c[3]);
+        *reinterpret_cast<uint4 *>(W.q + b) = make_uint4(q[0], q[1], q[2], q[3]);
     }
 }
 
