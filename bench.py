@@ -51,7 +51,9 @@ def algorithmic_bytes(kernel, meta):
         return listed * (8 + 7) + ev * 8       # list entry + mapq, contig_id, one position column (7 B) + one key per event
     if kernel == "k_classify":
         return meta["join_visits"] * 13        # ref_start, ref_end (8 B) + mapq, flags, link (5 B) per (site, read) visit (estimated count)
-    if kernel.startswith("rocprim::radix_sort_keys") or kernel == "k_bucket_sort":
+    if kernel == "k_bucket_sort":
+        return ev * (8 * 2 + 2 + 1 + 4)        # every key read and written once + CIGAR-end length in, info byte and head flag out (per-event information is written here)
+    if kernel.startswith("rocprim::radix_sort_keys"):
         return ev * 8 * 2                      # a sort has to read and write every key once
     if kernel.startswith("k_direct_repeats"):
         # (150 x 1.5 + 8) B per read over a pair's 50-bp window; a window of W bp at coverage c sees c (150 + W) / 150 reads
@@ -85,12 +87,13 @@ def kernel_entry(names, table, share, meta, config):
     traffic = _json_file(PMC_TRAFFIC_FILE).get(config, {})
     tr = [traffic.get(r[0], {}).get("traffic_bytes") for r in rows]
     valu = _json_file(VALU_MODELS_FILE)
-    m = valu.get(rows[0][0]) if len(rows) == 1 else None
+    m = (valu.get(config, {}).get(rows[0][0]) or valu.get(rows[0][0])) if len(rows) == 1 else None   # per config where the cost per unit depends on the data shape
+    tr_sum = sum(tr) if all(t is not None for t in tr) else None
     if all(a is not None for a in ab):
         ach = sum(ab) / (ms * 1e-3) / 1e9
         e.update({"bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5),
                   "algorithmic_bytes_per_step": sum(ab),
-                  "traffic": (sum(tr) if all(t is not None for t in tr) else None),
+                  "traffic": tr_sum,
                   "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, profiles/r02_pmc_traffic.json"})
     elif m and meta["work"].get(m["work_counter"]):
         units = meta["work"][m["work_counter"]]                               # per step, counted in this run
@@ -98,10 +101,10 @@ def kernel_entry(names, table, share, meta, config):
         ach = ops / (ms * 1e-3) / 1e12
         e.update({"bound": "valu", "achieved": round(ach, 3), "peak": round(VALU_PEAK_TOPS, 1), "unit": "Tlane-op/s",
                   "frac": round(ach / VALU_PEAK_TOPS, 5), "work_units_per_step": units, "work_unit": m["unit"],
-                  "valu_insts_per_unit": m["valu_insts_per_unit"], "model_source": m.get("source"), "traffic": None,
+                  "valu_insts_per_unit": m["valu_insts_per_unit"], "model_source": m.get("source"), "traffic": tr_sum,
                   "note": m.get("note")})
     else:
-        e.update({"bound": "valu", "achieved": None, "peak": round(VALU_PEAK_TOPS, 1), "unit": "Tlane-op/s", "frac": None, "traffic": None})
+        e.update({"bound": "valu", "achieved": None, "peak": round(VALU_PEAK_TOPS, 1), "unit": "Tlane-op/s", "frac": None, "traffic": tr_sum})
     return e
 
 
@@ -453,8 +456,10 @@ def main():
                 roofline = scan
             if roofline is not None:
                 roofline["read_scan"] = scan
-                roofline["top5_by_time"] = [{"kernel": r[0], "avg_ms": round(r[1], 5), "launches_per_step": r[2] // warm_calls,
-                                             "share": round(share[r[0]], 3)} for r in full_table[:5]]
+                # the five largest kernels by device time, each with its own model (durations from the bracketed warm-up steps)
+                meta_w = dict(meta, timed_steps=warm_calls)
+                roofline["top5_by_time"] = [kernel_entry([r[0]], full_table, share, meta_w, args.config) for r in full_table[:5]]
+                roofline["work_counters_per_step"] = work
                 roofline["whole_step"] = {"algorithmic_bytes": int(reads_here * 1 + meta["clipped_reads"] * 23 + meta["events"] * 24),
                                           "GBps": round((reads_here * 1 + meta["clipped_reads"] * 23 + meta["events"] * 24) / (ms_per_step * 1e-3) / 1e9, 1),
                                           "note": "the step is a chain of dependent launches over a few dozen sites: launch- and latency-bound, not HBM-bound"}

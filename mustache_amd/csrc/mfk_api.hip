@@ -305,8 +305,10 @@ int ReadBatch::flush() {
 // fills of a phase: [0, n_zero) 16-byte pieces of zeros, then ones up to n_total -- one launch for both groups (a
 // hipMemsetAsync each costs a launch of its own plus more host time than a kernel launch)
 __global__ __launch_bounds__(256) void k_fill2(uint4 *p, size_t n_zero, size_t n_total) {
-    const uint4 z = make_uint4(0u, 0u, 0u, 0u), o = make_uint4(~0u, ~0u, ~0u, ~0u);
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_total; i += (size_t)gridDim.x * blockDim.x) p[i] = i < n_zero ? z : o;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_total; i += (size_t)gridDim.x * blockDim.x) {
+        const uint32_t v = i < n_zero ? 0u : ~0u;   // (a select between two uint4 constants made the compiler keep both in scratch memory and load from there)
+        p[i] = make_uint4(v, v, v, v);
+    }
 }
 
 static int fill_launch(mfk_ctx *ctx, char *p, size_t zero_bytes, size_t one_bytes) {

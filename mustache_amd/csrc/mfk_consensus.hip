@@ -297,24 +297,25 @@ __device__ __forceinline__ void d_word_char(const DevReads &R, const WordSrc &sr
     *c_out = c; *q_out = q;
 }
 
-// 16 bytes at [p, p + 16) of which only those inside [vlo, vhi) are known to be readable.  The two aligned 16-byte blocks
-// around the window are each loaded only if they hold a readable byte (an aligned block never leaves the allocation its
-// readable byte is in), and the window is cut out of them in registers; the bytes outside [vlo, vhi) are unspecified.
-__device__ __forceinline__ uint4 d_window16(const uint8_t *p, const uint8_t *vlo, const uint8_t *vhi) {
-    const uintptr_t a = reinterpret_cast<uintptr_t>(p), a0 = a & ~(uintptr_t)15, lo = reinterpret_cast<uintptr_t>(vlo), hi = reinterpret_cast<uintptr_t>(vhi);
-    uint4 A = make_uint4(0, 0, 0, 0), B = make_uint4(0, 0, 0, 0);
-    if (a0 + 16 > lo && a0 < hi) A = *reinterpret_cast<const uint4 *>(a0);
-    if (a0 + 32 > lo && a0 + 16 < hi) B = *reinterpret_cast<const uint4 *>(a0 + 16);
-    const uint32_t sh = (uint32_t)(a & 15), sb = sh & 3u;
-    const bool s1 = sh & 4u, s2 = sh & 8u;
-    const uint32_t d[8] = {A.x, A.y, A.z, A.w, B.x, B.y, B.z, B.w};
-    uint32_t t[7], e[5];
-#pragma unroll
-    for (int i = 0; i < 7; i++) t[i] = s1 ? d[i + 1] : d[i];
-#pragma unroll
-    for (int i = 0; i < 5; i++) e[i] = s2 ? t[i + 2] : t[i];
-    return make_uint4(__builtin_amdgcn_alignbyte(e[1], e[0], sb), __builtin_amdgcn_alignbyte(e[2], e[1], sb),
-                      __builtin_amdgcn_alignbyte(e[3], e[2], sb), __builtin_amdgcn_alignbyte(e[4], e[3], sb));
+// The 16 bytes at base[s .. s + 16) of an array of which base[0 .. vlen) is known to be readable (s may be negative or run
+// past vlen: those bytes of the result are unspecified).  ONE 16-byte load, moved inside the aligned 16-byte blocks that hold
+// readable bytes (an aligned block never leaves the allocation its readable byte is in; the load itself need not be
+// aligned: gfx950 under HSA runs with unaligned access enabled), then a 128-bit shift puts the window in place.  (A select
+// network over two aligned blocks was turned into an indexed array in scratch memory by the compiler: three times the
+// kernel's payload in scratch stores.)
+__device__ __forceinline__ uint4 d_window16(const uint8_t *base, int64_t s, int64_t vlen) {
+    const uintptr_t a = reinterpret_cast<uintptr_t>(base);
+    const int64_t lo16 = -(int64_t)(a & 15), hi16 = vlen + (int64_t)((16 - ((a + (uintptr_t)vlen) & 15)) & 15);
+    int64_t ld = s < lo16 ? lo16 : s;
+    if (ld > hi16 - 16) ld = hi16 - 16;
+    const int delta = (int)(s - ld);   // -15 .. 15 whenever the window holds a readable byte
+    uint4 L;
+    __builtin_memcpy(&L, base + ld, 16);
+    unsigned __int128 x = ((unsigned __int128)(((uint64_t)L.w << 32) | L.z) << 64) | (((uint64_t)L.y << 32) | L.x);
+    const int n = 8 * (delta < 0 ? -delta : delta);
+    x = delta >= 0 ? x >> (n & 127) : x << (n & 127);
+    const uint64_t xl = (uint64_t)x, xh = (uint64_t)(x >> 64);
+    return make_uint4((uint32_t)xl, (uint32_t)(xl >> 32), (uint32_t)xh, (uint32_t)(xh >> 32));
 }
 // four packed bytes (two base codes each, the first in the high nibble) -> eight characters, one code per byte
 __device__ __forceinline__ void d_unpack8(uint32_t pk, uint32_t *c0, uint32_t *c1) {
@@ -358,9 +359,9 @@ __global__ __launch_bounds__(256) void k_word_fill(DevReads R, Words W) {
             // window of the read, in read coordinates: 5p = right clip as is, 3p = left clip backwards (Q14)
             const int64_t s = side == 0 ? (int64_t)src.q1len - l1 + p0 : (int64_t)l1 - 16 - p0;
             const uint8_t *qbase = R.pool_quals + src.o1, *bbase = R.pool_bases + (src.o1 >> 1);   // pool offsets are even
-            const uint4 qw = d_window16(qbase + s, qbase, qbase + src.q1len);
+            const uint4 qw = d_window16(qbase, s, (int64_t)src.q1len);
             const int64_t bs = s >> 1;    // floor: s is negative when a 3p word ends inside this chunk
-            const uint4 bw = d_window16(bbase + bs, bbase, bbase + ((src.q1len + 1) >> 1));
+            const uint4 bw = d_window16(bbase, bs, (int64_t)((src.q1len + 1) >> 1));
             uint32_t p0w = bw.x, p1w = bw.y;
             if (s & 1) {   // the window starts at the low nibble of its first byte: move the nibble stream up by one
                 p0w = ((bw.x << 4) & 0xF0F0F0F0u) | ((__builtin_amdgcn_alignbyte(bw.y, bw.x, 1) >> 4) & 0x0F0F0F0Fu);
