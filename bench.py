@@ -271,6 +271,8 @@ def end_to_end(n_records, tmp, device):
             t["contig"] = [str(c).rsplit("_", 1)[0] for c in t["contig"]]
             return bigbam.replicate_table(t, copies)
         want_ff, want_pf = base_table(tsv1, "flank_id"), base_table(tsv2, "pair_id")
+        # the pairs table is sorted by contig NAME (pandas sort_values in the reference, pairflanks.py:248), the flank table keeps file order
+        want_pf = want_pf.sort_values(["contig", "pos_5p", "pos_3p"], kind="stable").reset_index(drop=True)
         t0 = time.perf_counter()
         _findflanks(bam, *ff_args, output_file=tsv1, device=device, verbose=False)
         t1 = time.perf_counter()
