@@ -6,8 +6,8 @@ CFG=${1:-C5_tenth}; T=${2:-x}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/sq_$T
 rm -rf $O && mkdir -p $O
-timeout -s KILL 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS --output-format csv -d $O/a -- python3 bench.py --quick --pool near --config $CFG --steps 3 --warmup 1 > $O/a.log 2>&1
-timeout -s KILL 300 rocprofv3 --pmc SQC_ICACHE_REQ SQC_ICACHE_MISSES SQC_ICACHE_HITS SQ_IFETCH SQ_INSTS_LDS SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES --output-format csv -d $O/b -- python3 bench.py --quick --pool near --config $CFG --steps 3 --warmup 1 > $O/b.log 2>&1
+timeout -s KILL 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS --output-format csv -d $O/a -- python3 bench.py --quick --config $CFG --steps 3 --warmup 1 > $O/a.log 2>&1
+timeout -s KILL 300 rocprofv3 --pmc SQC_ICACHE_REQ SQC_ICACHE_MISSES SQC_ICACHE_HITS SQ_IFETCH SQ_INSTS_LDS SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES --output-format csv -d $O/b -- python3 bench.py --quick --config $CFG --steps 3 --warmup 1 > $O/b.log 2>&1
 python3 - $O <<'PY'
 import csv, glob, os, sys
 from collections import defaultdict
