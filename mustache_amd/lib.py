@@ -198,6 +198,11 @@ class Binding:
         self._check(self.comm_init(self.ctx, cid.ctypes.data, int(rank), int(world)))
         self.comm_world = int(world)
 
+    def free_comm(self):
+        if self.comm_world:
+            self._check(self.comm_free(self.ctx))
+            self.comm_world = 0
+
     def run_allgather(self, rows, blob, pad_bytes=0):
         """All-gather of one table per rank: rows = structured numpy array, blob = bytes.  -> [(rows, blob)] per rank."""
         rows = np.ascontiguousarray(rows)
