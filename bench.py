@@ -208,7 +208,7 @@ def make_workload(name, seed, pool, isolates=12, rank=0):
     return packed, g, goff, pfh.contig_ranks(packed.contig_names), cfg, truth, None, (packed, genome, truth)
 
 
-def time_config(hip, name, pool, device, steps=5, warmup=2, isolates=12):
+def time_config(hip, name, pool, device, steps=20, warmup=3, isolates=12):
     """ms/step of one more BASELINE config on this GPU (resident inputs, the fused call), for the `configs` table."""
     import torch
     from mustache_amd import lib
