@@ -616,6 +616,58 @@ __global__ __launch_bounds__(SEGS == DR_SEGS ? 1024 : 256) void k_direct_repeats
     }
 }
 
+// ---- pair rows on the device (thousands of pairs): the frame of run_pair_flanks pairflanks.py:96-122 ---------------------------
+// As for the flank rows (k_rows_fill): with ten thousand pairs the host loop over nine read-back arrays costs a quarter of a
+// millisecond.  k_prow_count gives every final pair its string bytes (IR_3p, IR_5p, reference repeat, reads repeat, in that
+// order) and raises a flag if a pair carries a direct-repeat error (then the host takes its own loop, which words the error);
+// a scan places the strings; k_prow_fill writes the mfk_pair records and the strings.
+__global__ void k_prow_count(FlankDev F, const uint32_t *fin, const uint32_t *n_fin, const int32_t *ir, const int32_t *meta, uint32_t *bytes, uint32_t *err) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= *n_fin) return;
+    const uint32_t c = fin[k];
+    const int32_t *m = meta + 3 * (size_t)c, *r = ir + 6 * (size_t)c;
+    if (m[2]) atomicOr(err, 1u);
+    uint32_t b = (uint32_t)m[0] + (uint32_t)m[1];
+    if (r[1]) b += (uint32_t)(r[2] - r[1] + 1) + (uint32_t)(r[4] - r[3] + 1);
+    bytes[k] = b;
+}
+__global__ void k_prow_fill(FlankDev F, const uint32_t *fin, const uint32_t *fin_span, const uint32_t *n_fin, const uint32_t *c5, const uint32_t *c3, const int32_t *ir,
+                            const int32_t *meta, const char *dr, uint32_t stride, const uint64_t *off, mfk_pair *pairs, char *strs) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= *n_fin) return;
+    const uint32_t c = fin[k], a = c5[c], b = c3[c];
+    const int32_t *m = meta + 3 * (size_t)c, *r = ir + 6 * (size_t)c;
+    mfk_pair o;
+    o.contig_id = F.contig[a]; o.pos_5p = F.pos[a]; o.pos_3p = F.pos[b]; o.index_5p = (int32_t)a; o.index_3p = (int32_t)b;
+    o.softclip_count_5p = F.ccount[a]; o.softclip_count_3p = F.ccount[b];
+    o.total_count_5p = F.total[a]; o.total_count_3p = F.total[b]; o.spanning_count = (int32_t)fin_span[k];
+    o.has_ir = r[0]; o.ir5_len = o.ir3_len = -1; o.ir_length = 0;
+    o.ir5_off = 0; o.ir3_off = 0;
+    int64_t at = (int64_t)off[k];
+    if (r[1]) {
+        const int l5 = F.seq_len[a], l3 = F.seq_len[b];
+        const int n5 = l5 > 40 ? 40 : l5, n3 = l3 > 40 ? 40 : l3;
+        const char *s5 = F.seqs + F.seq_off[a], *s3 = F.seqs + F.seq_off[b] + (l3 - n3);
+        // character q (0-based) of seq5[:40] + 'N' * 20 + seq3[-40:] (pairflanks.py:183-186)
+        auto comb = [&](int q) -> char { return q < n5 ? s5[q] : (q < n5 + 20 ? 'N' : s3[q - n5 - 20]); };
+        o.ir3_len = r[2] - r[1] + 1; o.ir3_off = at;       // IR_3p = ir1.seq
+        for (int i = 0; i < o.ir3_len; i++) strs[at + i] = comb(r[1] - 1 + i);
+        at += o.ir3_len;
+        o.ir5_len = r[4] - r[3] + 1; o.ir5_off = at;       // IR_5p = ir2.seq
+        for (int i = 0; i < o.ir5_len; i++) strs[at + i] = comb(r[3] - 1 + i);
+        at += o.ir5_len;
+        o.ir_length = o.ir5_len;
+    }
+    o.dr_ref_len = m[0]; o.dr_len = m[1];
+    const char *d = dr + (size_t)c * stride;
+    o.dr_ref_off = at;
+    for (int i = 0; i < m[0]; i++) strs[at + i] = d[i];
+    at += m[0];
+    o.dr_reads_off = at;
+    for (int i = 0; i < m[1]; i++) strs[at + i] = d[stride / 2 + i];
+    pairs[k] = o;
+}
+
 // =====================================================================================================================
 extern "C" int mfk_ir_detect(mfk_ctx *ctx, const char *seqs, const int64_t *off, int64_t n, int32_t *out) {
     if (!ctx || n < 0) return 1;
@@ -836,6 +888,49 @@ extern "C" int mfk_pairflanks(mfk_ctx *ctx, const mfk_reads *reads, const mfk_pa
         if (int rc = dev_excl_scan32(ctx, jflag, jscan, nP)) return rc;
         PROF_LAUNCH(k_pair_final, dim3(pb), dim3(256), 0, st, (const uint32_t *)kept, nK_p, (const uint32_t *)jflag, (const uint32_t *)jscan, (const uint32_t *)spanning, fin, fin_span);
         KCHK();
+        }
+        // thousands of candidates: the rows are assembled on the device (unless a pair carries a direct-repeat error)
+        if (nP >= 2048) {
+            uint32_t *pbytes = nullptr, *perr = nullptr;
+            { FillGroup z2(ctx, 0); z2.want(&pbytes, nP); z2.want(&perr, 64); if (z2.commit()) return 1; }
+            uint64_t *poff = aalloc<uint64_t>(ctx, (size_t)nP + 1);
+            mfk_pair *d_pairs = aalloc<mfk_pair>(ctx, nP);
+            const size_t str_cap = (size_t)nP * (2 * (size_t)IR_MAXLEN + stride) + 16;
+            char *d_strs = aalloc<char>(ctx, str_cap);
+            if (!poff || !d_pairs || !d_strs) return 1;
+            const uint32_t *nfin_p = jscan + nP;
+            PROF_LAUNCH(k_prow_count, dim3(pb), dim3(256), 0, st, F, (const uint32_t *)fin, nfin_p, (const int32_t *)ir, (const int32_t *)meta, pbytes, perr);
+            KCHK();
+            if (int rc = dev_excl_scan64(ctx, pbytes, poff, nP)) return rc;
+            PROF_LAUNCH(k_prow_fill, dim3(pb), dim3(256), 0, st, F, (const uint32_t *)fin, (const uint32_t *)fin_span, nfin_p, (const uint32_t *)c5, (const uint32_t *)c3, (const int32_t *)ir,
+                        (const int32_t *)meta, (const char *)dr, stride, (const uint64_t *)poff, d_pairs, d_strs);
+            KCHK();
+            HIPCHK(hipEventRecord(ctx->ev1, st));
+            uint32_t h_perr = 0; uint64_t h_total = 0;
+            {
+                ReadBatch rb(ctx);
+                rb.add(nK_p, &nK, 4); rb.add(jscan + nP, &nFin, 4); rb.add(d_pstats, h_ps, sizeof h_ps); rb.add(ctx->scan_err, &h_scan_err, 4);
+                rb.add(perr, &h_perr, 4); rb.add(poff + nP, &h_total, 8);
+                ht.lap("enqueue");
+                if (int rc = rb.flush()) return rc;
+            }
+            if (int rc = check_scan_error(ctx, h_scan_err)) return rc;
+            if (!h_perr && !(!ir_tab.empty() && h_ps[15])) {
+                ctx->pairs.resize(nFin); ctx->strs.resize((size_t)h_total);
+                ReadBatch rb(ctx);
+                rb.add(d_pairs, ctx->pairs.data(), (size_t)nFin * sizeof(mfk_pair)); rb.add(d_strs, &ctx->strs[0], (size_t)h_total);
+                if (int rc = rb.flush()) return rc;
+                ht.lap("results read-back (rows made on the device)");
+                ctx->pstats[1] = nK; ctx->pstats[2] = h_ps[2]; ctx->pstats[3] = h_ps[3]; ctx->pstats[4] = nFin;
+                prof_collect(ctx);
+                float ms = 0.f;
+                if (hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1) == hipSuccess) ctx->last_ms = ms;
+                ctx->call_ok = true;
+                if (n_pairs_out) *n_pairs_out = (int64_t)ctx->pairs.size();
+                if (str_bytes_out) *str_bytes_out = (int64_t)ctx->strs.size();
+                return 0;
+            }
+            // an error among the final pairs (rare): the host loop below reports it in the reference's words
         }
         HIPCHK(hipEventRecord(ctx->ev1, st));
         h_fin.resize(nP); h_span.resize(nP); h_meta.resize(3 * (size_t)nP); h_dr.resize((size_t)nP * stride);
