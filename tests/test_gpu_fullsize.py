@@ -155,3 +155,31 @@ def test_long_soft_clips(hip, oracle, read_len, expect):
     finally:
         del os.environ["MFK_NO_SMALL_JOBS"]
     assert b["seqs"] == off["seqs"] and b["flanks"].tobytes() == off["flanks"].tobytes()
+
+
+def test_documented_limits_fail_with_messages(hip, oracle):
+    """more than 65535 contigs, a reference beyond the 32-bit site axis and max_direct_repeat_length beyond
+    65000 are rejected with a message before any kernel runs, and the ctx works afterwards."""
+    packed, genome, _ = synth_packed(**CONFIGS["tiny"], seed=22)
+    tensors = packed.to_torch("cuda:0")
+    hdr = lib.host_header(packed)
+    params = lib.make_params()
+    n = packed.n_reads
+    # 70 000 contigs (the reads sit on the first)
+    many = dict(hdr, contig_len=np.full(70_000, 1000, dtype=np.int32), contig_read_start=np.concatenate([[0], np.full(70_000, n)]).astype(np.int64))
+    with pytest.raises(lib.MfkError, match="n_contigs 70000 out of range"):
+        hip.run_findflanks(hip.reads_struct(tensors, n, packed.max_span, many), params)
+    # 6.3 Gb of reference (the flat site axis is 32 bits wide)
+    big = dict(hdr, contig_len=np.array([int(hdr["contig_len"][0]), 2_100_000_000, 2_100_000_000, 2_100_000_000], dtype=np.int32),
+               contig_read_start=np.array([0, n, n, n, n], dtype=np.int64))
+    with pytest.raises(lib.MfkError, match="does not fit the 32-bit site axis"):
+        hip.run_findflanks(hip.reads_struct(tensors, n, packed.max_span, big), params)
+    import torch
+    ff = hip.run_findflanks(device_reads(hip, packed, "cuda:0"), params)
+    g, goff = pfh.genome_arrays(genome, packed.contig_names)
+    with pytest.raises(lib.MfkError, match="max_direct_repeat_length out of range"):
+        hip.run_pairflanks(device_reads(hip, packed, "cuda:0"), lib.make_params(max_direct_repeat_length=70_000), ff["flanks"], ff["seqs"],
+                           pfh.contig_ranks(packed.contig_names), torch.from_numpy(g).to("cuda:0"), goff)
+    # unharmed
+    a, pf, off, opf = _both(hip, oracle, packed, genome)
+    assert a["flanks"].tobytes() == off["flanks"].tobytes() and pf["strs"] == opf["strs"]
