@@ -213,11 +213,12 @@ int read_back(mfk_ctx *ctx, const void *dev, void *host, size_t bytes) {
 // stores the number with release semantics) and the host polls that word instead of sleeping in a stream
 // synchronisation: 6.8 us instead of 11 us per read-back on this box (scripts/micro/sync_cost.hip).
 #define GATHER_MAX 16
-struct GatherArgs { const uint8_t *src[GATHER_MAX]; uint32_t bytes[GATHER_MAX], off[GATHER_MAX]; int n; };
-__global__ __launch_bounds__(256) void k_gather(GatherArgs g, uint8_t *dst, uint32_t *count, uint32_t *flag, uint32_t seq) {
+#define DIRECT_MIN 65536   // read-back items from this size on are tried for an in-place write (one address lookup each)
+struct GatherArgs { const uint8_t *src[GATHER_MAX]; uint8_t *dst[GATHER_MAX]; uint32_t bytes[GATHER_MAX]; int n; };   // dst: device address of pinned host memory
+__global__ __launch_bounds__(256) void k_gather(GatherArgs g, uint32_t *count, uint32_t *flag, uint32_t seq) {
     for (int i = blockIdx.y; i < g.n; i += gridDim.y) {
         const uint8_t *src = g.src[i];
-        uint8_t *out = dst + g.off[i];
+        uint8_t *out = g.dst[i];
         const uint32_t nb = g.bytes[i];
         if ((((uintptr_t)src | (uintptr_t)out) & 15) == 0) {   // 16 bytes per lane: stores to host memory are few and wide
             const uint32_t nq = nb >> 4;
@@ -271,7 +272,19 @@ int check_scan_error(mfk_ctx *ctx, uint32_t h_scan_err) {
 
 int ReadBatch::flush() {
     if (items.empty()) return 0;
-    char *pin = (char *)pinned_buf(ctx, total);
+    // A large item whose destination is pinned, device-mapped memory (the result tables, PinVec / PinString) is written in place;
+    // everything else goes through the staging buffer and is copied out by the host.
+    std::vector<void *> direct(items.size(), nullptr);
+    size_t staged = 0;
+    for (size_t i = 0; i < items.size(); i++) {
+        if (items[i].bytes >= DIRECT_MIN) {
+            void *d = nullptr;
+            if (hipHostGetDevicePointer(&d, items[i].host, 0) == hipSuccess && d) direct[i] = d;
+            else (void)hipGetLastError();   // pageable destination: not an error of the call
+        }
+        if (!direct[i]) { items[i].off = staged; staged += (items[i].bytes + 15) & ~(size_t)15; }
+    }
+    char *pin = (char *)pinned_buf(ctx, staged ? staged : 16);
     if (!pin) { snprintf(ctx->err, sizeof ctx->err, "pinned allocation failed"); return 1; }
     bool small = items.size() <= GATHER_MAX && total < ((size_t)1 << 24);
     void *dpin = nullptr;
@@ -279,12 +292,16 @@ int ReadBatch::flush() {
     if (small) {
         GatherArgs g; g.n = (int)items.size();
         size_t biggest = 0;
-        for (int i = 0; i < g.n; i++) { g.src[i] = (const uint8_t *)items[i].dev; g.bytes[i] = (uint32_t)items[i].bytes; g.off[i] = (uint32_t)items[i].off; if (items[i].bytes > biggest) biggest = items[i].bytes; }
+        for (int i = 0; i < g.n; i++) {
+            g.src[i] = (const uint8_t *)items[i].dev; g.bytes[i] = (uint32_t)items[i].bytes;
+            g.dst[i] = direct[i] ? (uint8_t *)direct[i] : (uint8_t *)dpin + items[i].off;
+            if (items[i].bytes > biggest) biggest = items[i].bytes;
+        }
         unsigned bx = (unsigned)((biggest / 16 + 255) / 256); if (bx < 1) bx = 1; if (bx > 64) bx = 64;
         uint32_t seq = ++ctx->gather_seq;
         if (seq == 0) seq = ++ctx->gather_seq;
         volatile uint32_t *hflag = ctx->gather_flag;   // sequence numbers only grow: no reset needed between gathers
-        hipLaunchKernelGGL(k_gather, dim3(bx, g.n), dim3(256), 0, ctx->stream, g, (uint8_t *)dpin, ctx->gather_count, ctx->gather_flag_dev, seq);
+        hipLaunchKernelGGL(k_gather, dim3(bx, g.n), dim3(256), 0, ctx->stream, g, ctx->gather_count, ctx->gather_flag_dev, seq);
         KCHK();
         // poll; if the number does not arrive (a fault in an earlier kernel), the stream synchronisation reports why
         bool seen = false;
@@ -294,10 +311,11 @@ int ReadBatch::flush() {
         }
         if (!seen) HIPCHK(hipStreamSynchronize(ctx->stream));
     } else {
-        for (auto &it : items) HIPCHK(hipMemcpyAsync(pin + it.off, it.dev, it.bytes, hipMemcpyDeviceToHost, ctx->stream));
+        for (size_t i = 0; i < items.size(); i++)
+            HIPCHK(hipMemcpyAsync(direct[i] ? items[i].host : (void *)(pin + items[i].off), items[i].dev, items[i].bytes, hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(hipStreamSynchronize(ctx->stream));
     }
-    for (auto &it : items) memcpy(it.host, pin + it.off, it.bytes);
+    for (size_t i = 0; i < items.size(); i++) if (!direct[i]) memcpy(items[i].host, pin + items[i].off, items[i].bytes);
     items.clear(); total = 0;
     return 0;
 }

@@ -8,12 +8,32 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <new>
 #include <string>
 #include <vector>
 
 #include "mfk_device.h"
 
 struct Chunk { char *p; size_t cap, used; };
+
+// Result tables live in pinned, device-mapped host memory: the gather kernel of a read-back writes them in place (no staging
+// copy of megabytes by the host; the tables of C5 are 4 MB per call).  Capacity survives clear(), so a loop over calls
+// allocates once.
+template <typename T> struct PinnedAlloc {
+    using value_type = T;
+    PinnedAlloc() = default;
+    template <typename U> PinnedAlloc(const PinnedAlloc<U> &) {}
+    T *allocate(size_t n) {
+        void *p = nullptr;
+        if (hipHostMalloc(&p, n * sizeof(T), hipHostMallocMapped) != hipSuccess || !p) { (void)hipGetLastError(); throw std::bad_alloc(); }
+        return static_cast<T *>(p);
+    }
+    void deallocate(T *p, size_t) { (void)hipHostFree(p); }
+    template <typename U> bool operator==(const PinnedAlloc<U> &) const { return true; }
+    template <typename U> bool operator!=(const PinnedAlloc<U> &) const { return false; }
+};
+template <typename T> using PinVec = std::vector<T, PinnedAlloc<T>>;
+using PinString = std::basic_string<char, std::char_traits<char>, PinnedAlloc<char>>;
 
 struct mfk_ctx {
     int device;
@@ -46,13 +66,13 @@ struct mfk_ctx {
     std::vector<double> prof_ms;
     std::vector<int64_t> prof_calls;
     // findflanks results (host)
-    std::vector<mfk_site> sites;
-    std::vector<mfk_flank> flanks;
-    std::string seqs;
+    PinVec<mfk_site> sites;
+    PinVec<mfk_flank> flanks;
+    PinString seqs;
     int64_t stats[MFK_N_STATS];
     // pairflanks results (host)
-    std::vector<mfk_pair> pairs;
-    std::string strs;
+    PinVec<mfk_pair> pairs;
+    PinString strs;
     int64_t pstats[MFK_N_STATS];
     std::vector<int32_t> isq_f, isq_r;   // inferseq pairing result (mfk_inferseq_pairs)
     bool sj_attr;                   // k_job_small may use more than 64 KB of dynamic LDS on this device (attribute set)
