@@ -222,9 +222,9 @@ class Binding:
         ns, nf, sb = C.c_int64(0), C.c_int64(0), C.c_int64(0)
         self._check(self.findflanks(self.ctx, C.byref(reads), C.byref(params), stop_after, C.byref(ns), C.byref(nf),
                                     C.byref(sb)))
-        sites = np.zeros(ns.value, dtype=SITE_DTYPE)
-        flanks = np.zeros(nf.value, dtype=FLANK_DTYPE)
-        seqs = np.zeros(max(sb.value, 1), dtype=np.uint8)
+        sites = np.empty(ns.value, dtype=SITE_DTYPE)       # (the fetch writes every row)
+        flanks = np.empty(nf.value, dtype=FLANK_DTYPE)
+        seqs = np.empty(max(sb.value, 1), dtype=np.uint8)
         stats = np.zeros(N_STATS, dtype=np.int64)
         self._check(self.findflanks_fetch(self.ctx, sites.ctypes.data, flanks.ctypes.data, seqs.ctypes.data,
                                           stats.ctypes.data))
@@ -241,7 +241,7 @@ class Binding:
         self._check(self.pairflanks(self.ctx, C.byref(reads), C.byref(params), flanks.ctypes.data, fs.ctypes.data,
                                     flanks.shape[0], rank.ctypes.data, _ptr(genome), goff.ctypes.data,
                                     C.byref(npairs), C.byref(sb)))
-        pairs = np.zeros(npairs.value, dtype=PAIR_DTYPE)
+        pairs = np.empty(npairs.value, dtype=PAIR_DTYPE)
         strs = np.zeros(max(sb.value, 1), dtype=np.uint8)
         stats = np.zeros(N_STATS, dtype=np.int64)
         self._check(self.pairflanks_fetch(self.ctx, pairs.ctypes.data, strs.ctypes.data, stats.ctypes.data))
@@ -256,13 +256,13 @@ class Binding:
         ns, nf, sb, npairs, pb = (C.c_int64(0) for _ in range(5))
         self._check(self.flankpairs(self.ctx, C.byref(reads), C.byref(params), rank.ctypes.data, _ptr(genome), goff.ctypes.data,
                                     C.byref(ns), C.byref(nf), C.byref(sb), C.byref(npairs), C.byref(pb)))
-        sites = np.zeros(ns.value, dtype=SITE_DTYPE)
-        flanks = np.zeros(nf.value, dtype=FLANK_DTYPE)
-        seqs = np.zeros(max(sb.value, 1), dtype=np.uint8)
+        sites = np.empty(ns.value, dtype=SITE_DTYPE)       # (the fetch writes every row)
+        flanks = np.empty(nf.value, dtype=FLANK_DTYPE)
+        seqs = np.empty(max(sb.value, 1), dtype=np.uint8)
         stats = np.zeros(N_STATS, dtype=np.int64)
         self._check(self.findflanks_fetch(self.ctx, sites.ctypes.data, flanks.ctypes.data, seqs.ctypes.data, stats.ctypes.data))
-        pairs = np.zeros(npairs.value, dtype=PAIR_DTYPE)
-        strs = np.zeros(max(pb.value, 1), dtype=np.uint8)
+        pairs = np.empty(npairs.value, dtype=PAIR_DTYPE)
+        strs = np.empty(max(pb.value, 1), dtype=np.uint8)
         pstats = np.zeros(N_STATS, dtype=np.int64)
         self._check(self.pairflanks_fetch(self.ctx, pairs.ctypes.data, strs.ctypes.data, pstats.ctypes.data))
         self.last_stats, self.last_pair_stats = stats, pstats
