@@ -85,7 +85,10 @@ def kernel_entry(names, table, share, meta, config):
          "share_of_device_time": round(sum(share.get(r[0], 0.0) for r in rows), 3)}
     ab = [algorithmic_bytes(r[0], meta) for r in rows]
     traffic = _json_file(PMC_TRAFFIC_FILE).get(config, {})
-    tr = [traffic.get(r[0], {}).get("traffic_bytes") for r in rows]
+    def pmc(name):      # the PMC table spells every template argument ("k_direct_repeats<0, 384>"), the event table the first
+        hit = traffic.get(name) or next((v for k, v in traffic.items() if name.endswith(">") and k.startswith(name[:-1] + ",")), {})
+        return hit.get("traffic_bytes")
+    tr = [pmc(r[0]) for r in rows]
     valu = _json_file(VALU_MODELS_FILE)
     m = (valu.get(config, {}).get(rows[0][0]) or valu.get(rows[0][0])) if len(rows) == 1 else None   # per config where the cost per unit depends on the data shape
     tr_sum = sum(tr) if all(t is not None for t in tr) else None
