@@ -489,6 +489,37 @@ __device__ __forceinline__ int d_set_of(const DevReads &R, const DevParams &P, i
     return cat == CAT_DELETION ? 5 + qi : -1;                     // 6 upstream, 7 downstream
 }
 
+// The columns of a read that nearly every test of the tally looks at, loaded TOGETHER (one round trip): the per-read predicates
+// of mfk_device.h load what they need where they need it, behind the branch that decides whether they run, which makes
+// a chain of five dependent round trips per read and five more for its mate.  MFK_KEEP pins the loads before the first branch
+// (the compiler otherwise sinks each load to its first use).
+struct RdLite { int32_t rs, re; uint32_t f, mq; };
+#define MFK_KEEP(v) asm volatile("" : "+v"(v))
+__device__ __forceinline__ RdLite d_lite(const DevReads &R, int64_t r) {
+    RdLite x; x.rs = R.ref_start[r]; x.re = R.ref_end[r]; x.f = R.flags[r]; x.mq = R.mapq[r];
+    return x;
+}
+__device__ __forceinline__ bool l_overlaps(const RdLite &x, int32_t start) { return (x.re <= x.rs ? x.rs + 1 : x.re) > start; }   // d_overlaps
+__device__ __forceinline__ bool l_passes(const DevReads &R, const DevParams &P, int64_t r, const RdLite &x) {                     // d_passes
+    if ((int)x.mq < P.minq) return false;
+    if (d_lkind((uint8_t)x.f) && d_rkind((uint8_t)x.f)) {   // clipped at both ends (rare): the lengths come from memory
+        const int aligned = (int)R.qlen[r] - d_rlen(R, r, (uint8_t)x.f) - d_llen(R, r, (uint8_t)x.f);
+        if (aligned < P.minial) return false;
+    }
+    return true;
+}
+__device__ __forceinline__ int l_set_of(const DevReads &R, const DevParams &P, int64_t r, const RdLite &x, int32_t q, int qi) {   // d_set_of
+    const uint8_t f = (uint8_t)x.f;
+    const int lk = d_lkind(f), rk = d_rkind(f);
+    const bool rclip = rk && (rk == 1 ? x.re : x.re - 1) == q, lclip = lk && (lk == 1 ? x.rs - 1 : x.rs) == q;
+    if (qi == 3) return rclip ? 8 : -1;
+    if (qi == 4) return lclip ? 9 : -1;
+    if (rclip || lclip) return -1;                                 // findflanks.py:429-430
+    const int cat = (f & MFK_FLAG_COMPLEX) ? d_classify(R, P, r, f, q, qi != 0) : ((x.rs <= q && x.re > q) ? CAT_RUNTHROUGH : CAT_NONE);
+    if (qi == 0) return cat - 1;                                   // CAT_NONE -> -1
+    return cat == CAT_DELETION ? 5 + qi : -1;                      // 6 upstream, 7 downstream
+}
+
 // the whole workgroup tallies one site into cnt[NSETS] (LDS); range = 2 x int64 of LDS
 template <int NSETS>
 __device__ __forceinline__ void d_site_tally(const DevReads &R, const DevParams &P, int32_t contig, int32_t pos, uint32_t *cnt, int64_t *range) {
@@ -505,23 +536,37 @@ __device__ __forceinline__ void d_site_tally(const DevReads &R, const DevParams 
     for (int c = 0; c < NSETS; c++) mine[c] = 0;
     constexpr int NQ = NSETS > 8 ? 5 : 3;
     for (int64_t r = lo + threadIdx.x; r < hi; r += blockDim.x) {
-        if (!d_overlaps(R, r, start)) continue;
-        const uint8_t f = R.flags[r];
-        if (!d_passes(R, P, r, f)) continue;
+        RdLite x = d_lite(R, r);
+        int32_t lk1 = R.link[r];
+        MFK_KEEP(x.rs); MFK_KEEP(x.re); MFK_KEEP(x.f); MFK_KEEP(x.mq); MFK_KEEP(lk1);
+        if (!l_overlaps(x, start)) continue;
+        if (!l_passes(R, P, r, x)) continue;
+        // the previous read of the name (the mate, as a rule), loaded as a whole too
+        const bool has_p = lk1 >= 0 && (int64_t)lk1 < r;
+        RdLite y; y.rs = 0; y.re = 0; y.f = 0; y.mq = 0;
+        int32_t lk2 = -1; uint32_t pc = 0xFFFFFFFFu;
+        if (has_p) {
+            y = d_lite(R, lk1); lk2 = R.link[lk1]; pc = R.contig_id[lk1];
+            MFK_KEEP(y.rs); MFK_KEEP(y.re); MFK_KEEP(y.f); MFK_KEEP(y.mq); MFK_KEEP(lk2); MFK_KEEP(pc);
+        }
+        const bool p_in = has_p && (int32_t)pc == contig && y.rs < end && l_overlaps(y, start) && l_passes(R, P, lk1, y);
         for (int qi = 0; qi < NQ; qi++) {
             int32_t q = qi == 1 ? pos - 1 : (qi == 2 ? pos + 1 : pos);
             if (qi == 1 && pos - 1 < 0) continue;                 // findflanks.py:382
             if (qi == 2 && pos + 1 >= clen) continue;             // findflanks.py:387
-            int set = d_set_of(R, P, r, f, q, qi);
+            int set = l_set_of(R, P, r, x, q, qi);
             if (set < 0) continue;
-            bool dup = false;
-            int64_t prev = r;
-            for (int64_t p = R.link[r]; p >= 0 && p < prev; prev = p, p = R.link[p]) {
-                if ((int32_t)R.contig_id[p] != contig) continue;
-                if (!(R.ref_start[p] < end && d_overlaps(R, p, start))) continue;
-                const uint8_t fp = R.flags[p];
-                if (!d_passes(R, P, p, fp)) continue;
-                if (d_set_of(R, P, p, fp, q, qi) == set) { dup = true; break; }
+            // a read counts for a set only if no earlier read of its name falls in the same set: len(set(names))
+            bool dup = p_in && l_set_of(R, P, lk1, y, q, qi) == set;
+            if (!dup && has_p) {
+                int64_t prev = lk1;
+                for (int64_t p = lk2; p >= 0 && p < prev; prev = p, p = R.link[p]) {   // third and further reads of the name (rare)
+                    if ((int32_t)R.contig_id[p] != contig) continue;
+                    if (!(R.ref_start[p] < end && d_overlaps(R, p, start))) continue;
+                    const uint8_t fp = R.flags[p];
+                    if (!d_passes(R, P, p, fp)) continue;
+                    if (d_set_of(R, P, p, fp, q, qi) == set) { dup = true; break; }
+                }
             }
             if (!dup) {
 #pragma unroll

@@ -548,24 +548,31 @@ __global__ __launch_bounds__(SEGS == DR_SEGS ? 1024 : 256) void k_direct_repeats
         const uint32_t ns = nseg < SEGS ? nseg : SEGS;
         const int lane = threadIdx.x & 63;
         const uint32_t nw = blockDim.x >> 6;
-        constexpr int FL = DR_FLIGHT;   // (eight in flight in the 256-thread variant cost two waves per SIMD of occupancy: 0.85 -> 0.96 ms at C5)
+        // Segments in flight per wave.  Only the two loaded bytes of a segment stay in registers while the loads are out (the
+        // segment's column, read and nibble are looked up in LDS again afterwards), so the 256-thread variant can keep eight in
+        // flight without losing occupancy (with five registers per segment it lost two waves per SIMD: 0.85 -> 0.96 ms at C5).
+        constexpr int FL = SEGS == DR_SEGS ? DR_FLIGHT : 2 * DR_FLIGHT;
         for (uint32_t sgi = threadIdx.x >> 6; sgi < ns; sgi += FL * nw) {
-            uint32_t code[FL], qv[FL], rr[FL]; int col[FL]; bool on[FL];
+            uint32_t bb[FL], qq[FL], on = 0;
 #pragma unroll
             for (int u = 0; u < FL; u++) {
                 const uint32_t sg = sgi + u * nw;
-                on[u] = false;
-                if (sg < ns) {
-                    const int32_t rp = seg_lo[sg] + lane;
-                    if (rp < seg_hi[sg]) {
-                        const uint64_t qi = seg_q[sg] + (uint64_t)lane;
-                        code[u] = d_pool_base(R, qi); qv[u] = R.pool_quals[qi]; rr[u] = seg_r[sg]; col[u] = (int)(rp - es); on[u] = true;
-                    }
+                bb[u] = 0; qq[u] = 0;
+                if (sg < ns && seg_lo[sg] + lane < seg_hi[sg]) {
+                    const uint64_t qi = seg_q[sg] + (uint64_t)lane;
+                    bb[u] = R.pool_bases[qi >> 1]; qq[u] = R.pool_quals[qi];
+                    on |= 1u << u;
                 }
             }
 #pragma unroll
             for (int u = 0; u < FL; u++)
-                if (on[u]) { atomicAdd(&sum[col[u]][code[u]], qv[u]); atomicMin(&firstr[col[u]][code[u]], rr[u]); }
+                if (on & (1u << u)) {
+                    const uint32_t sg = sgi + u * nw;
+                    const uint32_t odd = (uint32_t)(seg_q[sg] + (uint64_t)lane) & 1u;
+                    const uint32_t code = odd ? (bb[u] & 15u) : (bb[u] >> 4);     // even base index = high nibble (BAM order)
+                    const int col = (int)(seg_lo[sg] + lane - es);
+                    atomicAdd(&sum[col][code], qq[u]); atomicMin(&firstr[col][code], seg_r[sg]);
+                }
         }
         __syncthreads();
     }
