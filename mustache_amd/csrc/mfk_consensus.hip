@@ -246,13 +246,19 @@ __global__ __launch_bounds__(256) void k_word_len(DevReads R, Words W, const uin
         int side = (int)(W.job[w] & 1);
         int64_t r1 = W.first[w], r2 = W.second[w];
         if (W.nextra[w] > 1) atomicOr(&meta->err, ERR_READ_NUMBER);      // findflanks.py:976-978 / 1025-1027
-        uint8_t f1 = R.flags[r1];
-        int l1 = side == 0 ? d_rlen(R, r1, f1) : d_llen(R, r1, f1), l2 = 0;
-        const int64_t p1 = d_pool_index(R, r1);
+        // the first read's columns together (one round trip): flags, the CIGAR-end length of this side, query length, pool offset
+        const bool all_pooled = R.n_pool == R.n;
+        uint32_t x_f = R.flags[r1], x_op = side == 0 ? R.last_op_len[r1] : R.first_op_len[r1], x_ql = R.qlen[r1];
+        uint64_t x_po = all_pooled ? R.pool_off[r1] : 0;
+        asm volatile("" : "+v"(x_f), "+v"(x_op), "+v"(x_ql));
+        const uint8_t f1 = (uint8_t)x_f;
+        const int k1 = side == 0 ? d_rkind(f1) : d_lkind(f1);
+        int l1 = k1 == 1 ? (int)x_op : (k1 == 2 ? 1 : 0), l2 = 0;      // d_rlen / d_llen
+        const int64_t p1 = all_pooled ? r1 : d_pool_index(R, r1);
         int64_t p2 = -1;
         WordSrc src;
-        src.o1 = p1 >= 0 ? R.pool_off[p1] : 0; src.o2 = 0;
-        src.q1len = R.qlen[r1]; src.q2len = 0;
+        src.o1 = all_pooled ? x_po : (p1 >= 0 ? R.pool_off[p1] : 0); src.o2 = 0;
+        src.q1len = (uint16_t)x_ql; src.q2len = 0;
         if (r2 >= 0) {
             uint8_t f2 = R.flags[r2];
             l2 = side == 0 ? d_rlen(R, r2, f2) : d_llen(R, r2, f2);

@@ -511,8 +511,16 @@ __global__ __launch_bounds__(SEGS == DR_SEGS ? 1024 : 256) void k_direct_repeats
         if (threadIdx.x == 0) nseg = 0;
         __syncthreads();
         const int64_t r = rbase + threadIdx.x;
-        if (r < r_end && d_overlaps(R, r, (int32_t)es) && R.qlen[r] != 0) {
-            const uint8_t f = R.flags[r];
+        // the read's columns together, before the first test (one round trip instead of a chain of four)
+        int32_t x_rs = 0, x_re = 0; uint32_t x_ql = 0, x_f = 0, x_fo = 0; uint64_t x_po = 0;
+        const bool all_pooled = R.n_pool == R.n;
+        if (r < r_end) {
+            x_rs = R.ref_start[r]; x_re = R.ref_end[r]; x_ql = R.qlen[r]; x_f = R.flags[r]; x_fo = R.first_op_len[r];
+            if (all_pooled) x_po = R.pool_off[r];
+            asm volatile("" : "+v"(x_rs), "+v"(x_re), "+v"(x_ql), "+v"(x_f), "+v"(x_fo));
+        }
+        if (r < r_end && (x_re <= x_rs ? x_rs + 1 : x_re) > (int32_t)es && x_ql != 0) {
+            const uint8_t f = (uint8_t)x_f;
             int64_t pi = -1;
             {   // the pool usually holds every read of the window: then read r sits at a fixed offset from the range start
                 const int64_t guess = prange[0] + (r - range[0]);
@@ -522,9 +530,10 @@ __global__ __launch_bounds__(SEGS == DR_SEGS ? 1024 : 256) void k_direct_repeats
             }
             if (pi < 0) err = 1;
             else {
-                const uint64_t o0 = R.pool_off[pi];
+                const uint64_t o0 = all_pooled ? x_po : R.pool_off[pi];
                 DevBlocks bl = d_blocks(R, r, f);
-                int64_t qpos = d_lkind(f) == 1 ? R.first_op_len[r] : 0;
+                if (!(f & MFK_FLAG_COMPLEX)) { bl.s1 = x_rs; bl.e1 = x_re; }   // (the same values, already here)
+                int64_t qpos = d_lkind(f) == 1 ? (int64_t)x_fo : 0;
                 for (int bi = 0; bi < bl.n; bi++) {
                     qpos += bl.bi(bi);
                     const int32_t bs = bl.bs(bi), be = bl.be(bi);
