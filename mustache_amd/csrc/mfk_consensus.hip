@@ -1109,7 +1109,6 @@ __global__ __launch_bounds__(CV_THREADS) void k_cluster_vote(DevParams P, Words 
         W.cl_len[slot] = stop;
         W.cl_key[slot] = ((W.has_match[slot] ? 1u : 0u) << 31) | (s_minrank & 0x7fffffffu);
     }
-    const char codes[17] = "=ACMGRSVTWYHKDBN";
     char *out = cl_chars + (size_t)slot * cl_stride;
     const int side = (int)(job & 1);
     for (int d = threadIdx.x; d < stop; d += blockDim.x) {
@@ -1119,7 +1118,7 @@ __global__ __launch_bounds__(CV_THREADS) void k_cluster_vote(DevParams P, Words 
             if (best < 0 || hq[d * 16 + c] > hq[d * 16 + best]) { best = c; nbest = 1; }
             else if (hq[d * 16 + c] == hq[d * 16 + best]) nbest++;
         }
-        char chv = nbest > 1 ? 'N' : codes[best < 0 ? 15 : best];   // get_best_qual_chars flanktrie.py:344-353
+        char chv = nbest > 1 ? 'N' : d_code_char(best < 0 ? 15 : best);   // get_best_qual_chars flanktrie.py:344-353
         out[side == 0 ? d : stop - 1 - d] = chv;                     // 3p consensus is reversed back (findflanks.py:894-895)
     }
     }
@@ -1717,7 +1716,6 @@ __global__ __launch_bounds__(SJ_THREADS) __attribute__((amdgpu_waves_per_eu(SJ_W
         }
         if ((uint32_t)tid < 8) s_wr[R + tid] = 0;   // the eight-word steps may look past the last word
         if (tid == 0) s_other = 0;
-        const char codes[17] = "=ACMGRSVTWYHKDBN";
         const uint32_t dsh = maxd <= 64 ? 6u : (maxd <= 128 ? 7u : 8u), D = 1u << dsh, nparts = SJ_THREADS >> dsh;
         const uint32_t d = (uint32_t)tid & (D - 1u), pi = (uint32_t)tid >> dsh;
         const uint32_t per = ((R + nparts - 1u) / nparts + 7u) & ~7u, vb = pi * per, ve = vb + per < R ? vb + per : R;
@@ -1788,7 +1786,7 @@ __global__ __launch_bounds__(SJ_THREADS) __attribute__((amdgpu_waves_per_eu(SJ_W
                 if (best < 0 || xq > bq) { best = (int)cx; nbest = 1; bq = xq; }
                 else if (xq == bq) nbest++;
             }
-            bestc[d] = nbest > 1 ? 'N' : codes[best < 0 ? 15 : best];   // get_best_qual_chars flanktrie.py:344-353
+            bestc[d] = nbest > 1 ? 'N' : d_code_char(best < 0 ? 15 : best);   // get_best_qual_chars flanktrie.py:344-353
         }
         __syncthreads();
     }

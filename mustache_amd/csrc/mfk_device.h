@@ -214,6 +214,13 @@ __device__ inline int64_t d_pool_index(const DevReads &R, int64_t r) {
     if (lo >= R.n_pool || (int64_t)R.pool_read[lo] != r) return -1;
     return lo;
 }
+// character of a 4-bit BAM base code ("=ACMGRSVTWYHKDBN") from two 64-bit immediates: a `const char codes[17]` indexed by a
+// register lives in constant MEMORY, i.e. every use is a load with the latency of one (3 us under load at the end of a job)
+__device__ __forceinline__ char d_code_char(int c) {
+    const uint64_t lo = 0x565352474d43413dull;                        // '=' 'A' 'C' 'M' 'G' 'R' 'S' 'V' (low byte first)
+    const uint64_t hi = 0x4e42444b48595754ull;                        // 'T' 'W' 'Y' 'H' 'K' 'D' 'B' 'N'
+    return (char)(((c & 8) ? hi : lo) >> (8 * (c & 7)));
+}
 __device__ __forceinline__ uint8_t d_pool_base(const DevReads &R, uint64_t k) { return (R.pool_bases[k >> 1] >> ((~k & 1) << 2)) & 15; }
 
 // ---- block-wide helpers (256 threads = 4 waves) -----------------------------------------------------------------

@@ -462,7 +462,6 @@ __global__ __launch_bounds__(SEGS == DR_SEGS ? 1024 : 256) void k_direct_repeats
     __shared__ uint64_t seg_q[SEGS];
     __shared__ int32_t seg_lo[SEGS], seg_hi[SEGS];
     __shared__ uint32_t seg_r[SEGS], nseg;
-    const char codes[17] = "=ACMGRSVTWYHKDBN";
     if (blockIdx.x >= n_cand) return;
     const uint32_t c = blockIdx.x, k = c;      // output row = candidate
     const int32_t contig = F.contig[c5[c]], end = F.pos[c5[c]], start = F.pos[c3[c]];
@@ -617,7 +616,7 @@ __global__ __launch_bounds__(SEGS == DR_SEGS ? 1024 : 256) void k_direct_repeats
         int col = (int)(p - es);
         uint8_t rc = refch[col];
         int refcode = -1;
-        for (int q = 0; q < 16; q++) if ((uint8_t)codes[q] == rc) refcode = q;
+        for (int q = 0; q < 16; q++) if ((uint8_t)d_code_char(q) == rc) refcode = q;
         // reference key first: weight 1 (+ read qualities when a read shows the same character); always > 0
         uint64_t best_q = 1 + (refcode >= 0 ? sum[col][refcode] : 0);
         char best_n = (char)rc;
@@ -629,7 +628,7 @@ __global__ __launch_bounds__(SEGS == DR_SEGS ? 1024 : 256) void k_direct_repeats
             if (fr == 0xFFFFFFFFu) continue;
             uint64_t v = sum[col][q];
             // a later key replaces the best only with a strictly larger sum; among equal sums the earlier key stays
-            if (v > best_q || (v == best_q && !best_is_ref && fr < best_first)) { best_q = v; best_n = codes[q]; best_first = fr; best_is_ref = false; }
+            if (v > best_q || (v == best_q && !best_is_ref && fr < best_first)) { best_q = v; best_n = d_code_char(q); best_first = fr; best_is_ref = false; }
         }
         out_reads[p - (start + 1)] = best_n;
     }
