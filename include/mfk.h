@@ -264,8 +264,10 @@ int mfk_inferseq_db_pairs(mfk_ctx *ctx, const mfk_aln *alns, int64_t n, double m
  *   mfk_comm_init:      collective; one communicator per ctx, on the ctx's device and stream.  world = 1 is allowed.
  *   mfk_allgather_sites: collective.  rows: n_rows records of row_bytes bytes (any fixed-width table: mfk_site, mfk_flank,
  *                       mfk_pair), blob: their string bytes; both HOST buffers (the tables of this ABI are host tables).
- *                       Every rank sends a 16-byte header + rows + blob padded to pad_bytes (<= 0: 256 KB) in ONE
- *                       ncclAllGather; a second one with the true maximum follows only if some table did not fit.
+ *                       Every rank sends a 16-byte header + rows + blob padded to pad_bytes in ONE
+ *                       ncclAllGather; a second one with the true maximum follows only if some table did not fit.  pad_bytes <= 0 lets the
+ *                       size follow the tables (16 KB at first, then the largest table of the previous gather + 25 %; the same on
+ *                       every rank because every rank sees every header).
  *                       counts (2 x world, may be NULL): rows and blob bytes of every rank.
  *   mfk_allgather_fetch: copies rank r's rows / blob of the last gather (either pointer may be NULL).
  * Return code 101 = an RCCL call failed, 102 = librccl.so could not be loaded (message in mfk_last_error). */

@@ -24,7 +24,7 @@ mfk_ctx *mfk_create(int device_id) {
     ctx->fill_stream = nullptr;
     ctx->na_pinned = nullptr;
     ctx->sj_attr = false; ctx->sj_static = 0;
-    ctx->comm = nullptr; ctx->comm_rank = 0; ctx->comm_world = 0; ctx->gat_msg = 0; ctx->gat_row_bytes = 0;
+    ctx->comm = nullptr; ctx->comm_rank = 0; ctx->comm_world = 0; ctx->gat_msg = 0; ctx->gat_hint = 0; ctx->gat_row_bytes = 0;
     ctx->err[0] = 0;
     ctx->prof_on = false;
     ctx->prof_skip = false;

@@ -103,7 +103,10 @@ extern "C" int mfk_allgather_sites(mfk_ctx *ctx, const void *rows, int64_t n_row
     ctx->err[0] = 0;
     const int world = ctx->comm_world;
     const size_t body = (size_t)n_rows * (size_t)row_bytes + (size_t)blob_bytes;
-    size_t size = pad_bytes > 0 ? (size_t)pad_bytes : ((size_t)256 << 10);
+    // pad_bytes <= 0: the common size follows the tables: 16 KB at first, then the largest table of the previous gather plus a
+    // quarter (every rank has seen the same headers, so every rank arrives at the same size): a loop over steps with tables of
+    // a few KB moves a few KB per rank, not a fixed maximum
+    size_t size = pad_bytes > 0 ? (size_t)pad_bytes : (ctx->gat_hint ? ctx->gat_hint + ctx->gat_hint / 4 : ((size_t)16 << 10));
     size = (size + 255) & ~(size_t)255;
     ctx->gat_counts.assign(2 * (size_t)world, 0);
     ctx->gat_row_bytes = row_bytes;
@@ -138,10 +141,14 @@ extern "C" int mfk_allgather_sites(mfk_ctx *ctx, const void *rows, int64_t n_row
             const size_t b = (size_t)h2[0] * (size_t)row_bytes + (size_t)h2[1];
             if (b > need) need = b;
         }
+        ctx->gat_hint = need < 4096 ? 4096 : need;
         if (need <= size) {
-            ctx->gat.resize(msg * (size_t)world);
-            memcpy(ctx->gat.data(), got, msg * (size_t)world);
-            ctx->gat_msg = msg;
+            // keep what the ranks sent, not the padding: rank r's rows and strings at r * (16 + need)
+            const size_t keep = 16 + ((need + 15) & ~(size_t)15);
+            ctx->gat.resize(keep * (size_t)world);
+            for (int r = 0; r < world; r++)
+                memcpy(ctx->gat.data() + (size_t)r * keep, got + (size_t)r * msg, 16 + (size_t)ctx->gat_counts[2 * r] * (size_t)row_bytes + (size_t)ctx->gat_counts[2 * r + 1]);
+            ctx->gat_msg = keep;
             if (counts) memcpy(counts, ctx->gat_counts.data(), 2 * (size_t)world * sizeof(int64_t));
             ctx->call_ok = true;
             return 0;

@@ -81,7 +81,7 @@ struct mfk_ctx {
     std::vector<int32_t> ir_ov;     // external inverted-repeat table for the next pairflanks call: rows i5 i3 has a1s a1e a2s a2e, sorted
     // multi-GPU merge (mfk_comm.hip): RCCL communicator of this ctx and the result of the last mfk_allgather_sites
     void *comm; int comm_rank, comm_world;
-    std::vector<uint8_t> gat; size_t gat_msg; std::vector<int64_t> gat_counts; int32_t gat_row_bytes;
+    std::vector<uint8_t> gat; size_t gat_msg, gat_hint; std::vector<int64_t> gat_counts; int32_t gat_row_bytes;   // gat_hint: largest table of the last gather
 };
 
 #define HIPCHK(call)                                                                                         \

@@ -336,7 +336,9 @@ def allgather_records(rows, blob, device=None, cap=GATHER_CAP, binding=None):
     import torch
     import torch.distributed as dist
     if binding is not None and getattr(binding, "comm_world", 0) > 0:
-        return binding.run_allgather(rows, blob, cap)     # inside the library: one ncclAllGather on the ctx stream
+        # inside the library: one ncclAllGather on the ctx stream; the library sizes the exchange after the previous one unless
+        # the caller asks for a size of its own
+        return binding.run_allgather(rows, blob, 0 if cap == GATHER_CAP else cap)
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return [(rows, blob)]
     ws = dist.get_world_size()

@@ -12,7 +12,8 @@ def test_allgather_one_rank_roundtrip():
     hip = lib.load(0)
     hip.init_comm(hip.make_comm_id(), 0, 1)
     rng = np.random.default_rng(5)
-    for n, nb, pad in [(0, 0, 0), (7, 300, 0), (1000, 70000, 4096), (3, 10, 4096)]:   # the third does not fit its padding: second exchange
+    # the third does not fit its padding: second exchange; the last three let the library size the exchange after the previous one
+    for n, nb, pad in [(0, 0, 0), (7, 300, 0), (1000, 70000, 4096), (3, 10, 4096), (5000, 100, 0), (5, 100, 0), (9000, 5, 0)]:
         rows = np.zeros(n, dtype=lib.FLANK_DTYPE)
         rows["pos"] = rng.integers(0, 1 << 30, n)
         rows["seq_off"] = np.arange(n)
