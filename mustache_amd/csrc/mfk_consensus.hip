@@ -52,6 +52,7 @@ struct Words {
     uint32_t *plen;                   // padded to a multiple of 16
     uint64_t *off;                    // byte offset into ch / q (multiple of 16)
     uint8_t *ch, *q;                  // characters (4-bit codes, one per byte) and qualities
+    uint2 *sig;                       // device-wide path: LCP of a word with each of its job's N_LONGEST longest words (4 x u16), see d_sig_lcp
     uint32_t *npos;                   // per character d of a leaf a: its trie node = position of character d of word t(a[:d+1])
     uint32_t *cover;                  // per word: a leaf (local leaf index) the word is a prefix of
     unsigned long long *agg_qc;       // per character position = trie node: quality sum | #words << 40
@@ -408,14 +409,62 @@ __global__ __launch_bounds__(256) void k_word_fill(DevReads R, Words W) {
 // ---- leaves -------------------------------------------------------------------------------------------------------
 // one block per job: its N_LONGEST longest words (ties: first).  A word without sequencing errors is a prefix of them,
 // so testing these first settles most words in k_leaf_flags without the all-pairs scan.
+__device__ __forceinline__ uint32_t d_wave_max(uint32_t v);   // (DPP wave maximum, defined with the small-job kernel)
 #define N_LONGEST 4
-__global__ __launch_bounds__(256) void k_job_longest(Words W, Jobs J) {
+// Signature of a word: p_k = LCP(word, L_k) for the job's N_LONGEST longest words L_k (0xFFFF where the job has fewer words).
+// Two words that leave a reference at DIFFERENT positions share exactly the shorter stretch, and two that follow it equally far,
+// one of them to its own end, share that stretch: nearly every LCP of a job (all but the pairs with the same sequencing error)
+// follows from two 8-byte signatures and the lengths, without a look at the characters.  Returns -1 if it does not.
+__device__ __forceinline__ int d_sig_lcp(uint2 sa, int la, uint2 sv, int lv) {
+    const uint32_t a[2] = {sa.x, sa.y}, v[2] = {sv.x, sv.y};
+#pragma unroll
+    for (int k = 0; k < N_LONGEST; k++) {
+        const int pa = (int)((a[k >> 1] >> (16 * (k & 1))) & 0xFFFFu), pv = (int)((v[k >> 1] >> (16 * (k & 1))) & 0xFFFFu);
+        if (pa == 0xFFFF) continue;
+        if (pa != pv) return pa < pv ? pa : pv;
+        if (pa == la || pa == lv) return pa;
+    }
+    return -1;
+}
+
+// 1024 threads per job: a deep site-side has about a thousand words, i.e. one word per thread in the signature pass
+#define JL_THREADS 1024
+__global__ __launch_bounds__(JL_THREADS) void k_job_longest(Words W, Jobs J) {
     __shared__ unsigned long long best;
+    __shared__ uint32_t s_j[N_LONGEST], s_len[N_LONGEST], s_off[N_LONGEST], s_w[JL_THREADS / 64];
+    __shared__ __align__(16) uint8_t s_ref[N_LONGEST][MAX_WORD_LEN + 16];   // the references' characters
     uint32_t job = blockIdx.x;
     if (job >= J.n) return;
     uint32_t w0 = J.w0[job], R = J.R[job];
+    // keys (length, first index wins) in 32 bits: 10 bits of length above 22 bits of reversed index; a thread reads the lengths of
+    // its words ONCE (up to KL per thread in registers; beyond that from memory again in every round), the block maximum
+    // goes through DPP wave maxima and four LDS words: no 64-bit shuffles, no atomics
+    constexpr int KL = 4;
+    const bool cached = R <= (uint32_t)JL_THREADS * KL && R < (1u << 22);
+    uint32_t keys[KL];
+#pragma unroll
+    for (int u = 0; u < KL; u++) { const uint32_t i = threadIdx.x + (uint32_t)JL_THREADS * u; keys[u] = cached && i < R ? (W.len[w0 + i] << 22) | (0x3FFFFFu - i) : 0u; }
     unsigned long long prev = ~0ull;
     for (int k = 0; k < N_LONGEST; k++) {
+        if (cached) {   // block-uniform
+            uint32_t mine = 0;
+            const uint32_t below = prev == ~0ull ? 0xFFFFFFFFu : (uint32_t)prev;
+#pragma unroll
+            for (int u = 0; u < KL; u++) if (keys[u] < below && keys[u] > mine) mine = keys[u];
+            mine = d_wave_max(mine);
+            if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = mine;
+            __syncthreads();
+            uint32_t m = s_w[0];
+            for (int w = 1; w < JL_THREADS / 64; w++) if (s_w[w] > m) m = s_w[w];
+            prev = m;
+            if (threadIdx.x == 0) {
+                const uint32_t j = m ? 0x3FFFFFu - (m & 0x3FFFFFu) : 0xFFFFFFFFu;
+                J.longest[job * N_LONGEST + k] = j;
+                s_j[k] = j; s_len[k] = m ? m >> 22 : 0u;   // (s_off: below, the four loads together)
+            }
+            __syncthreads();
+            continue;   // (m == 0: nothing left, the remaining references stay empty)
+        }
         if (threadIdx.x == 0) best = 0;
         __syncthreads();
         unsigned long long mine = 0;
@@ -430,18 +479,68 @@ __global__ __launch_bounds__(256) void k_job_longest(Words W, Jobs J) {
         if ((threadIdx.x & 63) == 0 && mine) atomicMax(&best, mine);
         __syncthreads();
         prev = best;
-        if (threadIdx.x == 0) J.longest[job * N_LONGEST + k] = best ? 0xFFFFFFFFu - (uint32_t)(best & 0xFFFFFFFFull) : 0xFFFFFFFFu;
+        if (threadIdx.x == 0) {
+            const uint32_t j = best ? 0xFFFFFFFFu - (uint32_t)(best & 0xFFFFFFFFull) : 0xFFFFFFFFu;
+            J.longest[job * N_LONGEST + k] = j;
+            s_j[k] = j; s_len[k] = best ? (uint32_t)(best >> 32) : 0u; s_off[k] = best ? (uint32_t)W.off[w0 + j] : 0u;
+        }
         __syncthreads();
+    }
+    if (cached && threadIdx.x < N_LONGEST) s_off[threadIdx.x] = s_j[threadIdx.x] != 0xFFFFFFFFu ? (uint32_t)W.off[w0 + s_j[threadIdx.x]] : 0u;
+    __syncthreads();
+    // signatures of the job's words (d_sig_lcp).  The references' characters go to LDS once; a word's characters are read once,
+    // 16 bytes per step, and compared with all references still in the race (one memory round trip per step, not one per
+    // reference and step)
+    for (int k = 0; k < N_LONGEST; k++) {   // block-uniform
+        if (s_j[k] == 0xFFFFFFFFu) continue;
+        const uint4 *src = reinterpret_cast<const uint4 *>(W.ch + s_off[k]);
+        for (uint32_t i = threadIdx.x; i < ((s_len[k] + 15u) >> 4); i += blockDim.x) reinterpret_cast<uint4 *>(s_ref[k])[i] = src[i];
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < R; i += blockDim.x) {
+        const int la = (int)W.len[w0 + i];
+        const uint8_t *a = W.ch + W.off[w0 + i];
+        uint32_t p[N_LONGEST]; int lim[N_LONGEST]; uint32_t open_ = 0;
+#pragma unroll
+        for (int k = 0; k < N_LONGEST; k++) {
+            lim[k] = la < (int)s_len[k] ? la : (int)s_len[k];
+            p[k] = s_j[k] == 0xFFFFFFFFu ? 0xFFFFu : (uint32_t)lim[k];   // (the word itself as a reference: its length)
+            if (s_j[k] != 0xFFFFFFFFu && s_j[k] != i && lim[k] > 0) open_ |= 1u << k;
+        }
+        for (int o0 = 0; o0 < la && open_; o0 += 64) {
+            uint4 xs[4];   // 64 bytes of the word per round trip (the pool has 64 bytes of slack behind the last word)
+#pragma unroll
+            for (int c = 0; c < 4; c++) xs[c] = *reinterpret_cast<const uint4 *>(a + o0 + 16 * c);
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                const int o = o0 + 16 * c;
+                const uint4 x = xs[c];
+#pragma unroll
+                for (int k = 0; k < N_LONGEST; k++) {
+                    if (!(open_ & (1u << k))) continue;
+                    if (o >= lim[k]) { open_ &= ~(1u << k); continue; }
+                    const uint4 y = *reinterpret_cast<const uint4 *>(&s_ref[k][o]);
+                    const uint32_t d[4] = {x.x ^ y.x, x.y ^ y.y, x.z ^ y.z, x.w ^ y.w};
+                    if (d[0] | d[1] | d[2] | d[3]) {
+                        int q = lim[k];
+#pragma unroll
+                        for (int z = 3; z >= 0; z--) if (d[z]) q = o + 4 * z + (__builtin_ctz(d[z]) >> 3);
+                        p[k] = (uint32_t)(q < lim[k] ? q : lim[k]);
+                        open_ &= ~(1u << k);
+                    }
+                }
+            }
+        }
+        W.sig[w0 + i] = make_uint2(p[0] | (p[1] << 16), p[2] | (p[3] << 16));
     }
 }
 
 // is some other word an extension of a word (or an earlier copy)?  One wave per LF_WORDS consecutive words.  First
-// every word is tested against the N_LONGEST longest words of its job, all LF_WORDS x N_LONGEST tests at once (one lane
-// each, so the dependent loads job -> word range -> longest -> characters are paid once per wave, not once per word);
-// the words that settles (error-free reads) are done.  The others differ from those longest words at some position p
-// (a sequencing error): a word that extends them must show the same character there, which nearly none does.  So the
-// scan of the job's words first looks at that one character of LF_BATCH x 64 candidates at once (their lengths, offsets
-// and characters are independent loads, all in flight together) and compares in full only the few that pass.
+// every word is tested against the N_LONGEST longest words of its job from its signature alone (k_job_longest: p_k >= its
+// length means it is a prefix of L_k), all LF_WORDS x N_LONGEST tests at once, one lane each; the words that settles
+// (error-free reads) are done.  The others leave every L_k before their end (a sequencing error), and a word that extends
+// them leaves every L_k at the same place: the scan of the job's words compares signatures (8 bytes per candidate,
+// LF_BATCH x 64 candidates with their lengths in flight together) and compares characters only for the few that agree.
 // lf = words per wave (1..LF_WORDS): the host takes fewer when there are too few words to fill the GPU with waves.
 #define LF_WORDS 8
 #define LF_BATCH 8
@@ -450,27 +549,26 @@ __global__ __launch_bounds__(256) void k_leaf_flags(Words W, Jobs J, int lf) {
     const uint32_t wbase = (blockIdx.x * 4 + (threadIdx.x >> 6)) * (uint32_t)lf;
     if (wbase >= W.n) return;
     uint32_t m_w0 = 0, m_R = 0, m_off = 0;
-    int m_la = 0, m_lcp = 0;
+    uint2 m_sig = make_uint2(0u, 0u);
+    int m_la = 0;
     bool covered = false;
     {
         const uint32_t w = wbase + (uint32_t)lane / N_LONGEST;
         if (lane < lf * N_LONGEST && w < W.n) {
             const uint32_t job = W.job[w];
+            const int k = lane % N_LONGEST;
             m_w0 = J.w0[job]; m_R = J.R[job]; m_off = (uint32_t)W.off[w]; m_la = (int)W.len[w];
-            const uint32_t j = J.longest[job * N_LONGEST + (lane % N_LONGEST)];
-            if (j != 0xFFFFFFFFu) {
+            const uint32_t j = J.longest[job * N_LONGEST + k];
+            if (j != 0xFFFFFFFFu) {   // (none for a job that k_job_small has done: its signatures were never written)
+                m_sig = W.sig[w];
                 const uint32_t v = m_w0 + j;
                 const int lb = (int)W.len[v];
-                if (v != w) {
-                    m_lcp = d_lcp(W.ch + m_off, m_la, W.ch + W.off[v], lb);
-                    if (lb >= m_la && m_lcp >= m_la && (lb > m_la || v < w)) covered = true;
-                }
+                const int p = (int)(((k & 2 ? m_sig.y : m_sig.x) >> (16 * (k & 1))) & 0xFFFFu);
+                if (v != w && lb >= m_la && p >= m_la && (lb > m_la || v < w)) covered = true;
             }
         }
     }
     const unsigned long long cov = __ballot(covered);
-    // longest match of a word with one of the longest words: maximum over its N_LONGEST lanes
-    for (int o = 1; o < N_LONGEST; o <<= 1) { const int other = __shfl_xor(m_lcp, o, 64); if (other > m_lcp) m_lcp = other; }
     for (int i = 0; i < lf; i++) {   // wave-uniform
         const uint32_t w = wbase + (uint32_t)i;
         if (w >= W.n) break;
@@ -480,30 +578,23 @@ __global__ __launch_bounds__(256) void k_leaf_flags(Words W, Jobs J, int lf) {
         const int la = __shfl(m_la, i * N_LONGEST, 64);
         if (la <= 0) { if (lane == 0) W.is_leaf[w] = R > 1 ? 0 : 1; continue; }   // an empty word is a prefix of everything (cannot happen: clips have >= 1 base)
         const uint8_t *a = W.ch + __shfl(m_off, i * N_LONGEST, 64);
-        int p = __shfl(m_lcp, i * N_LONGEST, 64);
-        if (p > la - 1) p = la - 1;
-        const uint8_t ap = a[p];
+        const uint32_t swx = __shfl(m_sig.x, i * N_LONGEST, 64), swy = __shfl(m_sig.y, i * N_LONGEST, 64);
         unsigned long long any = 0;
         for (uint32_t c0 = 0; c0 < R; c0 += 64 * LF_BATCH) {   // wave-uniform
-            int lens[LF_BATCH]; uint32_t offs[LF_BATCH]; bool ok[LF_BATCH]; uint8_t bp[LF_BATCH];
+            int lens[LF_BATCH]; uint2 sg[LF_BATCH]; bool ok[LF_BATCH];
 #pragma unroll
             for (int u = 0; u < LF_BATCH; u++) {
                 const uint32_t j = c0 + (uint32_t)u * 64 + lane;
                 ok[u] = j < R && w0 + j != w;
                 lens[u] = ok[u] ? (int)W.len[w0 + j] : 0;
-                offs[u] = ok[u] ? (uint32_t)W.off[w0 + j] : 0u;
-            }
-#pragma unroll
-            for (int u = 0; u < LF_BATCH; u++) {
-                ok[u] = ok[u] && lens[u] >= la;
-                bp[u] = ok[u] ? W.ch[(size_t)offs[u] + p] : (uint8_t)0xFE;
+                sg[u] = ok[u] ? W.sig[w0 + j] : make_uint2(0u, 0u);
             }
             bool c2 = false;
 #pragma unroll
             for (int u = 0; u < LF_BATCH; u++) {
-                if (ok[u] && bp[u] == ap) {
+                if (ok[u] && lens[u] >= la && sg[u].x == swx && sg[u].y == swy) {
                     const uint32_t v = w0 + c0 + (uint32_t)u * 64 + lane;
-                    if (d_lcp(a, la, W.ch + offs[u], lens[u]) >= la && (lens[u] > la || v < w)) c2 = true;
+                    if (d_lcp(a, la, W.ch + W.off[v], lens[u]) >= la && (lens[u] > la || v < w)) c2 = true;
                 }
             }
             any = __ballot(c2);
@@ -558,7 +649,7 @@ __global__ __launch_bounds__(64) void k_leaf_first(Words W, Jobs J, uint16_t *lc
     const int lane = threadIdx.x;
     const uint32_t n_leaf = W.n_list[4];
     for (uint64_t it0 = blockIdx.x; it0 < n_leaf; it0 += (uint64_t)gridDim.x * 64) {
-    uint32_t m_slot = 0, m_w0 = 0, m_R = 0, m_off = 0, m_la = 0;
+    uint32_t m_slot = 0, m_w0 = 0, m_R = 0, m_off = 0, m_la = 0, m_lw = 0;
     unsigned long long m_adj = 0;
     {
         const uint64_t it = it0 + (uint64_t)lane * gridDim.x;
@@ -566,7 +657,8 @@ __global__ __launch_bounds__(64) void k_leaf_first(Words W, Jobs J, uint16_t *lc
             m_slot = W.leaf_list[it];
             const uint32_t job = W.job[m_slot];
             m_w0 = J.w0[job]; m_R = J.R[job]; m_adj = J.adj_off[job];
-            const uint32_t wa = m_w0 + W.leaf_word[m_slot];
+            m_lw = W.leaf_word[m_slot];
+            const uint32_t wa = m_w0 + m_lw;
             m_off = (uint32_t)W.off[wa]; m_la = W.len[wa];
         }
     }
@@ -576,15 +668,17 @@ __global__ __launch_bounds__(64) void k_leaf_first(Words W, Jobs J, uint16_t *lc
     const uint32_t off_a = __shfl(m_off, kk, 64);
     const int la = (int)__shfl(m_la, kk, 64);
     const unsigned long long adj_off = __shfl(m_adj, kk, 64);
-    const uint32_t k = slot - w0;
+    const uint32_t k = slot - w0, k_word = __shfl(m_lw, kk, 64);   // leaf number in its job, and the leaf's word
     const uint8_t *a = W.ch + off_a;
     for (int d = lane; d < la; d += 64) tmin[d] = 0xFFFFFFFFu;
     __syncthreads();
     uint16_t *mrow = lcpm + adj_off * 32 + (size_t)k * ((R + 31) >> 5) * 32;   // LCP(leaf, word j), reused by k_leaf_share
+    const uint2 sa = W.sig[w0 + k_word];
     for (uint32_t j = lane; j < R; j += 64) {
         uint32_t v = w0 + j;
         const int lv = (int)W.len[v];
-        int l = d_lcp(a, la, W.ch + W.off[v], lv);
+        int l = j == k_word ? la : d_sig_lcp(sa, la, W.sig[v], lv);   // nearly always settled without the characters
+        if (l < 0) l = d_lcp(a, la, W.ch + W.off[v], lv);
         mrow[j] = (uint16_t)l;
         if (l > 0) atomicMin(&tmin[l - 1], j);
         if (l == lv) atomicMin(&W.cover[v], k);   // word v is a prefix of this leaf; fire-and-forget (a read-before-write check costs a load round trip)
@@ -1944,7 +2038,9 @@ int run_consensus(mfk_ctx *ctx, const DevReads &R, const DevParams &P, Consensus
     }
     W.npos = aalloc<uint32_t>(ctx, (size_t)total_chars + 8);
     if (!W.npos) return 1;
-    PROF_LAUNCH(k_job_longest, dim3(J.n), dim3(256), 0, st, W, J);
+    W.sig = aalloc<uint2>(ctx, Wn);
+    if (!W.sig) return 1;
+    PROF_LAUNCH(k_job_longest, dim3(J.n), dim3(JL_THREADS), 0, st, W, J);
     KCHK();
     const int lf = Wn >= (1u << 18) ? LF_WORDS : (Wn >= (1u << 17) ? 4 : (Wn >= (1u << 16) ? 2 : 1));
     PROF_LAUNCH(k_leaf_flags, dim3(nblocks(Wn, 4 * (size_t)lf)), dim3(256), 0, st, W, J, lf);
