@@ -98,17 +98,39 @@ class ShardPlan:
 
     def __init__(self, pieces, ranges):
         self.pieces, self.ranges = list(pieces), list(ranges)
+        self._lo = self._hi = None
 
     def n_reads(self):
         return sum(hi - lo for lo, hi in self.ranges)
 
     def owns(self, contig_id, pos):
-        """Boolean mask over arrays of contig ids and positions."""
+        """Boolean mask over arrays of contig ids and positions.  A rank's pieces are one stretch of the (contig, position) order,
+        so a contig appears in at most one of them: two tables indexed by contig id instead of a pass per piece (a metagenome
+        rank owns hundreds of contigs)."""
         contig_id, pos = np.asarray(contig_id), np.asarray(pos)
-        m = np.zeros(contig_id.shape, dtype=bool)
-        for c, a, b in self.pieces:
-            m |= (contig_id == c) & (pos >= a) & (pos < b)
-        return m
+        if contig_id.size == 0 or not self.pieces:
+            return np.zeros(contig_id.shape, dtype=bool)
+        if self._lo is None:
+            top = max(c for c, _, _ in self.pieces) + 1
+            lo, hi = np.zeros(top, dtype=np.int64), np.zeros(top, dtype=np.int64)      # empty interval: owns nothing
+            seen = set()
+            for c, a, b in self.pieces:
+                if c in seen:                                                          # (not produced by plan_shards) fall back
+                    lo = None
+                    break
+                seen.add(c)
+                lo[c], hi[c] = a, b
+            self._lo, self._hi = (lo, hi) if lo is not None else (False, False)
+        if self._lo is False:
+            m = np.zeros(contig_id.shape, dtype=bool)
+            for c, a, b in self.pieces:
+                m |= (contig_id == c) & (pos >= a) & (pos < b)
+            return m
+        cid = contig_id.astype(np.int64)
+        inside = cid < len(self._lo)
+        c2 = np.where(inside, cid, 0)
+        p64 = pos.astype(np.int64)
+        return inside & (p64 >= self._lo[c2]) & (p64 < self._hi[c2])
 
     def __repr__(self):
         return "ShardPlan(pieces=%r, ranges=%r)" % (self.pieces, self.ranges)
@@ -184,10 +206,42 @@ def plan_shards(packed, world_size, sharding="coordinate", h=None, small_contig_
 # ---------------------------------------------------------------------------------------------------------------------
 # stages
 # ---------------------------------------------------------------------------------------------------------------------
+def _fast_copy(rows):
+    """Copy of a structured array through its bytes (numpy copies structured elements one by one: 3 ms per 20 000 rows)."""
+    rows = np.ascontiguousarray(rows)
+    return rows.view(np.uint8).copy().view(rows.dtype) if len(rows) else rows.copy()
+
+
+def _fast_take(rows, order):
+    """rows[order] for a structured array, as a 2-D take over its bytes."""
+    rows = np.ascontiguousarray(rows)
+    if len(rows) == 0:
+        return rows[order]
+    w = rows.dtype.itemsize
+    return np.ascontiguousarray(rows.view(np.uint8).reshape(len(rows), w)[order]).reshape(-1).view(rows.dtype)
+
+
+def _stable_order(*keys_major_first):
+    """Stable order by the given int64 keys (most significant first), or None if the rows are in that order already (the
+    tables of coordinate shards, concatenated in rank order, are)."""
+    n = len(keys_major_first[0])
+    if n < 2:
+        return None
+    in_order = np.ones(n - 1, dtype=bool)
+    tie = np.ones(n - 1, dtype=bool)
+    for k in keys_major_first:
+        k = np.asarray(k, dtype=np.int64)
+        in_order &= ~(tie & (k[1:] < k[:-1]))
+        tie &= k[1:] == k[:-1]
+    if in_order.all():
+        return None
+    return np.lexsort(tuple(np.asarray(k, dtype=np.int64) for k in reversed(keys_major_first)))
+
+
 def _compact(rows, blob, off_len_fields):
     """Copy of ``rows`` whose strings lie in row order (fields in the given order inside a row) at the front of a fresh
     blob, offsets re-based; a negative length (None) takes no bytes."""
-    rows = rows.copy()
+    rows = _fast_copy(rows)
     n = len(rows)
     if n == 0:
         return rows, b""
@@ -196,7 +250,20 @@ def _compact(rows, blob, off_len_fields):
     new_off = np.concatenate([[0], np.cumsum(lens)])
     total = int(new_off[-1])
     src = np.frombuffer(bytes(blob), dtype=np.uint8)
-    out = src[np.repeat(offs - new_off[:-1], lens) + np.arange(total, dtype=np.int64)].tobytes() if total else b""
+    if not total:
+        out = b""
+    else:
+        # the strings of consecutive rows are nearly always neighbours in the source blob too (a rank keeps stretches of a
+        # table): copy stretch by stretch; only a table in scattered order needs an index per byte
+        nz = lens > 0
+        o, l = offs[nz], lens[nz]
+        breaks = np.flatnonzero(o[1:] != o[:-1] + l[:-1]) + 1
+        if len(breaks) < 512:
+            first = np.concatenate([[0], breaks])
+            last = np.concatenate([breaks, [len(o)]]) - 1
+            out = b"".join(src[int(o[a]):int(o[z] + l[z])].tobytes() for a, z in zip(first, last))
+        else:
+            out = src[np.repeat(offs - new_off[:-1], lens) + np.arange(total, dtype=np.int64)].tobytes()
     placed = new_off[:-1].reshape(n, len(off_len_fields))
     for j, (fo, _) in enumerate(off_len_fields):
         rows[fo] = placed[:, j]
@@ -204,7 +271,7 @@ def _compact(rows, blob, off_len_fields):
 
 
 _FLANK_STR = (("seq_off", "seq_len"),)
-_PAIR_STR = (("ir5_off", "ir5_len"), ("ir3_off", "ir3_len"), ("dr_ref_off", "dr_ref_len"), ("dr_reads_off", "dr_len"))
+_PAIR_STR = (("ir3_off", "ir3_len"), ("ir5_off", "ir5_len"), ("dr_ref_off", "dr_ref_len"), ("dr_reads_off", "dr_len"))   # the order the library lays a pair's strings out in
 
 
 def shard_findflanks(binding, reads_struct, plan, params):
@@ -212,7 +279,7 @@ def shard_findflanks(binding, reads_struct, plan, params):
     Returns (rows, seqs) with the sequences packed in row order."""
     res = binding.run_findflanks(reads_struct, params)
     fl = res["flanks"]
-    mine = fl[plan.owns(fl["contig_id"], fl["pos"])] if len(fl) else fl
+    mine = _fast_take(fl, np.flatnonzero(plan.owns(fl["contig_id"], fl["pos"]))) if len(fl) else fl
     return _compact(mine, res["seqs"], _FLANK_STR)
 
 
@@ -221,14 +288,14 @@ def merge_flanks(parts):
     sorted BAM, findflanks.py:640-666), positions ascending, 5p before 3p (kept from the rank that owns the position)."""
     rows, blobs, off = [], [], 0
     for r, b in parts:
-        r = np.array(r, dtype=_lib.FLANK_DTYPE, copy=True)
+        r = _fast_copy(np.asarray(r, dtype=_lib.FLANK_DTYPE))
         r["seq_off"] += off
         off += len(b)
         rows.append(r)
         blobs.append(bytes(b))
     tab = np.concatenate(rows) if rows else np.zeros(0, dtype=_lib.FLANK_DTYPE)
-    order = np.lexsort((tab["pos"], tab["contig_id"]))            # stable: the 5p / 3p order inside a position survives
-    return _compact(tab[order], b"".join(blobs), _FLANK_STR)
+    order = _stable_order(tab["contig_id"], tab["pos"])           # stable: the 5p / 3p order inside a position survives
+    return _compact(tab if order is None else _fast_take(tab, order), b"".join(blobs), _FLANK_STR)
 
 
 def _flank_rows_for(plan, tab, reach):
@@ -254,9 +321,9 @@ def shard_pairflanks(binding, reads_struct, plan, params, tab, seqs, contig_rank
     sel = _flank_rows_for(plan, tab, int(params.max_direct_repeat_length) + 1)
     if len(sel) == 0:
         return np.zeros(0, dtype=_lib.PAIR_DTYPE), b""
-    res = binding.run_pairflanks(reads_struct, params, tab[sel], seqs, contig_rank, genome, genome_off)
+    res = binding.run_pairflanks(reads_struct, params, _fast_take(tab, sel), seqs, contig_rank, genome, genome_off)
     pr = res["pairs"]
-    mine = pr[plan.owns(pr["contig_id"], pr["pos_5p"])].copy() if len(pr) else pr
+    mine = _fast_take(pr, np.flatnonzero(plan.owns(pr["contig_id"], pr["pos_5p"]))) if len(pr) else pr
     mine["index_5p"] = sel[mine["index_5p"]]
     mine["index_3p"] = sel[mine["index_3p"]]
     return _compact(mine, res["strs"], _PAIR_STR)
@@ -267,7 +334,7 @@ def merge_pairs(parts, contig_rank):
     (pairflanks.py:248)."""
     rows, blobs, off = [], [], 0
     for r, b in parts:
-        r = np.array(r, dtype=_lib.PAIR_DTYPE, copy=True)
+        r = _fast_copy(np.asarray(r, dtype=_lib.PAIR_DTYPE))
         for fo, _ in _PAIR_STR:
             r[fo] += off
         off += len(b)
@@ -275,8 +342,8 @@ def merge_pairs(parts, contig_rank):
         blobs.append(bytes(b))
     tab = np.concatenate(rows) if rows else np.zeros(0, dtype=_lib.PAIR_DTYPE)
     rank = np.asarray(contig_rank)[tab["contig_id"]] if len(tab) else np.zeros(0, np.int64)
-    order = np.lexsort((tab["pos_3p"], tab["pos_5p"], rank))
-    return _compact(tab[order], b"".join(blobs), _PAIR_STR)
+    order = _stable_order(rank, tab["pos_5p"], tab["pos_3p"])
+    return _compact(tab if order is None else _fast_take(tab, order), b"".join(blobs), _PAIR_STR)
 
 
 def run_sharded_sequential(binding, reads_of, packed, params, world_size, sharding, contig_rank, genome, genome_off,
