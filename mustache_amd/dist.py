@@ -283,7 +283,7 @@ def shard_findflanks(binding, reads_struct, plan, params):
     return _compact(mine, res["seqs"], _FLANK_STR)
 
 
-def merge_flanks(parts):
+def merge_flanks(parts, compacted=False):
     """Per-rank (rows, seqs) -> the flank table of the unsharded run: contigs in BAM header order (first-seen order of a
     sorted BAM, findflanks.py:640-666), positions ascending, 5p before 3p (kept from the rank that owns the position)."""
     rows, blobs, off = [], [], 0
@@ -295,6 +295,8 @@ def merge_flanks(parts):
         blobs.append(bytes(b))
     tab = np.concatenate(rows) if rows else np.zeros(0, dtype=_lib.FLANK_DTYPE)
     order = _stable_order(tab["contig_id"], tab["pos"])           # stable: the 5p / 3p order inside a position survives
+    if order is None and compacted:
+        return tab, b"".join(blobs)                               # parts in order, each with its strings in row order: done
     return _compact(tab if order is None else _fast_take(tab, order), b"".join(blobs), _FLANK_STR)
 
 
@@ -329,7 +331,7 @@ def shard_pairflanks(binding, reads_struct, plan, params, tab, seqs, contig_rank
     return _compact(mine, res["strs"], _PAIR_STR)
 
 
-def merge_pairs(parts, contig_rank):
+def merge_pairs(parts, contig_rank, compacted=False):
     """Per-rank (rows, strs) -> the pair table of the unsharded run: sorted by (contig name, pos_5p, pos_3p)
     (pairflanks.py:248)."""
     rows, blobs, off = [], [], 0
@@ -343,6 +345,8 @@ def merge_pairs(parts, contig_rank):
     tab = np.concatenate(rows) if rows else np.zeros(0, dtype=_lib.PAIR_DTYPE)
     rank = np.asarray(contig_rank)[tab["contig_id"]] if len(tab) else np.zeros(0, np.int64)
     order = _stable_order(rank, tab["pos_5p"], tab["pos_3p"])
+    if order is None and compacted:
+        return tab, b"".join(blobs)
     return _compact(tab if order is None else _fast_take(tab, order), b"".join(blobs), _PAIR_STR)
 
 
@@ -355,9 +359,9 @@ def run_sharded_sequential(binding, reads_of, packed, params, world_size, shardi
     if plans is None:
         plans = plan_shards(packed, world_size, sharding, h)
     structs = [reads_of(packed.take_ranges(p.ranges)) for p in plans]
-    tab, seqs = merge_flanks([shard_findflanks(binding, s, p, params) for s, p in zip(structs, plans)])
+    tab, seqs = merge_flanks([shard_findflanks(binding, s, p, params) for s, p in zip(structs, plans)], compacted=True)
     pairs = merge_pairs([shard_pairflanks(binding, s, p, params, tab, seqs, contig_rank, genome, genome_off)
-                         for s, p in zip(structs, plans)], contig_rank)
+                         for s, p in zip(structs, plans)], contig_rank, compacted=True)
     return (tab, seqs), pairs, plans
 
 
@@ -452,11 +456,11 @@ def allgather_flanks(flanks, seqs, device=None, cap=GATHER_CAP, binding=None):
 def findflanks_sharded(binding, reads_struct, plan, params, device=None, cap=GATHER_CAP):
     """Stage 1 of the calling rank + the all-gather of the owned rows -> the merged flank table on every rank."""
     rows, seqs = shard_findflanks(binding, reads_struct, plan, params)
-    return merge_flanks(allgather_records(rows, seqs, device, cap, binding if getattr(binding, "comm_world", 0) else None))
+    return merge_flanks(allgather_records(rows, seqs, device, cap, binding if getattr(binding, "comm_world", 0) else None), compacted=True)
 
 
 def pairflanks_sharded(binding, reads_struct, plan, params, tab, seqs, contig_rank, genome, genome_off, device=None,
                        cap=GATHER_CAP):
     """Stage 2 of the calling rank + the all-gather of its pairs -> the merged pair table on every rank."""
     rows, strs = shard_pairflanks(binding, reads_struct, plan, params, tab, seqs, contig_rank, genome, genome_off)
-    return merge_pairs(allgather_records(rows, strs, device, cap, binding if getattr(binding, "comm_world", 0) else None), contig_rank)
+    return merge_pairs(allgather_records(rows, strs, device, cap, binding if getattr(binding, "comm_world", 0) else None), contig_rank, compacted=True)
