@@ -98,6 +98,8 @@ def kernel_entry(names, table, share, meta, config):
                   "algorithmic_bytes_per_step": sum(ab),
                   "traffic": tr_sum,
                   "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, profiles/r02_pmc_traffic.json"})
+        if any(r[0] == "k_classify" for r in rows):
+            e["note"] = "algorithmic bytes from an ESTIMATED number of (site, read) visits: sites after the first neighbour filter x 3 positions x coverage"
     elif m and meta["work"].get(m["work_counter"]):
         units = meta["work"][m["work_counter"]]                               # per step, counted in this run
         ops = units * m["valu_insts_per_unit"] * 64.0                         # lane-operations: 64 lanes per wave instruction
