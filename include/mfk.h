@@ -278,6 +278,8 @@ int mfk_comm_free(mfk_ctx *ctx);
 int mfk_allgather_sites(mfk_ctx *ctx, const void *rows, int64_t n_rows, int32_t row_bytes, const void *blob, int64_t blob_bytes,
                         int64_t pad_bytes, int64_t *counts);
 int mfk_allgather_fetch(mfk_ctx *ctx, int rank, void *rows, void *blob);
+/* all ranks at once: rows of rank 0, 1, ... back to back, and their blobs back to back (sizes: the counts of the gather) */
+int mfk_allgather_fetch_all(mfk_ctx *ctx, void *rows, void *blob);
 
 /* time spent in device work of the last compute call, milliseconds (HIP events on the ctx stream) */
 double mfk_last_device_ms(mfk_ctx *ctx);

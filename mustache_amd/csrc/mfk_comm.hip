@@ -167,3 +167,16 @@ extern "C" int mfk_allgather_fetch(mfk_ctx *ctx, int rank, void *rows, void *blo
     if (blob && bb) memcpy(blob, p + rb, bb);
     return 0;
 }
+
+// every rank's rows back to back (rank order) and every rank's strings back to back: one call instead of one per rank
+extern "C" int mfk_allgather_fetch_all(mfk_ctx *ctx, void *rows, void *blob) {
+    if (!ctx || ctx->comm_world < 1 || ctx->gat.empty()) return 1;
+    char *ro = static_cast<char *>(rows), *bo = static_cast<char *>(blob);
+    for (int r = 0; r < ctx->comm_world; r++) {
+        const char *p = reinterpret_cast<const char *>(ctx->gat.data()) + (size_t)r * ctx->gat_msg + 16;
+        const size_t rb = (size_t)ctx->gat_counts[2 * r] * (size_t)ctx->gat_row_bytes, bb = (size_t)ctx->gat_counts[2 * r + 1];
+        if (ro && rb) { memcpy(ro, p, rb); ro += rb; }
+        if (bo && bb) { memcpy(bo, p + rb, bb); bo += bb; }
+    }
+    return 0;
+}

@@ -134,6 +134,7 @@ class Binding:
             f("comm_free", C.c_int, [_p])
             f("allgather_sites", C.c_int, [_p, _p, C.c_int64, C.c_int32, _p, C.c_int64, C.c_int64, _p])
             f("allgather_fetch", C.c_int, [_p, C.c_int, _p, _p])
+            f("allgather_fetch_all", C.c_int, [_p, _p, _p])
         if hasattr(self.so, prefix + "profile_enable"):
             f("profile_enable", C.c_int, [_p, C.c_int])
             f("profile_fetch", C.c_int, [_p, _p, C.c_int64, _p, _p, C.c_int64, C.POINTER(C.c_int64)])
@@ -210,13 +211,15 @@ class Binding:
         counts = np.zeros(2 * self.comm_world, dtype=np.int64)
         self._check(self.allgather_sites(self.ctx, rows.ctypes.data, rows.shape[0], rows.dtype.itemsize, b.ctypes.data, len(blob),
                                          int(pad_bytes), counts.ctypes.data))
-        parts = []
-        for r in range(self.comm_world):
-            pr = np.zeros(int(counts[2 * r]), dtype=rows.dtype)
-            pb = np.zeros(max(int(counts[2 * r + 1]), 1), dtype=np.uint8)
-            self._check(self.allgather_fetch(self.ctx, r, pr.ctypes.data, pb.ctypes.data))
-            parts.append((pr, pb[:int(counts[2 * r + 1])].tobytes()))
-        return parts
+        # one fetch for all ranks, then views per rank (a step of the scaling bench gathers eight tables of a few dozen rows)
+        nr, nb = counts[0::2], counts[1::2]
+        allr = np.empty(int(nr.sum()), dtype=rows.dtype)
+        allb = np.empty(max(int(nb.sum()), 1), dtype=np.uint8)
+        self._check(self.allgather_fetch_all(self.ctx, allr.ctypes.data, allb.ctypes.data))
+        blob_all = allb.tobytes()
+        r0 = np.concatenate([[0], np.cumsum(nr)])
+        b0 = np.concatenate([[0], np.cumsum(nb)])
+        return [(allr[int(r0[r]):int(r0[r + 1])], blob_all[int(b0[r]):int(b0[r + 1])]) for r in range(self.comm_world)]
 
     def run_findflanks(self, reads, params, stop_after=STAGE_ALL):
         ns, nf, sb = C.c_int64(0), C.c_int64(0), C.c_int64(0)
