@@ -236,7 +236,8 @@ def time_config(hip, name, pool, device, steps=20, warmup=3, isolates=12):
     dt = time.perf_counter() - t0
     row = {"workload": name if batch is None else "%s (%d isolates in one call)" % (name, isolates), "reads": packed.n_reads,
            "ms_per_step": round(dt / steps * 1e3, 4), "reads_per_s": round(packed.n_reads * steps / dt, 1), "steps": steps,
-           "pairflanks_device_ms": round(dev_ms / steps, 4), "insertions": len(truth), "flank_rows": int(len(ff["flanks"])),
+           "device_span_ms": round(dev_ms / steps, 4),   # first to last HIP event of findflanks + of pairflanks (mfk_last_device_ms of the fused call)
+           "insertions": len(truth), "flank_rows": int(len(ff["flanks"])),
            "pairs": int(len(pf["pairs"])), "pool": pool, "generate_s": round(gen_s, 1)}
     del reads, g_dev, packed
     torch.cuda.empty_cache()
@@ -300,9 +301,55 @@ def end_to_end(n_records, tmp, device):
                 pass
 
 
+def launch_ranks(n, argv, launch_only):
+    """`python bench.py --gpus N` without an external launcher: this process starts N fresh child processes of the same
+    script (one rank per GPU: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set, as torch.distributed.run would),
+    relays rank 0's JSON line and exits non-zero if any child does.  The parent never touches the GPU: it imports neither
+    torch nor the library, and children are plain subprocess.Popen (no exec from a process that has initialised HIP).
+    The reference's counterpart is Snakemake's --cores starting one process per sample (main.py:44, Snakefile:64-109)."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), MFK_BENCH_CHILD="1")
+        # rank 0's stdout carries the one JSON line; in launch-only mode every child's line is collected
+        out = subprocess.PIPE if (r == 0 or launch_only) else sys.stderr
+        procs.append(subprocess.Popen([sys.executable, "-u", os.path.abspath(__file__)] + argv, env=env, stdout=out))
+    lines, failed = [], []
+    try:
+        # drain the pipes first (a child blocks on a full pipe), rank 0 first; then collect the exit codes
+        for r, p in enumerate(procs):
+            if p.stdout is not None:
+                lines.append((r, p.stdout.read().decode()))
+        for r, p in enumerate(procs):
+            if p.wait() != 0:
+                failed.append((r, p.returncode))
+    finally:
+        for p in procs:              # the exact children started here, by PID, if something above raised
+            if p.poll() is None:
+                p.kill()
+    if failed:
+        sys.stderr.write("bench.py: rank(s) %s exited non-zero\n" % ", ".join("%d (code %s)" % f for f in failed))
+        for _, text in lines:
+            sys.stderr.write(text)
+        sys.exit(1)
+    if launch_only:
+        ranks = [json.loads(text.strip().splitlines()[-1]) for _, text in lines]
+        print(json.dumps({"launch_only": True, "n_gpus": n, "ranks": ranks}), flush=True)
+    else:
+        sys.stdout.write(lines[0][1])
+        sys.stdout.flush()
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=None, help="ranks (one per GPU).  Without an external launcher (no WORLD_SIZE in the "
+                    "environment) N > 1 makes this process start N child ranks itself; under torch.distributed.run it must equal WORLD_SIZE")
+    ap.add_argument("--launch-only", action="store_true", help="every rank reports its rank / world size as a JSON line and exits before any GPU work (checks the launcher)")
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default="C2_saureus_1000x")
@@ -321,12 +368,32 @@ def main():
     if args.quick:
         args.no_cpu_baseline, args.table_configs, args.end_to_end_reads = True, "", 0
 
-    import numpy as np
-    from mustache_amd import pairflanks as pfh
-
+    # ---- ranks: an external launcher (WORLD_SIZE set) or our own (N children of this script) -----------------------------
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None:
+        if (args.gpus or 1) > 1:
+            return launch_ranks(args.gpus, sys.argv[1:], args.launch_only)
+        args.gpus = 1
+    else:
+        if args.gpus is None:
+            args.gpus = int(env_world)
+        if args.gpus != int(env_world):
+            sys.exit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%s ranks: the numbers must agree "
+                     "(a line that says n_gpus=%d measured on %s ranks would be wrong)" % (args.gpus, env_world, args.gpus, env_world))
+        for k in ("RANK", "LOCAL_RANK"):
+            if k not in os.environ:
+                sys.exit("bench.py: WORLD_SIZE is set but %s is not: start the ranks with torch.distributed.run or with plain `--gpus N`" % k)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.launch_only:
+        print(json.dumps({"rank": rank, "local_rank": local_rank, "world": world, "pid": os.getpid(),
+                          "master": "%s:%s" % (os.environ.get("MASTER_ADDR"), os.environ.get("MASTER_PORT"))}), flush=True)
+        return
+
+    import numpy as np
+    from mustache_amd import pairflanks as pfh
+
     sharded = args.sharding != "sample"
 
     from mustache_amd import lib
@@ -364,12 +431,21 @@ def main():
     if world > 1:
         merge = "torch.distributed all_gather (host-staged)"
         if args.merge == "library":
-            try:                                  # the same outcome on every rank: same image, same library
+            why = ""
+            try:
                 mdist.init_library_comm(hip)
+                ok = 1
+            except Exception as e:                # noqa: BLE001 -- reported in the JSON line, the run goes on with torch.distributed
+                ok, why = 0, str(e)
+            # every rank must take the same route: one rank on torch.distributed while the others sit in ncclAllGather is a deadlock
+            flag = torch.tensor([ok], dtype=torch.int32, device=device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 1:
                 lib_merge = hip
                 merge = "mfk_allgather_sites (RCCL inside libmfk.so, one ncclAllGather per table)"
-            except Exception as e:                # noqa: BLE001 -- reported in the JSON line, the run goes on with torch.distributed
-                merge += "; library communicator failed: %s" % e
+            else:
+                hip.free_comm()
+                merge += "; library communicator failed on %s: %s" % ("this rank" if not ok else "another rank", why)
     plan = None
     if sharded:
         h = mdist.halo(params.min_distance_to_mate, params.max_direct_repeat_length)
@@ -420,6 +496,7 @@ def main():
 
     # timed region: HIP events only around the watched kernels (two event records per launch are not free)
     hip.profile_only(watched)
+    mdist.reset_stats()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -429,6 +506,7 @@ def main():
     prof = hip.profile_totals()
     hip.profile_only(None)
     hip.profile(False)
+    xstats = dict(mdist.STATS)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -484,6 +562,10 @@ def main():
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
                "higher_is_better": True, "scaling": "strong" if sharded else "weak", "vs_baseline": None, "dtype": "u8/int32 (+f64 ratio tests)",
                "data": "synthetic",
+               # the exchange step, rank 0's view: tables of how many ranks the last all-gather returned (= n_gpus when the
+               # collective really ran over all ranks), host ms per step inside the all-gathers and in the selection / merges around them
+               "ranks_seen": int(xstats["ranks_seen"]), "gather_ms": round(xstats["gather_s"] / args.steps * 1e3, 4),
+               "merge_ms": round(xstats["merge_s"] / args.steps * 1e3, 4), "gathers_per_step": round(xstats["gathers"] / args.steps, 2),
                "config": {"workload": args.config, "reads_per_gpu": reads_here, "reads_total": total_reads,
                           "genome_bp": int(sum(cfg["contig_lens"])) * (args.isolates if batch is not None else 1),
                           "isolates_per_gpu": args.isolates if batch is not None else 1,

@@ -280,6 +280,10 @@ int mfk_allgather_sites(mfk_ctx *ctx, const void *rows, int64_t n_rows, int32_t 
 int mfk_allgather_fetch(mfk_ctx *ctx, int rank, void *rows, void *blob);
 /* all ranks at once: rows of rank 0, 1, ... back to back, and their blobs back to back (sizes: the counts of the gather) */
 int mfk_allgather_fetch_all(mfk_ctx *ctx, void *rows, void *blob);
+/* bytes per rank the next mfk_allgather_sites with pad_bytes <= 0 will exchange.  The hint behind it belongs to the
+ * communicator: mfk_comm_init / mfk_comm_free reset it to 16 KB, so ranks that join a new communicator with different
+ * gather histories still agree on the size (they must: ncclAllGather with unequal counts is undefined). */
+int64_t mfk_allgather_next_bytes(mfk_ctx *ctx);
 
 /* time spent in device work of the last compute call, milliseconds (HIP events on the ctx stream) */
 double mfk_last_device_ms(mfk_ctx *ctx);

@@ -119,6 +119,32 @@ int mfk_profile_fetch(mfk_ctx *ctx, char *names, int64_t names_cap, double *ms, 
 
 }  // extern "C"
 
+// ---- result-table memory (PinnedAlloc) -------------------------------------------------------------------------------
+#include <mutex>
+#include <unordered_set>
+static std::mutex g_pin_mu;
+static std::unordered_set<void *> g_pin_heap;   // blocks that came from malloc because hipHostMalloc refused
+void *mfk_pin_alloc(size_t bytes) {
+    void *p = nullptr;
+    static const bool no_pin = getenv("MFK_NO_PINNED_TABLES") != nullptr;   // test hook: every table in pageable memory
+    if (!no_pin && hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocMapped) == hipSuccess && p) return p;
+    (void)hipGetLastError();
+    p = malloc(bytes ? bytes : 1);
+    if (!p) throw std::bad_alloc();   // the heap itself is exhausted: as for any std::vector in the process
+    std::lock_guard<std::mutex> g(g_pin_mu);
+    g_pin_heap.insert(p);
+    return p;
+}
+void mfk_pin_free(void *p) {
+    if (!p) return;
+    {
+        std::lock_guard<std::mutex> g(g_pin_mu);
+        auto it = g_pin_heap.find(p);
+        if (it != g_pin_heap.end()) { g_pin_heap.erase(it); free(p); return; }
+    }
+    (void)hipHostFree(p);
+}
+
 void prof_begin(mfk_ctx *ctx, const char *name, hipStream_t stream) {
     if (!ctx->prof_on) return;
     ctx->prof_skip = false;

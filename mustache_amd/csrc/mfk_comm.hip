@@ -79,7 +79,18 @@ extern "C" int mfk_comm_free(mfk_ctx *ctx) {
         ctx->comm = nullptr;
     }
     ctx->comm_world = 0; ctx->comm_rank = 0;
+    // what the last gather left belongs to the communicator that made it: the size hint is only the same on every rank
+    // because every rank of THAT communicator saw the same headers; a ctx that joins another one starts from 16 KB again
+    ctx->gat_hint = 0; ctx->gat_msg = 0; ctx->gat_row_bytes = 0;
+    ctx->gat.clear(); ctx->gat_counts.clear();
     return 0;
+}
+
+// size of the next exchange when the caller passes pad_bytes <= 0 (diagnostic; tests check that a new communicator starts over)
+extern "C" int64_t mfk_allgather_next_bytes(mfk_ctx *ctx) {
+    if (!ctx) return -1;
+    size_t size = ctx->gat_hint ? ctx->gat_hint + ctx->gat_hint / 4 : ((size_t)16 << 10);
+    return (int64_t)((size + 255) & ~(size_t)255);
 }
 
 extern "C" int mfk_comm_init(mfk_ctx *ctx, const void *id128, int rank, int world) {

@@ -1143,6 +1143,7 @@ extern "C" int mfk_recall(mfk_ctx *ctx, const mfk_reads *reads, const mfk_params
     prof_collect(ctx);
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1) == hipSuccess) ctx->last_ms = ms;
+    ctx->call_ok = true;
     return 0;
 }
 

@@ -16,6 +16,9 @@
 
 struct Chunk { char *p; size_t cap, used; };
 
+void *mfk_pin_alloc(size_t bytes);   // mfk_api.hip: pinned + device-mapped, or heap memory (remembered as such) when pinning fails
+void mfk_pin_free(void *p);
+
 // Result tables live in pinned, device-mapped host memory: the gather kernel of a read-back writes them in place (no staging
 // copy of megabytes by the host; the tables of C5 are 4 MB per call).  Capacity survives clear(), so a loop over calls
 // allocates once.
@@ -23,12 +26,10 @@ template <typename T> struct PinnedAlloc {
     using value_type = T;
     PinnedAlloc() = default;
     template <typename U> PinnedAlloc(const PinnedAlloc<U> &) {}
-    T *allocate(size_t n) {
-        void *p = nullptr;
-        if (hipHostMalloc(&p, n * sizeof(T), hipHostMallocMapped) != hipSuccess || !p) { (void)hipGetLastError(); throw std::bad_alloc(); }
-        return static_cast<T *>(p);
-    }
-    void deallocate(T *p, size_t) { (void)hipHostFree(p); }
+    // pinned memory is scarcer than the heap: when hipHostMalloc refuses, the table lives in pageable memory (ReadBatch::flush
+    // stages read-backs into pageable destinations anyway), so no exception leaves an extern "C" entry point for that reason
+    T *allocate(size_t n) { return static_cast<T *>(mfk_pin_alloc(n * sizeof(T))); }
+    void deallocate(T *p, size_t) { mfk_pin_free(p); }
     template <typename U> bool operator==(const PinnedAlloc<U> &) const { return true; }
     template <typename U> bool operator!=(const PinnedAlloc<U> &) const { return false; }
 };

@@ -213,6 +213,7 @@ extern "C" int mfk_inferseq_pairs(mfk_ctx *ctx, const mfk_aln *alns, int64_t n, 
         for (auto &t : tmp) { ctx->isq_f.push_back(order[(size_t)pf[(size_t)t.second]]); ctx->isq_r.push_back(order[(size_t)pr[(size_t)t.second]]); }
     }
     *n_pairs = (int64_t)ctx->isq_f.size();
+    ctx->call_ok = true;   // only ctx->stream was used and it has been read back: the next arena_reset need not drain anything
     return 0;
 }
 
@@ -410,6 +411,7 @@ extern "C" int mfk_inferseq_db_pairs(mfk_ctx *ctx, const mfk_aln *alns, int64_t 
         }
     }
     *n_pairs = (int64_t)ctx->isq_f.size();
+    ctx->call_ok = true;   // only ctx->stream was used and it has been read back: the next arena_reset need not drain anything
     return 0;
 }
 

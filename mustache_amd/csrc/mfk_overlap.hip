@@ -82,5 +82,6 @@ extern "C" int mfk_overlap(mfk_ctx *ctx, const char *seqs5, const int64_t *off5,
     prof_collect(ctx);
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1) == hipSuccess) ctx->last_ms = ms;
+    ctx->call_ok = true;
     return 0;
 }

@@ -707,6 +707,7 @@ extern "C" int mfk_ir_detect(mfk_ctx *ctx, const char *seqs, const int64_t *off,
     HIPCHK(hipStreamSynchronize(st));
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1) == hipSuccess) ctx->last_ms = ms;
+    ctx->call_ok = true;
     return 0;
 }
 

@@ -277,7 +277,10 @@ _PAIR_STR = (("ir3_off", "ir3_len"), ("ir5_off", "ir5_len"), ("dr_ref_off", "dr_
 def shard_findflanks(binding, reads_struct, plan, params):
     """Stage 1 of one rank: ``mfk_findflanks`` on the rank's reads, keep the flank rows the rank owns.
     Returns (rows, seqs) with the sequences packed in row order."""
-    res = binding.run_findflanks(reads_struct, params)
+    return _own_flanks(binding.run_findflanks(reads_struct, params), plan)
+
+
+def _own_flanks(res, plan):
     fl = res["flanks"]
     mine = _fast_take(fl, np.flatnonzero(plan.owns(fl["contig_id"], fl["pos"]))) if len(fl) else fl
     return _compact(mine, res["seqs"], _FLANK_STR)
@@ -316,19 +319,27 @@ def _flank_rows_for(plan, tab, reach):
     return np.flatnonzero(keep)
 
 
-def shard_pairflanks(binding, reads_struct, plan, params, tab, seqs, contig_rank, genome, genome_off):
+def shard_pairflanks(binding, reads_struct, plan, params, tab, seqs, contig_rank, genome, genome_off, _timing=False):
     """Stage 2 of one rank: ``mfk_pairflanks`` on the merged rows around the rank's range (its reads cover the spanning
     fetches and direct-repeat windows of every pair whose 5p flank it owns: halo >= maxdr + 2 + half a window), keep those
     pairs; flank indices are rows of the merged table (quirk P2).  Returns (rows, strs)."""
+    import time
+    t0 = time.perf_counter()
     sel = _flank_rows_for(plan, tab, int(params.max_direct_repeat_length) + 1)
     if len(sel) == 0:
         return np.zeros(0, dtype=_lib.PAIR_DTYPE), b""
-    res = binding.run_pairflanks(reads_struct, params, _fast_take(tab, sel), seqs, contig_rank, genome, genome_off)
+    rows_in = _fast_take(tab, sel)
+    t1 = time.perf_counter()
+    res = binding.run_pairflanks(reads_struct, params, rows_in, seqs, contig_rank, genome, genome_off)
+    t2 = time.perf_counter()
     pr = res["pairs"]
     mine = _fast_take(pr, np.flatnonzero(plan.owns(pr["contig_id"], pr["pos_5p"]))) if len(pr) else pr
     mine["index_5p"] = sel[mine["index_5p"]]
     mine["index_3p"] = sel[mine["index_3p"]]
-    return _compact(mine, res["strs"], _PAIR_STR)
+    out = _compact(mine, res["strs"], _PAIR_STR)
+    if _timing:
+        STATS["merge_s"] += (t1 - t0) + (time.perf_counter() - t2)
+    return out
 
 
 def merge_pairs(parts, contig_rank, compacted=False):
@@ -370,6 +381,14 @@ def run_sharded_sequential(binding, reads_of, packed, params, world_size, shardi
 # ---------------------------------------------------------------------------------------------------------------------
 GATHER_CAP = 64 * 1024     # bytes per rank that travel in the first (normally only) collective
 
+# what the exchanges of this process have cost so far (bench.py reports them per step): seconds inside the all-gathers,
+# seconds of host-side selection / merging around them, and the number of ranks the last gather returned tables of
+STATS = {"gather_s": 0.0, "merge_s": 0.0, "gathers": 0, "ranks_seen": 1}
+
+
+def reset_stats():
+    STATS.update(gather_s=0.0, merge_s=0.0, gathers=0, ranks_seen=1)
+
 
 def _all_gather_bytes(mine, ws):
     """all-gather of equally sized uint8 tensors -> (ws, n) tensor."""
@@ -398,6 +417,16 @@ def init_library_comm(binding):
 
 
 def allgather_records(rows, blob, device=None, cap=GATHER_CAP, binding=None):
+    import time
+    t0 = time.perf_counter()
+    parts = _allgather_records(rows, blob, device, cap, binding)
+    STATS["gather_s"] += time.perf_counter() - t0
+    STATS["gathers"] += 1
+    STATS["ranks_seen"] = len(parts)
+    return parts
+
+
+def _allgather_records(rows, blob, device=None, cap=GATHER_CAP, binding=None):
     """All-gather of one table per rank (fixed-width rows + their string bytes) -> list over ranks of (rows, blob).
     Without torch.distributed initialised (or with one rank) it is [(rows, blob)].
 
@@ -455,12 +484,26 @@ def allgather_flanks(flanks, seqs, device=None, cap=GATHER_CAP, binding=None):
 
 def findflanks_sharded(binding, reads_struct, plan, params, device=None, cap=GATHER_CAP):
     """Stage 1 of the calling rank + the all-gather of the owned rows -> the merged flank table on every rank."""
-    rows, seqs = shard_findflanks(binding, reads_struct, plan, params)
-    return merge_flanks(allgather_records(rows, seqs, device, cap, binding if getattr(binding, "comm_world", 0) else None), compacted=True)
+    import time
+    res = binding.run_findflanks(reads_struct, params)
+    t0 = time.perf_counter()
+    rows, seqs = _own_flanks(res, plan)
+    t1 = time.perf_counter()
+    parts = allgather_records(rows, seqs, device, cap, binding if getattr(binding, "comm_world", 0) else None)
+    t2 = time.perf_counter()
+    out = merge_flanks(parts, compacted=True)
+    STATS["merge_s"] += (t1 - t0) + (time.perf_counter() - t2)
+    return out
 
 
 def pairflanks_sharded(binding, reads_struct, plan, params, tab, seqs, contig_rank, genome, genome_off, device=None,
                        cap=GATHER_CAP):
     """Stage 2 of the calling rank + the all-gather of its pairs -> the merged pair table on every rank."""
-    rows, strs = shard_pairflanks(binding, reads_struct, plan, params, tab, seqs, contig_rank, genome, genome_off)
-    return merge_pairs(allgather_records(rows, strs, device, cap, binding if getattr(binding, "comm_world", 0) else None), contig_rank, compacted=True)
+    import time
+    t0 = time.perf_counter()
+    rows, strs = shard_pairflanks(binding, reads_struct, plan, params, tab, seqs, contig_rank, genome, genome_off, _timing=True)
+    parts = allgather_records(rows, strs, device, cap, binding if getattr(binding, "comm_world", 0) else None)
+    t2 = time.perf_counter()
+    out = merge_pairs(parts, contig_rank, compacted=True)
+    STATS["merge_s"] += time.perf_counter() - t2
+    return out

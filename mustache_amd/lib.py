@@ -135,6 +135,7 @@ class Binding:
             f("allgather_sites", C.c_int, [_p, _p, C.c_int64, C.c_int32, _p, C.c_int64, C.c_int64, _p])
             f("allgather_fetch", C.c_int, [_p, C.c_int, _p, _p])
             f("allgather_fetch_all", C.c_int, [_p, _p, _p])
+            f("allgather_next_bytes", C.c_int64, [_p])
         if hasattr(self.so, prefix + "profile_enable"):
             f("profile_enable", C.c_int, [_p, C.c_int])
             f("profile_fetch", C.c_int, [_p, _p, C.c_int64, _p, _p, C.c_int64, C.POINTER(C.c_int64)])

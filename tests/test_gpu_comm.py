@@ -45,3 +45,29 @@ def test_init_library_comm_under_torch_distributed():
     finally:
         dist.destroy_process_group()
         hip.free_comm()
+
+
+@pytest.mark.gpu
+def test_new_communicator_starts_from_the_first_size():
+    """The size of a pad_bytes = 0 exchange follows the previous gather of the SAME communicator only: a ctx that joins
+    another communicator must start from 16 KB again, or ranks with different histories call ncclAllGather with
+    different counts."""
+    hip = lib.load(0)
+    hip.init_comm(hip.make_comm_id(), 0, 1)
+    try:
+        assert hip.allgather_next_bytes(hip.ctx) == 16 << 10
+        rows = np.zeros(9000, dtype=lib.FLANK_DTYPE)
+        rows["pos"] = np.arange(9000)
+        parts = hip.run_allgather(rows, b"x" * 100, 0)
+        assert parts[0][0].tobytes() == rows.tobytes()
+        big = hip.allgather_next_bytes(hip.ctx)
+        assert big >= 9000 * lib.FLANK_DTYPE.itemsize          # the hint follows the large table ...
+        hip.init_comm(hip.make_comm_id(), 0, 1)                # ... and a new communicator forgets it
+        assert hip.allgather_next_bytes(hip.ctx) == 16 << 10
+        small = np.zeros(3, dtype=lib.FLANK_DTYPE)
+        parts = hip.run_allgather(small, b"abc", 0)
+        assert parts[0][0].tobytes() == small.tobytes() and parts[0][1] == b"abc"
+        hip.free_comm()
+        assert hip.allgather_next_bytes(hip.ctx) == 16 << 10
+    finally:
+        hip.free_comm()
