@@ -18,10 +18,16 @@ def _device_reads(hip, packed):
     return device_reads(hip, packed, "cuda:0")
 
 
-@pytest.mark.parametrize("name", util.CASES)
-def test_golden_tsvs_bit_exact(hip, name):
-    """findflanks + pairflanks TSVs equal to what the reference printed (IR columns: build's definition)."""
+@pytest.mark.parametrize("name", util.ALL_CASES)
+@pytest.mark.parametrize("small_jobs", [True, False])
+def test_golden_tsvs_bit_exact(hip, name, small_jobs, monkeypatch):
+    """findflanks + pairflanks TSVs equal to what the reference printed (IR columns: build's definition), with the consensus
+    through k_job_small where a job fits it and through the device-wide kernels for every job (MFK_NO_SMALL_JOBS).  The
+    deep_* cases (tests/golden/make_golden_deep.py) hold hundreds of leaves and several clusters per site-side, IUPAC clip
+    bases, clips past 200 bases and two surviving consensus sequences per side."""
     import torch
+    if not small_jobs:
+        monkeypatch.setenv("MFK_NO_SMALL_JOBS", "1")
     case = util.load_json(name)
     rs = util.case_readset(case)
     packed = pack_reads(rs.contigs, rs, pool="all")

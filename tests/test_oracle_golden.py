@@ -8,7 +8,7 @@ from mustache_amd.pack import pack_reads
 from tests import util
 
 
-@pytest.mark.parametrize("name", util.CASES)
+@pytest.mark.parametrize("name", util.ALL_CASES)
 def test_oracle_reproduces_reference_tsvs(oracle, name):
     case = util.load_json(name)
     rs = util.case_readset(case)

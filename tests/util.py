@@ -15,6 +15,10 @@ from mustache_amd.records import AlignedRead, ReadSet, parse_cigar_string
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 CASES = ["quirks", "sim_a", "sim_b", "sim_c", "sim_d"]
+# made by tests/golden/make_golden_deep.py (the reference itself, three hash seeds): hundreds of leaves and several clusters per
+# site-side, N / IUPAC clip bases, 250-bp reads with clips past 200 bases, two surviving consensus sequences per side
+DEEP_CASES = ["deep_clusters", "deep_iupac", "deep_long", "deep_two"]
+ALL_CASES = CASES + DEEP_CASES
 
 
 def load_json(name):
