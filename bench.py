@@ -291,10 +291,12 @@ def end_to_end(n_records, tmp, device):
         return {"records": n_rec, "bam_bytes": os.path.getsize(bam), "contigs": len(contigs), "flank_rows": int(len(got_ff)), "pairs": int(len(got_pf)),
                 "findflanks_s": round(t1 - t0, 3), "pairflanks_s": round(t2 - t1, 3),
                 "value": round(n_rec / (t2 - t0), 1), "unit": "reads/s",
-                "what": "BAM + FASTA files -> findflanks TSV -> pairflanks TSV (two BAM passes like the reference's two commands), host decode threads = %s" % os.environ.get("OMP_NUM_THREADS", "all"),
+                "what": "BAM + FASTA files -> findflanks TSV -> pairflanks TSV (two commands like the reference's; findflanks inflates the whole file and leaves a record index, "
+                        "pairflanks reads only the BGZF blocks around its candidate regions through it, as bam.fetch does through the BAI), host decode threads = %s" % os.environ.get("OMP_NUM_THREADS", "all"),
+                "record_index_bytes": os.path.getsize(tsv1 + ".mfki") if os.path.exists(tsv1 + ".mfki") else None,
                 "tables_equal_base_repeated": bool(ok), "write_inputs_s": round(write_s, 1)}
     finally:
-        for p in (bam, fa, one, one + ".fa", tsv1, tsv2):
+        for p in (bam, fa, one, one + ".fa", tsv1, tsv2, tsv1 + ".mfki"):
             try:
                 os.remove(p)
             except OSError:

@@ -40,7 +40,9 @@ enum {
     MFKIO_ERR_IO = 1,        /* cannot open / map the file                                  */
     MFKIO_ERR_FORMAT = 2,    /* not BGZF / not BAM / truncated / checksum mismatch          */
     MFKIO_ERR_PACK = 3,      /* a record the packer rejects (same cases as pack.PackError)  */
-    MFKIO_ERR_ARG = 4
+    MFKIO_ERR_ARG = 4,
+    MFKIO_ERR_INDEX = 5      /* mfkio_pack_bam_regions_indexed: no usable record index (missing, stale, another FLAG
+                                filter): run mfkio_pack_bam_filtered instead                 */
 };
 
 /* One candidate region of pairflanks (mustache_amd/pairflanks.py::candidate_regions): reads with
@@ -93,6 +95,20 @@ int mfkio_pack_bam(const char *path, int pool_mode, const mfkio_region *regions,
  * "more than two reads of one query name" abort of findflanks.py:971-978. */
 int mfkio_pack_bam_filtered(const char *path, int pool_mode, const mfkio_region *regions, int64_t n_regions, int n_threads,
                             int64_t chunk_bytes, uint32_t exclude_flags, mfkio_pack **out);
+
+/* Record index: what lets pairflanks read only the reads over its candidate regions, as the reference does through the BAI
+ * and bam.fetch (pairflanks.py:393-409) -- findflanks has to inflate every block anyway (findflanks.py:100-121) and leaves,
+ * per 32 KiB of the uncompressed stream, the offset of a record and its (reference id, position), plus the BGZF block table.
+ *   mfkio_pack_bam_index:           mfkio_pack_bam_filtered (pool_mode NONE / CLIPPED / ALL) that also writes the index
+ *                                   to `index_out` (best effort: a path that cannot be written is not an error).
+ *   mfkio_pack_bam_regions_indexed: mfkio_pack_bam_filtered(MFKIO_POOL_REGIONS) through the index: only the BGZF blocks
+ *                                   between the marks around each region are inflated.  Same arrays, byte for byte.
+ *                                   MFKIO_ERR_INDEX when the index is missing or was made for another file (size, mtime)
+ *                                   or FLAG filter: the caller falls back to the full pass. */
+int mfkio_pack_bam_index(const char *path, int pool_mode, int n_threads, int64_t chunk_bytes, uint32_t exclude_flags, const char *index_out,
+                         mfkio_pack **out);
+int mfkio_pack_bam_regions_indexed(const char *path, const char *index_path, const mfkio_region *regions, int64_t n_regions, int n_threads,
+                                   uint32_t exclude_flags, mfkio_pack **out);
 const mfkio_arrays *mfkio_pack_arrays(const mfkio_pack *p);
 const char *mfkio_pack_error(const mfkio_pack *p);
 void mfkio_pack_free(mfkio_pack *p);

@@ -79,6 +79,30 @@ struct Block {
     uint32_t crc;
 };
 
+// One BGZF block header (SAM spec 4.1: a gzip member with a 'BC' extra subfield holding the block size) at file offset o.
+// Returns nullptr and fills *b / *bsize, or the reason the bytes are not a block.
+const char *block_header(const uint8_t *file, size_t fsize, size_t o, const char *path, Block *b, size_t *bsize_out) {
+    static thread_local std::string msg;
+    if (o + 18 > fsize) return "truncated BGZF block header";
+    const uint8_t *h = file + o;
+    if (h[0] != 31 || h[1] != 139 || h[2] != 8 || !(h[3] & 4)) { msg = std::string(path) + " is not a BGZF (BAM) file"; return msg.c_str(); }
+    size_t xlen = le16(h + 10), x = 12, bsize = 0;
+    if (o + 12 + xlen > fsize) return "truncated BGZF block header";
+    while (x + 4 <= 12 + xlen) {
+        size_t slen = le16(h + x + 2);
+        if (h[x] == 66 && h[x + 1] == 67 && slen == 2 && x + 6 <= 12 + xlen) bsize = (size_t)le16(h + x + 4) + 1;
+        x += 4 + slen;
+    }
+    if (!bsize || bsize < 12 + xlen + 8 || o + bsize > fsize) return "bad BGZF block size";
+    b->payload = o + 12 + xlen;
+    b->clen = (uint32_t)(bsize - 12 - xlen - 8);
+    b->crc = le32(h + bsize - 8);
+    b->ulen = le32(h + bsize - 4);
+    if (b->ulen > 65536) return "BGZF block larger than 64 KiB";
+    *bsize_out = bsize;
+    return nullptr;
+}
+
 // disjoint sorted intervals + the (never seen in practice) inverted ones, kept so the test equals the Python predicate
 struct IvSet {
     std::vector<int32_t> lo, hi;
@@ -108,6 +132,13 @@ struct Shared {
     std::vector<IvSet> near_, win_;
 };
 
+// Record index: one mark per IDX_GRANULE bytes of the uncompressed stream = the offset of a record that starts there and
+// that record's (reference id, position).  A coordinate-sorted file read from a mark onwards only holds records at or
+// behind the mark's coordinate, so the reads over a region are found by inflating the few BGZF blocks between two marks
+// (pairflanks: the reference does the same through the BAI and bam.fetch, pairflanks.py:393-409).
+#define IDX_GRANULE ((uint64_t)32 << 10)
+struct IdxEntry { uint64_t u; int32_t ref, pos; };
+
 // what one thread produced from its share of one pass
 struct Local {
     std::vector<int32_t> ref_start, ref_end;
@@ -121,6 +152,8 @@ struct Local {
     std::vector<uint8_t> pool_bases, pool_quals;
     int32_t max_span = 0;
     int64_t first_key = -1, last_key = -1;
+    std::vector<IdxEntry> idx;   // block-index marks of this share (see "record index" below)
+    uint64_t next_mark = 0;
     std::string err;
     bool format_err = false;  // err is about the file's bytes (MFKIO_ERR_FORMAT), not a record the packer rejects
     void clear() {
@@ -129,6 +162,7 @@ struct Local {
         cx_read.clear(); cx_nblk.clear(); pool_read.clear(); pool_plen.clear();
         blk_start.clear(); blk_end.clear(); blk_ins.clear(); pool_bases.clear(); pool_quals.clear();
         max_span = 0; first_key = last_key = -1; err.clear(); format_err = false;
+        idx.clear(); next_mark = 0;
     }
 };
 
@@ -357,6 +391,7 @@ struct mfkio_pack {
     std::vector<char> contig_names;
     int32_t max_span = 0;
     int64_t last_key = -1;
+    std::vector<IdxEntry> index;   // marks in file order (full passes with an index file to write)
 };
 
 namespace {
@@ -486,8 +521,169 @@ bool chain_plausible(const Shared &sh, const uint8_t *buf, size_t q, size_t len)
     return true;
 }
 
+// links, first read of every contig, and the array pointers of the finished pack.  Returns the time the link pass began.
+double finish_pack(mfkio_pack *P, int n_contigs, int T, double *t_links_done) {
+    double t2 = now_s();
+    compute_links(P, T);
+    *t_links_done = now_s();
+    // first read of each contig
+    P->contig_read_start.assign((size_t)n_contigs + 1, 0);
+    for (int c = 0; c <= n_contigs; ++c)
+        P->contig_read_start[(size_t)c] = std::lower_bound(P->contig_id.p, P->contig_id.p + P->contig_id.n, (uint32_t)c,
+                                                            [](uint16_t a, uint32_t b) { return (uint32_t)a < b; }) - P->contig_id.p;
+    // release what only the link pass needed
+    P->hash.release();
+    P->name_off.release();
+    P->name_len.release();
+    P->names.release();
+
+    mfkio_arrays &a = P->a;
+    a.n_reads = (int64_t)P->ref_start.size();
+    a.n_contigs = n_contigs;
+    a.max_span = P->max_span;
+    a.n_cx = (int64_t)P->cx_read.size();
+    a.n_blk = (int64_t)P->blk_start.size();
+    a.n_pool = (int64_t)P->pool_read.size();
+    a.pool_bases_bytes = (int64_t)P->pool_bases.size();
+    a.pool_quals_bytes = (int64_t)P->pool_quals.size();
+    a.ref_start = P->ref_start.data(); a.ref_end = P->ref_end.data(); a.link = P->link.data();
+    a.contig_id = P->contig_id.data(); a.qlen = P->qlen.data(); a.first_op_len = P->first_op.data();
+    a.last_op_len = P->last_op.data(); a.mapq = P->mapq.data(); a.flags = P->flags.data();
+    a.contig_len = P->contig_len.data(); a.contig_read_start = P->contig_read_start.data();
+    a.cx_read = P->cx_read.data(); a.cx_off = P->cx_off.data();
+    a.blk_start = P->blk_start.data(); a.blk_end = P->blk_end.data(); a.blk_ins = P->blk_ins.data();
+    a.pool_read = P->pool_read.data(); a.pool_off = P->pool_off.data();
+    a.pool_bases = P->pool_bases.data(); a.pool_quals = P->pool_quals.data();
+    a.contig_names = P->contig_names.data();
+    a.contig_names_bytes = (int64_t)P->contig_names.size();
+    return t2;
+}
+
+
+// ---- record index file ---------------------------------------------------------------------------------------------
+// "MFKI0002" | bam size u64 | bam mtime ns i64 | uncompressed bytes u64 | first record offset u64 | max_span i32 |
+// exclude_flags u32 | n_marks u64 | n_blocks u64 | marks (u64 offset, i32 ref, i32 pos) | blocks (u64 file offset, u64 first
+// uncompressed byte).  Written next to the findflanks table by a full pass, read by the region pass of pairflanks; a file
+// that does not match the BAM it is used with (size, mtime, FLAG filter) is ignored.
+static const char IDX_MAGIC[8] = {'M', 'F', 'K', 'I', '0', '0', '0', '2'};
+inline int64_t mtime_ns(const struct stat &st) { return (int64_t)st.st_mtim.tv_sec * 1000000000ll + (int64_t)st.st_mtim.tv_nsec; }
+
+void write_index(mfkio_pack *P, const char *path, const struct stat &st, uint64_t total_u, uint32_t exclude_flags,
+                 const std::vector<Block> &blocks, const std::vector<uint64_t> &block_at, uint64_t hdr_u_end) {
+    std::string tmp = std::string(path) + ".tmp";
+    FILE *f = fopen(tmp.c_str(), "wb");
+    if (!f) return;
+    uint64_t h64[4] = {(uint64_t)st.st_size, (uint64_t)mtime_ns(st), total_u, hdr_u_end};
+    int32_t h32[2] = {P->max_span, (int32_t)exclude_flags};
+    uint64_t n[2] = {(uint64_t)P->index.size(), (uint64_t)blocks.size()};
+    bool ok = fwrite(IDX_MAGIC, 8, 1, f) == 1 && fwrite(h64, sizeof h64, 1, f) == 1 && fwrite(h32, sizeof h32, 1, f) == 1 && fwrite(n, sizeof n, 1, f) == 1;
+    if (ok && !P->index.empty()) ok = fwrite(P->index.data(), sizeof(IdxEntry), P->index.size(), f) == P->index.size();
+    uint64_t u = 0;
+    for (size_t k = 0; ok && k < blocks.size(); ++k) {
+        uint64_t row[2] = {block_at[k], u};
+        ok = fwrite(row, sizeof row, 1, f) == 1;
+        u += blocks[k].ulen;
+    }
+    ok = fclose(f) == 0 && ok;
+    if (!ok || rename(tmp.c_str(), path) != 0) unlink(tmp.c_str());
+}
+
+struct Index {
+    uint64_t bam_size = 0, total_u = 0, hdr_u_end = 0;
+    int64_t bam_mtime = 0;
+    int32_t max_span = 0;
+    uint32_t exclude_flags = 0;
+    std::vector<IdxEntry> marks;
+    std::vector<uint64_t> block_at, block_u;
+};
+
+bool load_index(const char *path, Index *ix) {
+    FILE *f = fopen(path, "rb");
+    if (!f) return false;
+    char magic[8];
+    uint64_t h64[4], n[2];
+    int32_t h32[2];
+    bool ok = fread(magic, 8, 1, f) == 1 && memcmp(magic, IDX_MAGIC, 8) == 0 && fread(h64, sizeof h64, 1, f) == 1 &&
+              fread(h32, sizeof h32, 1, f) == 1 && fread(n, sizeof n, 1, f) == 1 && n[0] < ((uint64_t)1 << 32) && n[1] < ((uint64_t)1 << 32);
+    if (ok) {
+        ix->bam_size = h64[0]; ix->bam_mtime = (int64_t)h64[1]; ix->total_u = h64[2]; ix->hdr_u_end = h64[3];
+        ix->max_span = h32[0]; ix->exclude_flags = (uint32_t)h32[1];
+        ix->marks.resize((size_t)n[0]);
+        ok = n[0] == 0 || fread(ix->marks.data(), sizeof(IdxEntry), (size_t)n[0], f) == (size_t)n[0];
+        std::vector<uint64_t> rows((size_t)n[1] * 2);
+        ok = ok && (n[1] == 0 || fread(rows.data(), 16, (size_t)n[1], f) == (size_t)n[1]);
+        if (ok) {
+            ix->block_at.resize((size_t)n[1]); ix->block_u.resize((size_t)n[1]);
+            for (size_t k = 0; k < (size_t)n[1]; ++k) { ix->block_at[k] = rows[2 * k]; ix->block_u[k] = rows[2 * k + 1]; }
+        }
+    }
+    fclose(f);
+    // marks and blocks ascend, or the file is not one of ours
+    for (size_t k = 1; ok && k < ix->marks.size(); ++k) ok = ix->marks[k].u > ix->marks[k - 1].u;
+    for (size_t k = 1; ok && k < ix->block_u.size(); ++k) ok = ix->block_u[k] > ix->block_u[k - 1] && ix->block_at[k] > ix->block_at[k - 1];
+    return ok;
+}
+
+// Shares (or index ranges) that were parsed side by side go into the pack in file order: offsets first (sequential, a few
+// numbers per share), then parallel copies.
+int place_shares(mfkio_pack *P, std::vector<Local> &locals, int S, const std::vector<int64_t> &seg_records, int64_t &n_records, bool keep_index) {
+    // place the shares in file order: offsets first (sequential, a few numbers per share), then parallel copies
+    struct Base { size_t reads, names, cx, blk, pool, pbytes, qbytes; };
+    std::vector<Base> base((size_t)S);
+    Base cur{P->ref_start.size(), P->names.size(), P->cx_read.size(), P->blk_start.size(), P->pool_read.size(),
+             P->pool_bases.size(), P->pool_quals.size()};
+    for (int s = 0; s < S; ++s) {
+        Local &L = locals[(size_t)s];
+        if (!L.err.empty()) return fail(P, L.format_err ? MFKIO_ERR_FORMAT : MFKIO_ERR_PACK, L.err);  // first in file order
+        n_records += seg_records[(size_t)s];
+        base[(size_t)s] = cur;
+        if (L.ref_start.empty()) continue;
+        if (L.first_key < P->last_key)
+            return fail(P, MFKIO_ERR_PACK, "alignments are not coordinate-sorted (the reference needs a sorted, indexed BAM)");
+        P->last_key = L.last_key;
+        if (L.max_span > P->max_span) P->max_span = L.max_span;
+        cur.reads += L.ref_start.size(); cur.names += L.names.size(); cur.cx += L.cx_read.size();
+        cur.blk += L.blk_start.size(); cur.pool += L.pool_read.size(); cur.pbytes += L.pool_bases.size();
+        cur.qbytes += L.pool_quals.size();
+    }
+    if (cur.reads > (size_t)INT32_MAX) return fail(P, MFKIO_ERR_PACK, "more than 2^31-1 reads");
+    if (cur.blk > (size_t)UINT32_MAX) return fail(P, MFKIO_ERR_PACK, "more than 2^32-1 aligned blocks");
+    P->ref_start.grow(cur.reads); P->ref_end.grow(cur.reads); P->contig_id.grow(cur.reads); P->qlen.grow(cur.reads);
+    P->first_op.grow(cur.reads); P->last_op.grow(cur.reads); P->mapq.grow(cur.reads); P->flags.grow(cur.reads);
+    P->name_len.grow(cur.reads); P->hash.grow(cur.reads); P->name_off.grow(cur.reads); P->names.grow(cur.names);
+    P->cx_read.grow(cur.cx); P->cx_off.grow(cur.cx + 1); P->blk_start.grow(cur.blk); P->blk_end.grow(cur.blk);
+    P->blk_ins.grow(cur.blk); P->pool_read.grow(cur.pool); P->pool_off.grow(cur.pool + 1);
+    P->pool_bases.grow(cur.pbytes); P->pool_quals.grow(cur.qbytes);
+    parallel(S, [&](int s) {
+        const Local &L = locals[(size_t)s];
+        const Base &b = base[(size_t)s];
+        put(P->ref_start, b.reads, L.ref_start); put(P->ref_end, b.reads, L.ref_end);
+        put(P->contig_id, b.reads, L.contig_id); put(P->qlen, b.reads, L.qlen); put(P->first_op, b.reads, L.first_op);
+        put(P->last_op, b.reads, L.last_op); put(P->mapq, b.reads, L.mapq); put(P->flags, b.reads, L.flags);
+        put(P->name_len, b.reads, L.name_len); put(P->hash, b.reads, L.hash); put(P->names, b.names, L.names);
+        for (size_t k = 0; k < L.name_off.size(); ++k) P->name_off.p[b.reads + k] = b.names + L.name_off[k];
+        uint32_t boff = (uint32_t)b.blk;
+        for (size_t k = 0; k < L.cx_read.size(); ++k) {
+            P->cx_read.p[b.cx + k] = (uint32_t)(b.reads + L.cx_read[k]);
+            boff += L.cx_nblk[k];
+            P->cx_off.p[b.cx + k + 1] = boff;
+        }
+        put(P->blk_start, b.blk, L.blk_start); put(P->blk_end, b.blk, L.blk_end); put(P->blk_ins, b.blk, L.blk_ins);
+        uint64_t poff = b.qbytes;                             // base offsets count padded bases = quality bytes
+        for (size_t k = 0; k < L.pool_read.size(); ++k) {
+            P->pool_read.p[b.pool + k] = (uint32_t)(b.reads + L.pool_read[k]);
+            poff += L.pool_plen[k];
+            P->pool_off.p[b.pool + k + 1] = poff;
+        }
+        put(P->pool_bases, b.pbytes, L.pool_bases); put(P->pool_quals, b.qbytes, L.pool_quals);
+    });
+    if (keep_index)
+        for (int s = 0; s < S; ++s) P->index.insert(P->index.end(), locals[(size_t)s].idx.begin(), locals[(size_t)s].idx.end());
+    return MFKIO_OK;
+}
+
 int run(mfkio_pack *P, const char *path, int pool_mode, const mfkio_region *regions, int64_t n_regions, int T,
-        int64_t chunk_bytes, uint32_t exclude_flags) {
+        int64_t chunk_bytes, uint32_t exclude_flags, const char *index_out) {
     double t_begin = now_s(), t_inflate = 0, t_parse = 0, t_par = 0, t_merge = 0;
     if (pool_mode < MFKIO_POOL_NONE || pool_mode > MFKIO_POOL_REGIONS) return fail(P, MFKIO_ERR_ARG, "bad pool_mode");
     if (pool_mode == MFKIO_POOL_REGIONS && n_regions > 0 && !regions) return fail(P, MFKIO_ERR_ARG, "regions is NULL");
@@ -509,25 +705,11 @@ int run(mfkio_pack *P, const char *path, int pool_mode, const mfkio_region *regi
     // BGZF block table (SAM spec 4.1): gzip members with a 'BC' extra subfield holding the block size
     std::vector<Block> blocks;
     uint64_t total_u = 0;
+    std::vector<uint64_t> block_at;   // file offset of every block kept in `blocks` (for the index)
     for (size_t o = 0; o < fsize;) {
-        if (o + 18 > fsize) return fail(P, MFKIO_ERR_FORMAT, "truncated BGZF block header");
-        const uint8_t *h = file + o;
-        if (h[0] != 31 || h[1] != 139 || h[2] != 8 || !(h[3] & 4)) return fail(P, MFKIO_ERR_FORMAT, std::string(path) + " is not a BGZF (BAM) file");
-        size_t xlen = le16(h + 10), x = 12, bsize = 0;
-        if (o + 12 + xlen > fsize) return fail(P, MFKIO_ERR_FORMAT, "truncated BGZF block header");
-        while (x + 4 <= 12 + xlen) {
-            size_t slen = le16(h + x + 2);
-            if (h[x] == 66 && h[x + 1] == 67 && slen == 2 && x + 6 <= 12 + xlen) bsize = (size_t)le16(h + x + 4) + 1;
-            x += 4 + slen;
-        }
-        if (!bsize || bsize < 12 + xlen + 8 || o + bsize > fsize) return fail(P, MFKIO_ERR_FORMAT, "bad BGZF block size");
-        Block b;
-        b.payload = o + 12 + xlen;
-        b.clen = (uint32_t)(bsize - 12 - xlen - 8);
-        b.crc = le32(h + bsize - 8);
-        b.ulen = le32(h + bsize - 4);
-        if (b.ulen > 65536) return fail(P, MFKIO_ERR_FORMAT, "BGZF block larger than 64 KiB");
-        if (b.ulen) { blocks.push_back(b); total_u += b.ulen; }
+        Block b; size_t bsize = 0;
+        if (const char *why = block_header(file, fsize, o, path, &b, &bsize)) return fail(P, MFKIO_ERR_FORMAT, why);
+        if (b.ulen) { blocks.push_back(b); if (index_out) block_at.push_back(o); total_u += b.ulen; }
         o += bsize;
     }
 
@@ -543,12 +725,14 @@ int run(mfkio_pack *P, const char *path, int pool_mode, const mfkio_region *regi
     uint8_t *buf = nullptr;
     struct Free { uint8_t **p; ~Free() { free(*p); } } free_buf{&buf};
     bool header_done = false;
+    uint64_t hdr_u_end = 0;   // offset of the first alignment record in the uncompressed stream
     int64_t n_records = 0, n_redone = 0;
     P->cx_off.grow(1);
     P->cx_off.p[0] = 0;
     P->pool_off.grow(1);
     P->pool_off.p[0] = 0;
 
+    uint64_t u_done = 0;   // uncompressed bytes of the blocks before this pass
     for (size_t b0 = 0; b0 < blocks.size();) {
         size_t b1 = b0;
         uint64_t usum = 0;
@@ -559,6 +743,8 @@ int run(mfkio_pack *P, const char *path, int pool_mode, const mfkio_region *regi
             ++b1;
         }
         size_t len = carry + (size_t)usum;
+        const uint64_t pass_base = u_done - carry;   // offset in the uncompressed stream of buf[0]
+        u_done += usum;
         if (len > cap) {
             size_t ncap = len + len / 4 + 65536;
             uint8_t *nb = (uint8_t *)realloc(buf, ncap);
@@ -616,6 +802,7 @@ int run(mfkio_pack *P, const char *path, int pool_mode, const mfkio_region *regi
             if (h == 0) { carry = len; continue; }
             header_done = true;
             off = (size_t)h;
+            hdr_u_end = pass_base + off;
             if (P->contig_len.size() > 65535) return fail(P, MFKIO_ERR_PACK, "more than 65535 contigs");
             sh.n_contigs = (int32_t)P->contig_len.size();
             if (pool_mode == MFKIO_POOL_REGIONS) {
@@ -643,6 +830,13 @@ int run(mfkio_pack *P, const char *path, int pool_mode, const mfkio_region *regi
                 uint32_t bs = le32(buf + o);
                 if (bs < 32 || bs > (1u << 30)) { L.err = "bad alignment record size (corrupt file)"; L.format_err = true; break; }
                 if (o + 4 + (size_t)bs > len) break;
+                if (index_out) {
+                    const uint64_t au = pass_base + o;
+                    if (au >= L.next_mark) {
+                        L.idx.push_back({au, (int32_t)le32(buf + o + 4), (int32_t)le32(buf + o + 8)});
+                        L.next_mark = (au / IDX_GRANULE + 1) * IDX_GRANULE;
+                    }
+                }
                 if (!parse_record(sh, buf + o + 4, bs, L)) break;
                 o += 4 + (size_t)bs;
                 ++nrec;
@@ -682,56 +876,7 @@ int run(mfkio_pack *P, const char *path, int pool_mode, const mfkio_region *regi
         }
         double tp = now_s();
         t_par += tp - t1;
-        // place the shares in file order: offsets first (sequential, a few numbers per share), then parallel copies
-        struct Base { size_t reads, names, cx, blk, pool, pbytes, qbytes; };
-        std::vector<Base> base((size_t)S);
-        Base cur{P->ref_start.size(), P->names.size(), P->cx_read.size(), P->blk_start.size(), P->pool_read.size(),
-                 P->pool_bases.size(), P->pool_quals.size()};
-        for (int s = 0; s < S; ++s) {
-            Local &L = locals[(size_t)s];
-            if (!L.err.empty()) return fail(P, L.format_err ? MFKIO_ERR_FORMAT : MFKIO_ERR_PACK, L.err);  // first in file order
-            n_records += seg_records[(size_t)s];
-            base[(size_t)s] = cur;
-            if (L.ref_start.empty()) continue;
-            if (L.first_key < P->last_key)
-                return fail(P, MFKIO_ERR_PACK, "alignments are not coordinate-sorted (the reference needs a sorted, indexed BAM)");
-            P->last_key = L.last_key;
-            if (L.max_span > P->max_span) P->max_span = L.max_span;
-            cur.reads += L.ref_start.size(); cur.names += L.names.size(); cur.cx += L.cx_read.size();
-            cur.blk += L.blk_start.size(); cur.pool += L.pool_read.size(); cur.pbytes += L.pool_bases.size();
-            cur.qbytes += L.pool_quals.size();
-        }
-        if (cur.reads > (size_t)INT32_MAX) return fail(P, MFKIO_ERR_PACK, "more than 2^31-1 reads");
-        if (cur.blk > (size_t)UINT32_MAX) return fail(P, MFKIO_ERR_PACK, "more than 2^32-1 aligned blocks");
-        P->ref_start.grow(cur.reads); P->ref_end.grow(cur.reads); P->contig_id.grow(cur.reads); P->qlen.grow(cur.reads);
-        P->first_op.grow(cur.reads); P->last_op.grow(cur.reads); P->mapq.grow(cur.reads); P->flags.grow(cur.reads);
-        P->name_len.grow(cur.reads); P->hash.grow(cur.reads); P->name_off.grow(cur.reads); P->names.grow(cur.names);
-        P->cx_read.grow(cur.cx); P->cx_off.grow(cur.cx + 1); P->blk_start.grow(cur.blk); P->blk_end.grow(cur.blk);
-        P->blk_ins.grow(cur.blk); P->pool_read.grow(cur.pool); P->pool_off.grow(cur.pool + 1);
-        P->pool_bases.grow(cur.pbytes); P->pool_quals.grow(cur.qbytes);
-        parallel(S, [&](int s) {
-            const Local &L = locals[(size_t)s];
-            const Base &b = base[(size_t)s];
-            put(P->ref_start, b.reads, L.ref_start); put(P->ref_end, b.reads, L.ref_end);
-            put(P->contig_id, b.reads, L.contig_id); put(P->qlen, b.reads, L.qlen); put(P->first_op, b.reads, L.first_op);
-            put(P->last_op, b.reads, L.last_op); put(P->mapq, b.reads, L.mapq); put(P->flags, b.reads, L.flags);
-            put(P->name_len, b.reads, L.name_len); put(P->hash, b.reads, L.hash); put(P->names, b.names, L.names);
-            for (size_t k = 0; k < L.name_off.size(); ++k) P->name_off.p[b.reads + k] = b.names + L.name_off[k];
-            uint32_t boff = (uint32_t)b.blk;
-            for (size_t k = 0; k < L.cx_read.size(); ++k) {
-                P->cx_read.p[b.cx + k] = (uint32_t)(b.reads + L.cx_read[k]);
-                boff += L.cx_nblk[k];
-                P->cx_off.p[b.cx + k + 1] = boff;
-            }
-            put(P->blk_start, b.blk, L.blk_start); put(P->blk_end, b.blk, L.blk_end); put(P->blk_ins, b.blk, L.blk_ins);
-            uint64_t poff = b.qbytes;                             // base offsets count padded bases = quality bytes
-            for (size_t k = 0; k < L.pool_read.size(); ++k) {
-                P->pool_read.p[b.pool + k] = (uint32_t)(b.reads + L.pool_read[k]);
-                poff += L.pool_plen[k];
-                P->pool_off.p[b.pool + k + 1] = poff;
-            }
-            put(P->pool_bases, b.pbytes, L.pool_bases); put(P->pool_quals, b.qbytes, L.pool_quals);
-        });
+        if (int rc = place_shares(P, locals, S, seg_records, n_records, index_out != nullptr)) return rc;
         off = seg_end[(size_t)S - 1];
         carry = len - off;
         if (carry && off) memmove(buf, buf + off, carry);
@@ -743,39 +888,9 @@ int run(mfkio_pack *P, const char *path, int pool_mode, const mfkio_region *regi
     if (!header_done) return fail(P, MFKIO_ERR_FORMAT, std::string(path) + " is not a BAM file (no header)");
     if (carry) return fail(P, MFKIO_ERR_FORMAT, "truncated alignment record at the end of the file");
 
-    double t2 = now_s();
-    compute_links(P, T);
-    double t3 = now_s();
-    // first read of each contig
-    P->contig_read_start.assign((size_t)sh.n_contigs + 1, 0);
-    for (int c = 0; c <= sh.n_contigs; ++c)
-        P->contig_read_start[(size_t)c] = std::lower_bound(P->contig_id.p, P->contig_id.p + P->contig_id.n, (uint32_t)c,
-                                                            [](uint16_t a, uint32_t b) { return (uint32_t)a < b; }) - P->contig_id.p;
-    // release what only the link pass needed
-    P->hash.release();
-    P->name_off.release();
-    P->name_len.release();
-    P->names.release();
-
+    if (index_out) write_index(P, index_out, st, total_u, exclude_flags, blocks, block_at, hdr_u_end);   // best effort: a directory that cannot be written costs pairflanks a full pass, nothing else
+    double t3 = 0, t2 = finish_pack(P, sh.n_contigs, T, &t3);
     mfkio_arrays &a = P->a;
-    a.n_reads = (int64_t)P->ref_start.size();
-    a.n_contigs = sh.n_contigs;
-    a.max_span = P->max_span;
-    a.n_cx = (int64_t)P->cx_read.size();
-    a.n_blk = (int64_t)P->blk_start.size();
-    a.n_pool = (int64_t)P->pool_read.size();
-    a.pool_bases_bytes = (int64_t)P->pool_bases.size();
-    a.pool_quals_bytes = (int64_t)P->pool_quals.size();
-    a.ref_start = P->ref_start.data(); a.ref_end = P->ref_end.data(); a.link = P->link.data();
-    a.contig_id = P->contig_id.data(); a.qlen = P->qlen.data(); a.first_op_len = P->first_op.data();
-    a.last_op_len = P->last_op.data(); a.mapq = P->mapq.data(); a.flags = P->flags.data();
-    a.contig_len = P->contig_len.data(); a.contig_read_start = P->contig_read_start.data();
-    a.cx_read = P->cx_read.data(); a.cx_off = P->cx_off.data();
-    a.blk_start = P->blk_start.data(); a.blk_end = P->blk_end.data(); a.blk_ins = P->blk_ins.data();
-    a.pool_read = P->pool_read.data(); a.pool_off = P->pool_off.data();
-    a.pool_bases = P->pool_bases.data(); a.pool_quals = P->pool_quals.data();
-    a.contig_names = P->contig_names.data();
-    a.contig_names_bytes = (int64_t)P->contig_names.size();
     a.n_records = n_records;
     a.compressed_bytes = (int64_t)fsize;
     a.uncompressed_bytes = (int64_t)total_u;
@@ -786,6 +901,222 @@ int run(mfkio_pack *P, const char *path, int pool_mode, const mfkio_region *regi
     a.seconds_link = t3 - t2;
     a.seconds_total = now_s() - t_begin;
     a.n_redone_passes = n_redone;
+    return MFKIO_OK;
+}
+
+
+// ---- the region pass through a record index ------------------------------------------------------------------------------
+// pairflanks needs the reads over a few dozen to a few thousand short regions; the reference fetches them through the BAI
+// (pairflanks.py:393-409).  With the record index findflanks left behind, only the BGZF blocks between the marks around each
+// region are inflated and walked.  Every record the full region pass would pack is packed, in the same order, so the
+// arrays are equal (tests/test_bamio_native.py).  Returns MFKIO_ERR_INDEX when the index cannot serve (missing, stale,
+// another FLAG filter, inverted regions): the caller then runs the full pass.
+inline int64_t mark_key(int32_t ref, int32_t pos) { return ref < 0 ? INT64_MAX : ((int64_t)ref << 32) + (int64_t)(uint32_t)(pos < 0 ? 0 : pos); }
+
+int run_indexed(mfkio_pack *P, const char *path, const char *index_path, const mfkio_region *regions, int64_t n_regions, int T, uint32_t exclude_flags) {
+    double t_begin = now_s(), t_inflate = 0, t_parse = 0;
+    if (n_regions > 0 && !regions) return fail(P, MFKIO_ERR_ARG, "regions is NULL");
+    Index ix;
+    if (!load_index(index_path, &ix)) return fail(P, MFKIO_ERR_INDEX, std::string("no usable record index at ") + index_path);
+    int fd = open(path, O_RDONLY);
+    if (fd < 0) return fail(P, MFKIO_ERR_IO, std::string("cannot open ") + path);
+    struct stat st;
+    if (fstat(fd, &st) != 0) { close(fd); return fail(P, MFKIO_ERR_IO, std::string("cannot stat ") + path); }
+    const size_t fsize = (size_t)st.st_size;
+    if ((uint64_t)fsize != ix.bam_size || mtime_ns(st) != ix.bam_mtime || exclude_flags != ix.exclude_flags || ix.marks.empty() || ix.block_at.empty() || !fsize) {
+        close(fd);
+        return fail(P, MFKIO_ERR_INDEX, "the record index was made for another file or another FLAG filter");
+    }
+    void *m = mmap(nullptr, fsize, PROT_READ, MAP_PRIVATE, fd, 0);
+    close(fd);
+    if (m == MAP_FAILED) return fail(P, MFKIO_ERR_IO, std::string("cannot map ") + path);
+    const uint8_t *file = (const uint8_t *)m;
+    struct Unmap { const uint8_t *p; size_t n; ~Unmap() { munmap((void *)p, n); } } unmap{file, fsize};
+    const LibDeflate &ld = libdeflate();
+    const size_t NB = ix.block_at.size();
+    auto block_of = [&](uint64_t u) { return (size_t)(std::upper_bound(ix.block_u.begin(), ix.block_u.end(), u) - ix.block_u.begin()) - 1; };
+
+    // blocks [bA, bB] -> buf (grown as needed); returns 0 or the failure, *base = uncompressed offset of buf[0]
+    struct Inflated { std::vector<uint8_t> buf; uint64_t base = 0; };
+    auto inflate_run = [&](size_t bA, size_t bB, Inflated &out, void *dec, z_stream *zs) -> const char * {
+        out.base = ix.block_u[bA];
+        const uint64_t end_u = bB + 1 < NB ? ix.block_u[bB + 1] : ix.total_u;
+        out.buf.resize((size_t)(end_u - out.base));
+        for (size_t k = bA; k <= bB; ++k) {
+            Block b; size_t bsize = 0;
+            if (ix.block_at[k] >= fsize) return "record index points beyond the file";
+            if (const char *why = block_header(file, fsize, (size_t)ix.block_at[k], path, &b, &bsize)) return why;
+            const uint64_t want = (k + 1 < NB ? ix.block_u[k + 1] : ix.total_u) - ix.block_u[k];
+            if (b.ulen != want) return "record index does not match the BGZF blocks of the file";
+            uint8_t *dst = out.buf.data() + (ix.block_u[k] - out.base);
+            uint32_t crc;
+            if (dec) {
+                size_t got = 0;
+                if (ld.decompress(dec, file + b.payload, b.clen, dst, b.ulen, &got) != 0 || got != b.ulen) return "BGZF block does not inflate (corrupt file)";
+                crc = ld.crc(0, dst, b.ulen);
+            } else {
+                inflateReset(zs);
+                zs->next_in = (Bytef *)(file + b.payload); zs->avail_in = b.clen; zs->next_out = dst; zs->avail_out = b.ulen;
+                if (inflate(zs, Z_FINISH) != Z_STREAM_END || zs->avail_out != 0) return "BGZF block does not inflate (corrupt file)";
+                crc = (uint32_t)crc32(crc32(0L, Z_NULL, 0), dst, b.ulen);
+            }
+            if (crc != b.crc) return "BGZF checksum mismatch (corrupt file)";
+        }
+        return nullptr;
+    };
+    struct Codec {
+        const LibDeflate &ld; void *dec = nullptr; z_stream zs; bool ok = false;
+        explicit Codec(const LibDeflate &l) : ld(l) { memset(&zs, 0, sizeof zs); dec = ld.ok() ? ld.alloc() : nullptr; ok = dec || inflateInit2(&zs, -15) == Z_OK; }
+        ~Codec() { if (dec) ld.release(dec); else if (ok) inflateEnd(&zs); }
+    };
+
+    // header: the blocks up to the first record
+    {
+        Codec cd(ld);
+        if (!cd.ok) return fail(P, MFKIO_ERR_IO, "cannot set up the inflater");
+        Inflated hb;
+        const size_t bH = block_of(ix.hdr_u_end ? ix.hdr_u_end - 1 : 0);
+        if (const char *why = inflate_run(0, bH, hb, cd.dec, &cd.zs)) return fail(P, MFKIO_ERR_FORMAT, why);
+        int64_t h = parse_header(P, hb.buf.data(), hb.buf.size());
+        if (h <= 0 || (uint64_t)h != ix.hdr_u_end) return fail(P, MFKIO_ERR_INDEX, "the record index does not match the BAM header");
+    }
+    if (P->contig_len.size() > 65535) return fail(P, MFKIO_ERR_PACK, "more than 65535 contigs");
+    Shared sh;
+    sh.pool_mode = MFKIO_POOL_REGIONS;
+    sh.exclude_flags = exclude_flags;
+    sh.n_contigs = (int32_t)P->contig_len.size();
+    {
+        std::vector<std::vector<std::pair<int32_t, int32_t>>> nr((size_t)sh.n_contigs), wn((size_t)sh.n_contigs);
+        for (int64_t i = 0; i < n_regions; ++i) {
+            const mfkio_region &r = regions[i];
+            if (r.contig_id < 0 || r.contig_id >= sh.n_contigs) return fail(P, MFKIO_ERR_ARG, "region on an unknown contig");
+            nr[r.contig_id].push_back({r.lo, r.hi});
+            wn[r.contig_id].push_back({r.es, r.ee});
+        }
+        sh.near_.resize((size_t)sh.n_contigs);
+        sh.win_.resize((size_t)sh.n_contigs);
+        for (int c = 0; c < sh.n_contigs; ++c) {
+            sh.near_[c].build(nr[c]); sh.win_[c].build(wn[c]);
+            if (!sh.near_[c].odd.empty()) return fail(P, MFKIO_ERR_INDEX, "inverted region: full pass");
+        }
+    }
+    // stretches of the uncompressed stream that can hold a read over a region: from the last mark at or before
+    // (contig, lo - max_span) to the first mark at or behind (contig, hi); neighbours merged
+    std::vector<std::pair<uint64_t, uint64_t>> stretch;
+    std::vector<int64_t> keys(ix.marks.size());
+    for (size_t k = 0; k < ix.marks.size(); ++k) keys[k] = mark_key(ix.marks[k].ref, ix.marks[k].pos);
+    for (size_t k = 1; k < keys.size(); ++k) if (keys[k] < keys[k - 1]) return fail(P, MFKIO_ERR_INDEX, "the record index is not in coordinate order");
+    for (int c = 0; c < sh.n_contigs; ++c)
+        for (size_t j = 0; j < sh.near_[c].lo.size(); ++j) {
+            const int64_t lo = (int64_t)sh.near_[c].lo[j] - ix.max_span, hi = sh.near_[c].hi[j];
+            if (hi <= 0) continue;
+            const int64_t klo = ((int64_t)c << 32) + (lo < 0 ? 0 : lo), khi = ((int64_t)c << 32) + hi;
+            size_t e0 = (size_t)(std::upper_bound(keys.begin(), keys.end(), klo) - keys.begin());   // first mark beyond klo
+            e0 = e0 ? e0 - 1 : 0;
+            const size_t e1 = (size_t)(std::lower_bound(keys.begin(), keys.end(), khi) - keys.begin());
+            const uint64_t u0 = ix.marks[e0].u, u1 = e1 < keys.size() ? ix.marks[e1].u : ix.total_u;
+            if (u1 <= u0) continue;
+            if (!stretch.empty() && u0 <= stretch.back().second) stretch.back().second = std::max(stretch.back().second, u1);
+            else stretch.push_back({u0, u1});
+        }
+    std::sort(stretch.begin(), stretch.end());
+    {   // (contigs ascend and so do their stretches, but merged neighbours of different contigs may touch)
+        std::vector<std::pair<uint64_t, uint64_t>> mg;
+        for (auto &x : stretch) { if (!mg.empty() && x.first <= mg.back().second) mg.back().second = std::max(mg.back().second, x.second); else mg.push_back(x); }
+        stretch.swap(mg);
+    }
+    P->cx_off.grow(1); P->cx_off.p[0] = 0;
+    P->pool_off.grow(1); P->pool_off.p[0] = 0;
+    int64_t n_records = 0, inflated_bytes = 0;
+    // T groups of neighbouring stretches, balanced by bytes; a thread walks its group in file order into one Local (the
+    // coordinates ascend from stretch to stretch, so the sorted-input check of parse_record holds across them)
+    uint64_t all_bytes = 0;
+    for (auto &x : stretch) all_bytes += x.second - x.first;
+    int S = (int)std::min<size_t>((size_t)T, stretch.size());
+    if (S < 1) S = 1;
+    std::vector<size_t> g_begin((size_t)S + 1, stretch.size());
+    {
+        uint64_t acc = 0; int g = 0;
+        g_begin[0] = 0;
+        for (size_t k = 0; k < stretch.size(); ++k) {
+            while (g + 1 < S && acc >= all_bytes * (uint64_t)(g + 1) / (uint64_t)S && k > g_begin[(size_t)g]) g_begin[(size_t)++g] = k;
+            acc += stretch[k].second - stretch[k].first;
+        }
+        for (int q = g + 1; q <= S; ++q) g_begin[(size_t)q] = stretch.size();
+    }
+    std::vector<Local> locals((size_t)S);
+    std::vector<int64_t> seg_records((size_t)S, 0);
+    std::vector<std::string> why_bad((size_t)S);
+    std::vector<double> t_inf((size_t)S, 0.0), t_all((size_t)S, 0.0);
+    std::atomic<int64_t> inf_bytes{0};
+    parallel(S, [&](int s) {
+        const double t_in = now_s();
+        Local &L = locals[(size_t)s];
+        L.clear();
+        Codec cd(ld);
+        if (!cd.ok) { why_bad[(size_t)s] = "cannot set up the inflater"; return; }
+        Inflated inf;
+        int64_t nrec = 0;
+        for (size_t k = g_begin[(size_t)s]; k < g_begin[(size_t)s + 1] && L.err.empty(); ++k) {
+            const uint64_t u0 = stretch[k].first, u1 = stretch[k].second;
+            const size_t bA = block_of(u0);
+            size_t bB = block_of(u1 - 1);
+            for (;;) {
+                double t0 = now_s();
+                if (const char *why = inflate_run(bA, bB, inf, cd.dec, &cd.zs)) { why_bad[(size_t)s] = why; return; }
+                t_inf[(size_t)s] += now_s() - t0;
+                const uint8_t *buf = inf.buf.data();
+                const size_t len = inf.buf.size(), end = (size_t)(u1 - inf.base);
+                size_t o = (size_t)(u0 - inf.base);
+                // the last record of a stretch may run into the next block(s): look before anything is parsed
+                size_t q = o;
+                bool more = false;
+                while (q < end) {
+                    if (q + 4 > len) { more = true; break; }
+                    uint32_t bs = le32(buf + q);
+                    if (bs < 32 || bs > (1u << 30)) break;          // reported by the walk below
+                    if (q + 4 + (size_t)bs > len) { more = true; break; }
+                    q += 4 + (size_t)bs;
+                }
+                if (more && bB + 1 < NB) { bB = std::min(NB - 1, bB + 1 + (bB - bA)); continue; }
+                if (more) { L.err = "truncated alignment record at the end of the file"; L.format_err = true; break; }
+                while (o < end) {
+                    uint32_t bs = le32(buf + o);
+                    if (bs < 32 || bs > (1u << 30)) { L.err = "bad alignment record size (corrupt file or stale record index)"; L.format_err = true; break; }
+                    if (!parse_record(sh, buf + o + 4, bs, L)) break;
+                    o += 4 + (size_t)bs;
+                    ++nrec;
+                }
+                if (L.err.empty() && o != end) { L.err = "the record index does not land on a record boundary (stale index)"; L.format_err = true; }
+                inf_bytes += (int64_t)len;
+                break;
+            }
+        }
+        seg_records[(size_t)s] = nrec;
+        t_all[(size_t)s] = now_s() - t_in;
+    });
+    for (int s = 0; s < S; ++s) if (!why_bad[(size_t)s].empty()) return fail(P, MFKIO_ERR_FORMAT, why_bad[(size_t)s]);
+    {
+        double ti = 0, ta = 0;
+        for (int s = 0; s < S; ++s) { ti = std::max(ti, t_inf[(size_t)s]); ta = std::max(ta, t_all[(size_t)s]); }
+        t_inflate = ti;
+        double tp0 = now_s();
+        if (int rc = place_shares(P, locals, S, seg_records, n_records, false)) return rc;
+        t_parse = (ta - ti) + (now_s() - tp0);
+    }
+    inflated_bytes = inf_bytes.load();
+    double t3 = 0, t2 = finish_pack(P, sh.n_contigs, T, &t3);
+    mfkio_arrays &a = P->a;
+    a.n_records = n_records;
+    a.compressed_bytes = (int64_t)fsize;
+    a.uncompressed_bytes = inflated_bytes;     // what this pass inflated, not the file's total
+    a.n_threads = T;
+    a.inflate_backend = ld.ok() ? 1 : 0;
+    a.seconds_inflate = t_inflate;
+    a.seconds_parse = t_parse;
+    a.seconds_link = t3 - t2;
+    a.seconds_total = now_s() - t_begin;
+    a.n_redone_passes = 0;
     return MFKIO_OK;
 }
 
@@ -815,7 +1146,53 @@ int mfkio_pack_bam_filtered(const char *path, int pool_mode, const mfkio_region 
     T = std::min(T, 256);
     if (chunk_bytes <= 0) chunk_bytes = (int64_t)256 << 20;
     try {
-        return run(P, path, pool_mode, regions, n_regions, T, chunk_bytes, exclude_flags);
+        return run(P, path, pool_mode, regions, n_regions, T, chunk_bytes, exclude_flags, nullptr);
+    } catch (const std::bad_alloc &) {
+        return fail(P, MFKIO_ERR_IO, "out of memory while packing");
+    } catch (const std::exception &e) {
+        return fail(P, MFKIO_ERR_IO, std::string("unexpected failure: ") + e.what());
+    }
+}
+
+static int thread_count(int n_threads) {
+    int T = n_threads;
+    if (T <= 0) {
+        const char *e = getenv("MFK_THREADS");
+        T = e ? atoi(e) : 0;
+        if (T <= 0) T = (int)std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+    }
+    return std::min(T, 256);
+}
+
+int mfkio_pack_bam_index(const char *path, int pool_mode, int n_threads, int64_t chunk_bytes, uint32_t exclude_flags, const char *index_out,
+                         mfkio_pack **out) {
+    if (!out) return MFKIO_ERR_ARG;
+    mfkio_pack *P = new (std::nothrow) mfkio_pack();
+    *out = P;
+    if (!P) return MFKIO_ERR_IO;
+    memset(&P->a, 0, sizeof P->a);
+    if (!path) return fail(P, MFKIO_ERR_ARG, "path is NULL");
+    if (pool_mode == MFKIO_POOL_REGIONS) return fail(P, MFKIO_ERR_ARG, "the record index is written by a full pass");
+    if (chunk_bytes <= 0) chunk_bytes = (int64_t)256 << 20;
+    try {
+        return run(P, path, pool_mode, nullptr, 0, thread_count(n_threads), chunk_bytes, exclude_flags, index_out);
+    } catch (const std::bad_alloc &) {
+        return fail(P, MFKIO_ERR_IO, "out of memory while packing");
+    } catch (const std::exception &e) {
+        return fail(P, MFKIO_ERR_IO, std::string("unexpected failure: ") + e.what());
+    }
+}
+
+int mfkio_pack_bam_regions_indexed(const char *path, const char *index_path, const mfkio_region *regions, int64_t n_regions, int n_threads,
+                                   uint32_t exclude_flags, mfkio_pack **out) {
+    if (!out) return MFKIO_ERR_ARG;
+    mfkio_pack *P = new (std::nothrow) mfkio_pack();
+    *out = P;
+    if (!P) return MFKIO_ERR_IO;
+    memset(&P->a, 0, sizeof P->a);
+    if (!path || !index_path) return fail(P, MFKIO_ERR_ARG, "path is NULL");
+    try {
+        return run_indexed(P, path, index_path, regions, n_regions, thread_count(n_threads), exclude_flags);
     } catch (const std::bad_alloc &) {
         return fail(P, MFKIO_ERR_IO, "out of memory while packing");
     } catch (const std::exception &e) {

@@ -39,6 +39,14 @@ def log(msg):
     print("[mustache_amd] " + msg, file=sys.stderr)
 
 
+def index_path(table_file, enabled=True):
+    """Where the record index of a findflanks run lives: next to its TSV (which is pairflanks' input)."""
+    import os
+    if not enabled or not table_file or os.environ.get("MFK_NO_RECORD_INDEX", "0") not in ("", "0"):
+        return None
+    return str(table_file) + ".mfki"
+
+
 def device_reads(binding, packed: PackedReads, device):
     """Move a PackedReads to ``device`` and describe it to the library."""
     tensors = packed.to_torch(device)
@@ -90,11 +98,15 @@ def findflanks_packed(binding, reads_struct, contig_names, params, sample_id, ou
 def _findflanks(bamfile, min_softclip_length, min_softclip_count, min_alignment_quality, min_alignment_inner_length,
                 min_distance_to_mate, min_softclip_ratio, max_indel_ratio, large_insertion_cutoff,
                 min_count_consensus, sample_id, output_file=None, device="cuda:0", verbose=True, decoder="native",
-                exclude_flags=0):
+                exclude_flags=0, record_index=True):
     """Drop-in for reference findflanks.py:18-59 (same positional arguments).  ``decoder``: "native" (libmfkio.so) or
     "python" (bamio.BamReader + pack_reads, the readable statement of the same packing rules).  ``exclude_flags``: skip
     records with any of these FLAG bits (0x900 = what the reference's formatbam step removes, samtools.py:9-18), for BAM
-    files that did not go through formatbam; 0 = every mapped record, like the reference."""
+    files that did not go through formatbam; 0 = every mapped record, like the reference.  ``record_index``: the pass over
+    the BAM also leaves ``<output_file>.mfki`` (record offsets + coordinates per 32 KiB of the uncompressed stream and the
+    BGZF block table, include/mfk_bamio.h), through which ``_pairflanks`` reads only the blocks around its candidate
+    regions instead of inflating the file a second time -- what the reference's bam.fetch gets from the BAI
+    (pairflanks.py:393-409).  MFK_NO_RECORD_INDEX=1 or record_index=False turn it off."""
     binding = _lib.load(int(str(device).split(":")[1]) if ":" in str(device) else 0)
     params = _lib.make_params(min_softclip_length=min_softclip_length, min_softclip_count=min_softclip_count,
                               min_alignment_quality=min_alignment_quality,
@@ -105,7 +117,7 @@ def _findflanks(bamfile, min_softclip_length, min_softclip_count, min_alignment_
     if verbose:
         log("Parsing softclipped sites from provided BAM file...")
     if decoder == "native":
-        packed = pack_bam(bamfile, pool="clipped", exclude_flags=exclude_flags)
+        packed = pack_bam(bamfile, pool="clipped", exclude_flags=exclude_flags, index_out=index_path(output_file, record_index))
     elif decoder == "python":
         from .bamio import BamReader
         with BamReader(bamfile) as bam:

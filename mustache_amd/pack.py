@@ -377,6 +377,10 @@ def io_lib():
         so.mfkio_pack_bam.argtypes = [_C.c_char_p, _C.c_int, _vp, _C.c_int64, _C.c_int, _C.c_int64, _C.POINTER(_vp)]
         so.mfkio_pack_bam_filtered.restype = _C.c_int
         so.mfkio_pack_bam_filtered.argtypes = [_C.c_char_p, _C.c_int, _vp, _C.c_int64, _C.c_int, _C.c_int64, _C.c_uint32, _C.POINTER(_vp)]
+        so.mfkio_pack_bam_index.restype = _C.c_int
+        so.mfkio_pack_bam_index.argtypes = [_C.c_char_p, _C.c_int, _C.c_int, _C.c_int64, _C.c_uint32, _C.c_char_p, _C.POINTER(_vp)]
+        so.mfkio_pack_bam_regions_indexed.restype = _C.c_int
+        so.mfkio_pack_bam_regions_indexed.argtypes = [_C.c_char_p, _C.c_char_p, _vp, _C.c_int64, _C.c_int, _C.c_uint32, _C.POINTER(_vp)]
         so.mfkio_pack_arrays.restype = _C.POINTER(_IoArrays)
         so.mfkio_pack_arrays.argtypes = [_vp]
         so.mfkio_pack_error.restype = _C.c_char_p
@@ -400,13 +404,17 @@ class _IoOwner:
             self.handle = None
 
 
-def pack_bam(path, pool="clipped", regions=None, threads=0, chunk_bytes=0, exclude_flags=0):
+def pack_bam(path, pool="clipped", regions=None, threads=0, chunk_bytes=0, exclude_flags=0, index_out=None, index=None):
     """Native counterpart of ``pack_reads(BamReader(path))``: same arrays, bit for bit.
 
     pool:    'clipped' | 'all' | 'none' | 'regions'.
     regions: for pool='regions' (pairflanks), rows (contig_id, lo, hi, es, ee) as ``candidate_regions`` returns them:
              only reads over [lo, hi) are packed, those over [es, ee) carry their bases.
     exclude_flags: skip records with any of these FLAG bits (0x900: secondary / supplementary, as formatbam does).
+    index_out: (full passes) also write the record index of the file there (include/mfk_bamio.h); best effort.
+    index:   (pool='regions') a record index written by an earlier full pass over the same file: only the BGZF blocks
+             around the regions are inflated, as the reference's bam.fetch does through the BAI.  A missing or stale
+             index (other size / mtime / FLAG filter) falls back to the full pass; ``.io_stats['indexed']`` says which ran.
     The returned PackedReads views the library's memory (no copy); ``.io_stats`` says what the run did.
     """
     so = io_lib()
@@ -419,8 +427,25 @@ def pack_bam(path, pool="clipped", regions=None, threads=0, chunk_bytes=0, exclu
         for k, r in enumerate(regs):
             reg_arr[k] = _IoRegion(*[int(x) for x in r])
     handle = _vp()
-    rc = so.mfkio_pack_bam_filtered(_os.fsencode(path), mode, _C.cast(reg_arr, _vp) if reg_arr is not None else None, n_reg,
-                                    int(threads), int(chunk_bytes), int(exclude_flags), _C.byref(handle))
+    indexed = False
+    rc = -1
+    if mode == 3 and index is not None and _os.path.exists(index):
+        rc = so.mfkio_pack_bam_regions_indexed(_os.fsencode(path), _os.fsencode(index), _C.cast(reg_arr, _vp), n_reg, int(threads),
+                                               int(exclude_flags), _C.byref(handle))
+        if rc == 5:                       # MFKIO_ERR_INDEX: not an error of the call, the full pass below serves
+            if handle.value:
+                so.mfkio_pack_free(handle)
+            handle = _vp()
+            rc = -1
+        else:
+            indexed = True
+    if rc == -1:
+        if index_out is not None and mode != 3:
+            rc = so.mfkio_pack_bam_index(_os.fsencode(path), mode, int(threads), int(chunk_bytes), int(exclude_flags),
+                                         _os.fsencode(index_out), _C.byref(handle))
+        else:
+            rc = so.mfkio_pack_bam_filtered(_os.fsencode(path), mode, _C.cast(reg_arr, _vp) if reg_arr is not None else None, n_reg,
+                                            int(threads), int(chunk_bytes), int(exclude_flags), _C.byref(handle))
     owner = _IoOwner(so, handle.value)
     if rc != 0:
         msg = so.mfkio_pack_error(handle).decode("utf-8", "replace") if handle.value else "out of memory"
@@ -451,5 +476,6 @@ def pack_bam(path, pool="clipped", regions=None, threads=0, chunk_bytes=0, exclu
     p.io_stats = {k: getattr(a, k) for k in ("n_records", "compressed_bytes", "uncompressed_bytes", "n_threads",
                                              "inflate_backend", "seconds_inflate", "seconds_parse", "seconds_link",
                                              "seconds_total", "n_redone_passes")}
+    p.io_stats["indexed"] = indexed
     p._owner = owner
     return p

@@ -8,7 +8,7 @@ import numpy as np
 import pandas as pd
 
 from . import lib as _lib
-from .findflanks import device_reads, log
+from .findflanks import device_reads, index_path, log
 from .pack import pack_bam, pack_reads
 
 PAIR_COLUMNS = ["pair_id", "contig", "pos_5p", "pos_3p", "softclip_count_5p", "softclip_count_3p", "total_count_5p",
@@ -170,8 +170,11 @@ def _pack_regions_python(bam, contig_names, regions, exclude_flags=0):
 
 def _pairflanks(flanksfile, bamfile, genome, max_direct_repeat_length, min_alignment_quality,
                 min_alignment_inner_length, max_junction_spanning_prop=0.15, large_insertion_cutoff=30,
-                output_file=None, device="cuda:0", verbose=True, ir_backend="builtin", decoder="native", exclude_flags=0):
-    """Drop-in for reference pairflanks.py:18-51 (same positional arguments).  ``decoder`` as in ``_findflanks``."""
+                output_file=None, device="cuda:0", verbose=True, ir_backend="builtin", decoder="native", exclude_flags=0,
+                record_index=True):
+    """Drop-in for reference pairflanks.py:18-51 (same positional arguments).  ``decoder`` as in ``_findflanks``.
+    ``record_index``: use ``<flanksfile>.mfki`` when ``_findflanks`` left it and it still matches the BAM (size, mtime,
+    FLAG filter): only the BGZF blocks around the candidate regions are inflated; otherwise the whole file is read."""
     if ir_backend == "einverted":
         from . import einverted
         einverted.find_einverted()          # fail before any work when the executable is missing
@@ -195,7 +198,11 @@ def _pairflanks(flanksfile, bamfile, genome, max_direct_repeat_length, min_align
         regions = candidate_regions(tab, max_direct_repeat_length, glen)
         # only reads that can overlap a candidate region are packed; reads over a direct-repeat window carry bases
         if decoder == "native":
-            packed = pack_bam(bamfile, pool="regions", regions=regions, exclude_flags=exclude_flags)
+            packed = pack_bam(bamfile, pool="regions", regions=regions, exclude_flags=exclude_flags, index=index_path(flanksfile, record_index))
+            if verbose:
+                st = packed.io_stats
+                log("BAM decode (%s): %d reads over %d candidate regions, %.1f MB inflated in %.3f s" % (
+                    "record index" if st["indexed"] else "whole file", packed.n_reads, len(regions), st["uncompressed_bytes"] / 1e6, st["seconds_total"]))
         elif decoder == "python":
             packed = _pack_regions_python(bam, contig_names, regions, exclude_flags)
         else:

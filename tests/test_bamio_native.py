@@ -265,3 +265,88 @@ def test_wrong_share_guess_is_caught(tmp_path):
         got = pack.pack_bam(path, pool="clipped", threads=threads)
         same(got, want)
         assert got.io_stats["n_records"] == len(rs.reads) + 1 and got.io_stats["n_redone_passes"] == 1
+
+
+# ---- record index (mfkio_pack_bam_index / mfkio_pack_bam_regions_indexed) ------------------------------------------------
+def _regions_around(rs, truth, names, extra=()):
+    idx = {n: i for i, n in enumerate(names)}
+    regs = []
+    for t in truth:
+        cid, start, end = idx[t["contig"]], t["pos_3p"], t["pos_5p"]
+        center = round((end + start) / 2)
+        es, ee = max(center - 25, 0), center + 25
+        regs.append((cid, min(es, start - 1), max(ee, end + 2), es, ee))
+    return regs + list(extra)
+
+
+@pytest.mark.parametrize("threads,chunk", [(1, 0), (4, 1), (5, 70000)])
+def test_indexed_region_pass_equals_full_region_pass(tmp_path, threads, chunk):
+    """The region pass through the record index that a full pass left behind packs the same arrays as the full region pass:
+    regions at insertion sites, at both contig ends, on a contig without reads nearby, overlapping regions, none at all."""
+    genome, rs, truth = simulate_readset(seed=21, contig_lens=(30000, 12000, 900), n_insertions=5, coverage=60)
+    path, idx = os.path.join(tmp_path, "s.bam"), os.path.join(tmp_path, "s.mfki")
+    bamio.write_bam(path, rs)
+    names = [n for n, _ in rs.contigs]
+    full = pack.pack_bam(path, pool="clipped", threads=threads, chunk_bytes=chunk, index_out=idx)
+    same(full, pack.pack_bam(path, pool="clipped", threads=threads, chunk_bytes=chunk))        # writing the index changes nothing
+    assert os.path.exists(idx) and not os.path.exists(idx + ".tmp")
+    extra = [(0, -5, 60, 0, 40), (0, 29900, 30050, 29950, 30000), (1, 0, 12000, 100, 150), (2, 300, 420, 320, 370), (0, 15000, 15010, 15000, 15010)]
+    for regs in (_regions_around(rs, truth, names), _regions_around(rs, truth, names, extra), extra[:1], extra[2:3], []):
+        want = pack.pack_bam(path, pool="regions", regions=regs, threads=3)
+        got = pack.pack_bam(path, pool="regions", regions=regs, threads=threads, index=idx)
+        assert got.io_stats["indexed"] and not want.io_stats["indexed"]
+        same(got, want)
+        if regs and regs != extra[2:3]:
+            assert got.io_stats["uncompressed_bytes"] < full.io_stats["uncompressed_bytes"]     # it inflated less than the file
+
+
+def test_indexed_pass_inflates_a_small_part_of_a_deep_file(tmp_path):
+    genome, rs, truth = simulate_readset(seed=22, contig_lens=(60000,), n_insertions=3, coverage=150)
+    path, idx = os.path.join(tmp_path, "d.bam"), os.path.join(tmp_path, "d.mfki")
+    bamio.write_bam(path, rs)
+    full = pack.pack_bam(path, pool="clipped", index_out=idx)
+    regs = _regions_around(rs, truth, [n for n, _ in rs.contigs])
+    got = pack.pack_bam(path, pool="regions", regions=regs, index=idx)
+    same(got, pack.pack_bam(path, pool="regions", regions=regs))
+    assert got.io_stats["indexed"] and got.io_stats["uncompressed_bytes"] * 5 < full.io_stats["uncompressed_bytes"]
+
+
+def test_stale_or_foreign_index_falls_back_to_the_full_pass(tmp_path):
+    genome, rs, truth = simulate_readset(seed=23, contig_lens=(9000,), n_insertions=2, coverage=40)
+    path, idx = os.path.join(tmp_path, "a.bam"), os.path.join(tmp_path, "a.mfki")
+    bamio.write_bam(path, rs)
+    pack.pack_bam(path, pool="clipped", index_out=idx)
+    regs = _regions_around(rs, truth, [n for n, _ in rs.contigs])
+    want = pack.pack_bam(path, pool="regions", regions=regs)
+    # another FLAG filter than the index was made with
+    got = pack.pack_bam(path, pool="regions", regions=regs, index=idx, exclude_flags=0x900)
+    assert not got.io_stats["indexed"]
+    same(got, pack.pack_bam(path, pool="regions", regions=regs, exclude_flags=0x900))
+    # the BAM was rewritten after the index (other mtime, possibly other size)
+    genome2, rs2, truth2 = simulate_readset(seed=24, contig_lens=(9000,), n_insertions=2, coverage=41)
+    bamio.write_bam(path, rs2)
+    os.utime(path, ns=(1, 1))
+    got = pack.pack_bam(path, pool="regions", regions=regs, index=idx)
+    assert not got.io_stats["indexed"]
+    same(got, pack.pack_bam(path, pool="regions", regions=regs))
+    # garbage, a truncated index, no index at all
+    for blob in (b"not an index", open(idx, "rb").read()[:100], None):
+        bad = os.path.join(tmp_path, "bad.mfki")
+        if blob is None:
+            os.remove(bad)
+        else:
+            open(bad, "wb").write(blob)
+        got = pack.pack_bam(path, pool="regions", regions=regs, index=bad)
+        assert not got.io_stats["indexed"]
+    # inverted regions keep the Python meaning through the full pass
+    got = pack.pack_bam(path, pool="regions", regions=regs + [(0, 500, 400, 450, 420)], index=idx)
+    assert not got.io_stats["indexed"]
+    del want
+
+
+def test_index_path_that_cannot_be_written_is_not_an_error(tmp_path):
+    genome, rs, truth = simulate_readset(seed=25, contig_lens=(5000,), n_insertions=1, coverage=20)
+    path = os.path.join(tmp_path, "a.bam")
+    bamio.write_bam(path, rs)
+    got = pack.pack_bam(path, pool="clipped", index_out=os.path.join(tmp_path, "no_such_dir", "a.mfki"))
+    same(got, pack.pack_bam(path, pool="clipped"))

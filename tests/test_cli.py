@@ -73,6 +73,13 @@ def test_cli_end_to_end_from_bam(tmp_path, name):
     r = CliRunner().invoke(cli, args, catch_exceptions=False)
     assert r.exit_code == 0, r.output
     assert open(pf).read() == case["pairflanks_tsv"]
+    # findflanks left the record index next to its table and pairflanks read the BAM through it; without it: same bytes
+    assert os.path.exists(ff + ".mfki")
+    os.remove(ff + ".mfki")
+    pf2 = os.path.join(tmp_path, "s.pairflanks.noindex.tsv")
+    r = CliRunner().invoke(cli, ["pairflanks", ff, bam, fa, "-o", pf2] + args[6:], catch_exceptions=False)
+    assert r.exit_code == 0, r.output
+    assert open(pf2).read() == case["pairflanks_tsv"]
     # recall on the pairs just written (reference main.py:272-284, recall.py)
     rc = os.path.join(tmp_path, "s.recall.tsv")
     r = CliRunner().invoke(cli, ["recall", pf, bam, "-o", rc], catch_exceptions=False)
