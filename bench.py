@@ -251,6 +251,7 @@ def end_to_end(n_records, tmp, device):
     are the base set's tables repeated: checked."""
     import pandas as pd
     from mustache_amd import bamio, bigbam, lib
+    from mustache_amd import findflanks as ff_mod
     from mustache_amd.findflanks import _findflanks
     from mustache_amd.pairflanks import _pairflanks
     from mustache_amd.simulate import simulate_readset
@@ -294,6 +295,7 @@ def end_to_end(n_records, tmp, device):
                 "what": "BAM + FASTA files -> findflanks TSV -> pairflanks TSV (two commands like the reference's; findflanks inflates the whole file and leaves a record index, "
                         "pairflanks reads only the BGZF blocks around its candidate regions through it, as bam.fetch does through the BAI), host decode threads = %s" % os.environ.get("OMP_NUM_THREADS", "all"),
                 "record_index_bytes": os.path.getsize(tsv1 + ".mfki") if os.path.exists(tsv1 + ".mfki") else None,
+                "stages": dict(ff_mod.LAST_TIMING),
                 "tables_equal_base_repeated": bool(ok), "write_inputs_s": round(write_s, 1)}
     finally:
         for p in (bam, fa, one, one + ".fa", tsv1, tsv2, tsv1 + ".mfki"):

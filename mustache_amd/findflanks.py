@@ -39,6 +39,9 @@ def log(msg):
     print("[mustache_amd] " + msg, file=sys.stderr)
 
 
+LAST_TIMING = {}     # stage split of the last _findflanks / _pairflanks call in this process (seconds), for bench.py's end_to_end line
+
+
 def index_path(table_file, enabled=True):
     """Where the record index of a findflanks run lives: next to its TSV (which is pairflanks' input)."""
     import os
@@ -56,19 +59,15 @@ def device_reads(binding, packed: PackedReads, device):
 def flank_frame(result, contig_names):
     """Result of ``Binding.run_findflanks`` -> DataFrame with the reference's columns and row order."""
     fl, seqs = result["flanks"], result["seqs"]
-    data = {c: [] for c in FLANK_COLUMNS}
-    for row in fl:
-        data["contig"].append(contig_names[int(row["contig_id"])])
-        data["pos"].append(int(row["pos"]))
-        data["orient"].append("5p" if row["orient"] == 5 else "3p")
-        for c in FLANK_COLUMNS[3:15]:
-            data[c].append(int(row[c]))
-        o, n = int(row["seq_off"]), int(row["seq_len"])
-        data["consensus_seq"].append(seqs[o:o + n].decode("ascii"))
-    df = pd.DataFrame(data, columns=FLANK_COLUMNS)
-    if len(df) == 0:
-        df = pd.DataFrame(columns=FLANK_COLUMNS)
-    return df
+    if len(fl) == 0:
+        return pd.DataFrame(columns=FLANK_COLUMNS)
+    text = bytes(seqs).decode("ascii")
+    data = {"contig": np.asarray(contig_names, dtype=object)[fl["contig_id"]], "pos": fl["pos"].astype(np.int64),
+            "orient": np.where(fl["orient"] == 5, "5p", "3p").astype(object)}
+    for c in FLANK_COLUMNS[3:15]:
+        data[c] = fl[c].astype(np.int64)
+    data["consensus_seq"] = [text[o:o + n] for o, n in zip(fl["seq_off"].tolist(), fl["seq_len"].tolist())]
+    return pd.DataFrame(data, columns=FLANK_COLUMNS)
 
 
 def findflanks_packed(binding, reads_struct, contig_names, params, sample_id, output_file=None, verbose=True):
@@ -114,6 +113,8 @@ def _findflanks(bamfile, min_softclip_length, min_softclip_count, min_alignment_
                               min_distance_to_mate=min_distance_to_mate, min_softclip_ratio=min_softclip_ratio,
                               max_indel_ratio=max_indel_ratio, large_insertion_cutoff=large_insertion_cutoff,
                               min_count_consensus=min_count_consensus)
+    import time
+    t0 = time.perf_counter()
     if verbose:
         log("Parsing softclipped sites from provided BAM file...")
     if decoder == "native":
@@ -131,5 +132,17 @@ def _findflanks(bamfile, min_softclip_length, min_softclip_count, min_alignment_
             log("BAM decode: %.2f s on %d threads (inflate %.2f s, parse %.2f s, names %.2f s), %.1f M records/s" % (
                 st["seconds_total"], st["n_threads"], st["seconds_inflate"], st["seconds_parse"], st["seconds_link"],
                 st["n_records"] / max(st["seconds_total"], 1e-9) / 1e6))
+    t1 = time.perf_counter()
     rs = device_reads(binding, packed, device)
-    return findflanks_packed(binding, rs, packed.contig_names, params, sample_id, output_file, verbose)
+    if str(device).startswith("cuda"):
+        import torch
+        torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    out = findflanks_packed(binding, rs, packed.contig_names, params, sample_id, output_file, verbose)
+    t3 = time.perf_counter()
+    st = getattr(packed, "io_stats", None) or {}
+    LAST_TIMING["findflanks"] = {"decode_s": round(t1 - t0, 4), "inflate_s": round(st.get("seconds_inflate", 0.0), 4),
+                                 "parse_s": round(st.get("seconds_parse", 0.0), 4), "links_s": round(st.get("seconds_link", 0.0), 4),
+                                 "upload_s": round(t2 - t1, 4), "kernels_and_tsv_s": round(t3 - t2, 4), "device_ms": round(binding.device_ms(), 3),
+                                 "reads_packed": int(packed.n_reads), "inflated_bytes": int(st.get("uncompressed_bytes", 0))}
+    return out

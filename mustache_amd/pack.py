@@ -421,11 +421,10 @@ def pack_bam(path, pool="clipped", regions=None, threads=0, chunk_bytes=0, exclu
     mode = POOL_MODES[pool]
     reg_arr, n_reg = None, 0
     if mode == 3:
-        regs = list(regions or ())
-        n_reg = len(regs)
-        reg_arr = (_IoRegion * max(n_reg, 1))()
-        for k, r in enumerate(regs):
-            reg_arr[k] = _IoRegion(*[int(x) for x in r])
+        regs = np.ascontiguousarray(np.asarray(list(regions) if regions is not None and not isinstance(regions, np.ndarray) else
+                                               (regions if regions is not None else []), dtype=np.int32).reshape(-1, 5))
+        n_reg = int(regs.shape[0])
+        reg_arr = regs.ctypes.data_as(_vp) if n_reg else (_IoRegion * 1)()     # rows (contig_id, lo, hi, es, ee) = mfkio_region
     handle = _vp()
     indexed = False
     rc = -1

@@ -23,68 +23,74 @@ def flanks_to_table(flanks: pd.DataFrame, contig_names):
     exactly where the reference would fail too (bam.fetch on a contig that is not in the header)."""
     index = {n: i for i, n in enumerate(contig_names)}
     tab = np.zeros(len(flanks), dtype=_lib.FLANK_DTYPE)
-    seqs, off = [], 0
-    for k, row in enumerate(flanks.itertuples(index=False)):
-        contig = str(row.contig)
-        if contig not in index:
-            raise KeyError("contig %r of the flanks file is not in the BAM header" % contig)
-        t = tab[k]
-        t["contig_id"], t["pos"] = index[contig], int(row.pos)
-        t["orient"] = 5 if row.orient == "5p" else (3 if row.orient == "3p" else 0)
-        for c in ("softclip_count_5p", "softclip_count_3p", "runthrough_count", "small_insertion_count_5p",
-                  "small_insertion_count_3p", "large_insertion_count_5p", "large_insertion_count_3p", "deletion_count",
-                  "upstream_deletion_count", "downstream_deletion_count", "total_count", "consensus_softclip_count"):
-            t[c] = int(getattr(row, c))
-        s = str(row.consensus_seq).encode("ascii")
-        t["seq_len"], t["seq_off"] = len(s), off
-        seqs.append(s)
-        off += len(s)
+    if len(flanks) == 0:
+        return tab, b""
+    contigs = [str(c) for c in flanks["contig"].tolist()]
+    ids = [index.get(c, -1) for c in contigs]
+    if -1 in ids:
+        raise KeyError("contig %r of the flanks file is not in the BAM header" % contigs[ids.index(-1)])
+    tab["contig_id"] = ids
+    tab["pos"] = [int(p) for p in flanks["pos"].tolist()]
+    orient = flanks["orient"].to_numpy(dtype=object)
+    tab["orient"] = np.where(orient == "5p", 5, np.where(orient == "3p", 3, 0))
+    for c in ("softclip_count_5p", "softclip_count_3p", "runthrough_count", "small_insertion_count_5p",
+              "small_insertion_count_3p", "large_insertion_count_5p", "large_insertion_count_3p", "deletion_count",
+              "upstream_deletion_count", "downstream_deletion_count", "total_count", "consensus_softclip_count"):
+        tab[c] = [int(v) for v in flanks[c].tolist()]
+    seqs = [str(s).encode("ascii") for s in flanks["consensus_seq"].tolist()]
+    lens = np.fromiter((len(s) for s in seqs), dtype=np.int64, count=len(seqs))
+    tab["seq_len"] = lens
+    tab["seq_off"] = np.concatenate([[0], np.cumsum(lens)[:-1]])
     return tab, b"".join(seqs)
 
 
 def candidate_regions(tab, max_direct_repeat_length, genome_len):
     """Per contig, the reference intervals pairflanks can touch: the spanning fetch [pos3-1, pos5+2) and the direct
     repeat window (pairflanks.py:294-305) of every (5p, 3p) candidate.  Returns (contig_id, start, end) arrays."""
-    out = []
     five = tab[tab["orient"] == 5]
     three = tab[tab["orient"] == 3]
-    for f5 in five:
-        m = three[(three["contig_id"] == f5["contig_id"]) & (three["pos"] >= f5["pos"] - max_direct_repeat_length - 1)
-                  & (three["pos"] < f5["pos"])]
-        for f3 in m:
-            start, end = int(f3["pos"]), int(f5["pos"])
-            center = round((end + start) / 2)
-            es = max(int(center - TARGET_REGION_SIZE / 2), 0)
-            ee = min(int(center + TARGET_REGION_SIZE / 2), genome_len[int(f5["contig_id"])])
-            out.append((int(f5["contig_id"]), min(es, start - 1), max(ee, end + 2), es, ee))
-    return out
+    if len(five) == 0 or len(three) == 0:
+        return np.zeros((0, 5), dtype=np.int32)
+    # 3p flanks sorted by (contig, position): the partners of a 5p flank are one stretch of them
+    key3 = (three["contig_id"].astype(np.int64) << 33) + (three["pos"].astype(np.int64) + 2)
+    order = np.argsort(key3, kind="stable")
+    key3 = key3[order]
+    c5, p5 = five["contig_id"].astype(np.int64), five["pos"].astype(np.int64)
+    lo = np.searchsorted(key3, (c5 << 33) + np.maximum(p5 - max_direct_repeat_length - 1, -2) + 2, side="left")
+    hi = np.searchsorted(key3, (c5 << 33) + p5 + 2, side="left")
+    n = np.maximum(hi - lo, 0)
+    a = np.repeat(np.arange(len(five)), n)                              # 5p flank of every candidate
+    b = order[np.repeat(lo, n) + (np.arange(int(n.sum())) - np.repeat(np.cumsum(n) - n, n))]
+    start, end, cid = three["pos"].astype(np.int64)[b], p5[a], c5[a]
+    center = np.rint((end + start) / 2).astype(np.int64)               # Python's round(): half to even (quirk P10)
+    es = np.maximum(center - TARGET_REGION_SIZE // 2, 0)
+    ee = np.minimum(center + TARGET_REGION_SIZE // 2, np.asarray(genome_len, dtype=np.int64)[cid])
+    return np.stack([cid, np.minimum(es, start - 1), np.maximum(ee, end + 2), es, ee], 1).astype(np.int32)
 
 
 def pair_frame(result, flank_tab, flank_seqs, contig_names):
     pr, strs = result["pairs"], result["strs"]
+    if len(pr) == 0:
+        return pd.DataFrame({c: [] for c in PAIR_COLUMNS}, columns=PAIR_COLUMNS)
+    text, ftext = bytes(strs).decode("ascii"), bytes(flank_seqs).decode("ascii")
 
-    def s(off, n):
-        return None if n < 0 else strs[int(off):int(off) + int(n)].decode("ascii")
-    data = {c: [] for c in PAIR_COLUMNS}
-    for k, row in enumerate(pr):
-        f5, f3 = flank_tab[int(row["index_5p"])], flank_tab[int(row["index_3p"])]
-        data["pair_id"].append(k + 1)                                         # pairflanks.py:120
-        data["contig"].append(contig_names[int(row["contig_id"])])
-        for c in ("pos_5p", "pos_3p", "softclip_count_5p", "softclip_count_3p", "total_count_5p", "total_count_3p",
-                  "spanning_count"):
-            data[c].append(int(row[c]))
-        data["has_IR"].append(bool(row["has_ir"]))
-        data["IR_length"].append(int(row["ir_length"]))
-        data["IR_5p"].append(s(row["ir5_off"], row["ir5_len"]))
-        data["IR_3p"].append(s(row["ir3_off"], row["ir3_len"]))
-        data["seq_5p"].append(flank_seqs[int(f5["seq_off"]):int(f5["seq_off"]) + int(f5["seq_len"])].decode("ascii"))
-        data["seq_3p"].append(flank_seqs[int(f3["seq_off"]):int(f3["seq_off"]) + int(f3["seq_len"])].decode("ascii"))
-        data["direct_repeat_reference"].append(s(row["dr_ref_off"], row["dr_ref_len"]))
-        data["direct_repeat_reads_consensus"].append(s(row["dr_reads_off"], row["dr_len"]))
-    df = pd.DataFrame(data, columns=PAIR_COLUMNS)
-    if len(df):
-        df["has_IR"] = df["has_IR"].astype(bool)
-    return df
+    def col(off, n):            # None for a negative length
+        return [None if m < 0 else text[o:o + m] for o, m in zip(pr[off].tolist(), pr[n].tolist())]
+
+    def fcol(idx):
+        f = flank_tab[pr[idx]]
+        return [ftext[o:o + m] for o, m in zip(f["seq_off"].tolist(), f["seq_len"].tolist())]
+    data = {"pair_id": np.arange(1, len(pr) + 1, dtype=np.int64),          # pairflanks.py:120
+            "contig": np.asarray(contig_names, dtype=object)[pr["contig_id"]]}
+    for c in ("pos_5p", "pos_3p", "softclip_count_5p", "softclip_count_3p", "total_count_5p", "total_count_3p", "spanning_count"):
+        data[c] = pr[c].astype(np.int64)
+    data["has_IR"] = pr["has_ir"].astype(bool)
+    data["IR_length"] = pr["ir_length"].astype(np.int64)
+    data["IR_5p"], data["IR_3p"] = col("ir5_off", "ir5_len"), col("ir3_off", "ir3_len")
+    data["seq_5p"], data["seq_3p"] = fcol("index_5p"), fcol("index_3p")
+    data["direct_repeat_reference"] = col("dr_ref_off", "dr_ref_len")
+    data["direct_repeat_reads_consensus"] = col("dr_reads_off", "dr_len")
+    return pd.DataFrame(data, columns=PAIR_COLUMNS)
 
 
 def genome_arrays(genome, contig_names):
@@ -186,6 +192,8 @@ def _pairflanks(flanksfile, bamfile, genome, max_direct_repeat_length, min_align
                               min_alignment_inner_length=min_alignment_inner_length,
                               max_junction_spanning_prop=max_junction_spanning_prop,
                               large_insertion_cutoff=large_insertion_cutoff)
+    import time
+    t0 = time.perf_counter()
     flanks = pd.read_csv(flanksfile, sep="\t")                                 # pairflanks.py:23 (default NA parsing)
     gen = read_fasta(genome)
     with BamReader(bamfile) as bam:
@@ -207,6 +215,17 @@ def _pairflanks(flanksfile, bamfile, genome, max_direct_repeat_length, min_align
             packed = _pack_regions_python(bam, contig_names, regions, exclude_flags)
         else:
             raise ValueError("decoder must be 'native' or 'python', not %r" % (decoder,))
+    t1 = time.perf_counter()
     rs = device_reads(binding, packed, device)
     gdev = torch.from_numpy(g).to(device)
-    return pairflanks_packed(binding, rs, contig_names, params, flanks, gdev, goff, output_file, verbose, ir_backend)
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    out = pairflanks_packed(binding, rs, contig_names, params, flanks, gdev, goff, output_file, verbose, ir_backend)
+    t3 = time.perf_counter()
+    st = getattr(packed, "io_stats", None) or {}
+    from . import findflanks as _ff
+    _ff.LAST_TIMING["pairflanks"] = {"tables_fasta_decode_s": round(t1 - t0, 4), "bam_decode_s": round(st.get("seconds_total", 0.0), 4),
+                                     "indexed": bool(st.get("indexed", False)), "inflated_bytes": int(st.get("uncompressed_bytes", 0)),
+                                     "reads_packed": int(packed.n_reads), "upload_s": round(t2 - t1, 4),
+                                     "kernels_and_tsv_s": round(t3 - t2, 4), "device_ms": round(binding.device_ms(), 3)}
+    return out

@@ -75,3 +75,32 @@ def test_slice_is_self_contained(oracle):
     full = res_full["flanks"][res_full["flanks"]["contig_id"] == 1]
     assert np.array_equal(full["pos"], res_sub["flanks"]["pos"])
     assert np.array_equal(full["consensus_softclip_count"], res_sub["flanks"]["consensus_softclip_count"])
+
+
+def test_candidate_regions_equal_the_per_flank_loop():
+    """pairflanks.candidate_regions (searchsorted over the 3p flanks) against the loop it replaces: for each 5p flank the 3p
+    flanks of its contig in [pos5 - maxdr - 1, pos5) (pairflanks.py:155-157) and the 50-bp window around round() of the
+    middle (pairflanks.py:294-305, half to even)."""
+    import numpy as np
+    from mustache_amd import lib, pairflanks as pfh
+    rng = np.random.default_rng(4)
+    for maxdr in (0, 3, 20):
+        n = 400
+        tab = np.zeros(n, dtype=lib.FLANK_DTYPE)
+        tab["contig_id"] = rng.integers(0, 3, n)
+        tab["pos"] = rng.integers(-1, 300, n)
+        tab["orient"] = rng.choice([5, 3, 0], n)
+        glen = np.array([300, 40, 10_000])
+        want = set()
+        five, three = tab[tab["orient"] == 5], tab[tab["orient"] == 3]
+        for f5 in five:
+            m = three[(three["contig_id"] == f5["contig_id"]) & (three["pos"] >= f5["pos"] - maxdr - 1) & (three["pos"] < f5["pos"])]
+            for f3 in m:
+                start, end = int(f3["pos"]), int(f5["pos"])
+                center = round((end + start) / 2)
+                es = max(int(center - 50 / 2), 0)
+                ee = min(int(center + 50 / 2), int(glen[int(f5["contig_id"])]))
+                want.add((int(f5["contig_id"]), min(es, start - 1), max(ee, end + 2), es, ee))
+        got = pfh.candidate_regions(tab, maxdr, glen)
+        assert got.dtype == np.int32 and got.shape[1] == 5
+        assert set(map(tuple, got.tolist())) == want and (len(want) > 0 or maxdr == 0)
