@@ -333,6 +333,54 @@ __device__ __forceinline__ void d_unpack8(uint32_t pk, uint32_t *c0, uint32_t *c
 }
 __device__ __forceinline__ uint32_t d_bswap(uint32_t x) { return __builtin_amdgcn_perm(x, x, 0x00010203u); }
 
+// Characters [p0, p0 + 16) of a word and their qualities, straight from the pool: what one lane of k_word_fill writes, and what
+// k_job_small loads into LDS when the fill is fused into it.  The source of a chunk is 16 consecutive quality bytes and 16
+// consecutive 4-bit base codes of ONE read (the usual word: one read clipped here; 3p words are read backwards), fetched with one
+// clamped 16-byte load each.  A word merged from both mates of a pair (both clipped at this site, findflanks.py:932-1027) goes
+// character by character.  Padding behind the word: 0xFF / quality 0.
+__device__ __forceinline__ void d_word_chunk(const DevReads &R, const WordSrc &src, int len, int side, int p0, uint32_t *c, uint32_t *q) {
+    if (src.l2 == 0 && len > 0) {
+        const int l1 = (int)src.l1;   // = len
+        // window of the read, in read coordinates: 5p = right clip as is, 3p = left clip backwards (Q14)
+        const int64_t s = side == 0 ? (int64_t)src.q1len - l1 + p0 : (int64_t)l1 - 16 - p0;
+        const uint8_t *qbase = R.pool_quals + src.o1, *bbase = R.pool_bases + (src.o1 >> 1);   // pool offsets are even
+        const uint4 qw = d_window16(qbase, s, (int64_t)src.q1len);
+        const int64_t bs = s >> 1;    // floor: s is negative when a 3p word ends inside this chunk
+        const uint4 bw = d_window16(bbase, bs, (int64_t)((src.q1len + 1) >> 1));
+        uint32_t p0w = bw.x, p1w = bw.y;
+        if (s & 1) {   // the window starts at the low nibble of its first byte: move the nibble stream up by one
+            p0w = ((bw.x << 4) & 0xF0F0F0F0u) | ((__builtin_amdgcn_alignbyte(bw.y, bw.x, 1) >> 4) & 0x0F0F0F0Fu);
+            p1w = ((bw.y << 4) & 0xF0F0F0F0u) | ((__builtin_amdgcn_alignbyte(bw.z, bw.y, 1) >> 4) & 0x0F0F0F0Fu);
+        }
+        d_unpack8(p0w, &c[0], &c[1]);
+        d_unpack8(p1w, &c[2], &c[3]);
+        q[0] = qw.x; q[1] = qw.y; q[2] = qw.z; q[3] = qw.w;
+        if (side) {
+            const uint32_t c0 = d_bswap(c[3]), c1 = d_bswap(c[2]), c2 = d_bswap(c[1]), c3 = d_bswap(c[0]);
+            c[0] = c0; c[1] = c1; c[2] = c2; c[3] = c3;
+            const uint32_t q0 = d_bswap(q[3]), q1 = d_bswap(q[2]), q2 = d_bswap(q[1]), q3 = d_bswap(q[0]);
+            q[0] = q0; q[1] = q1; q[2] = q2; q[3] = q3;
+        }
+        const int n = len - p0;   // characters of the word in this chunk (>= 1); the rest is padding: 0xFF / quality 0
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int vb = n - 4 * i;
+            const uint32_t m = vb >= 4 ? 0xFFFFFFFFu : (vb <= 0 ? 0u : (1u << (8 * vb)) - 1u);
+            c[i] = (c[i] & m) | ~m; q[i] &= m;
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            c[i] = 0; q[i] = 0;
+            for (int k = 0; k < 4; k++) {
+                uint8_t cc, qv;
+                d_word_char(R, src, side, len, p0 + 4 * i + k, &cc, &qv);
+                c[i] |= (uint32_t)cc << (8 * k); q[i] |= (uint32_t)qv << (8 * k);
+            }
+        }
+    }
+}
+
 // A lane fills 16 characters (and their qualities) at a time; a wave takes WF_WORDS consecutive words.  The characters of
 // consecutive words are neighbours in memory (every word padded to 16), so the wave walks the 16-byte chunks of its words'
 // whole region, lane = chunk: every store instruction of the wave writes one contiguous kilobyte (chunks handed out word by
@@ -342,14 +390,18 @@ __device__ __forceinline__ uint32_t d_bswap(uint32_t x) { return __builtin_amdgc
 // fetched with aligned 16-byte loads.  A word merged from both mates of a pair (both clipped at this site,
 // findflanks.py:932-1027) goes character by character.
 #define WF_WORDS 16
-__global__ __launch_bounds__(256) void k_word_fill(DevReads R, Words W) {
+__global__ __launch_bounds__(256) void k_word_fill(DevReads R, Words W, const uint32_t *rbig) {   // rbig: only the words of jobs with rbig[job] != 0 (those k_job_small left over)
     __shared__ uint32_t s_off[4][WF_WORDS + 1], s_meta[4][WF_WORDS];   // s_meta: length | side << 16
     __shared__ WordSrc s_src[4][WF_WORDS];
     const int wave = (int)(threadIdx.x >> 6), lane = (int)(threadIdx.x & 63);
     const uint32_t w0 = (blockIdx.x * 4 + (uint32_t)wave) * WF_WORDS;
     const uint32_t nw = w0 < W.n ? (W.n - w0 < WF_WORDS ? W.n - w0 : WF_WORDS) : 0u;
     if ((uint32_t)lane <= nw && nw) s_off[wave][lane] = (uint32_t)W.off[w0 + lane];   // off[] has an entry behind the last word
-    if ((uint32_t)lane < nw) { s_src[wave][lane] = W.src[w0 + lane]; s_meta[wave][lane] = W.len[w0 + lane] | ((W.job[w0 + lane] & 1u) << 16); }
+    if ((uint32_t)lane < nw) {
+        const uint32_t jb = W.job[w0 + lane];
+        s_src[wave][lane] = W.src[w0 + lane];
+        s_meta[wave][lane] = W.len[w0 + lane] | ((jb & 1u) << 16) | ((rbig && rbig[jb] == 0) ? 1u << 17 : 0u);
+    }
     __syncthreads();
     if (!nw) return;
     const uint32_t b_end = s_off[wave][nw];
@@ -358,49 +410,11 @@ __global__ __launch_bounds__(256) void k_word_fill(DevReads R, Words W) {
 #pragma unroll
         for (uint32_t step = WF_WORDS / 2; step; step >>= 1) if (u + step < nw && s_off[wave][u + step] <= b) u += step;
         const WordSrc src = s_src[wave][u];
-        const int len = (int)(s_meta[wave][u] & 0xFFFFu), side = (int)(s_meta[wave][u] >> 16);
+        const int len = (int)(s_meta[wave][u] & 0xFFFFu), side = (int)((s_meta[wave][u] >> 16) & 1u);
+        if (s_meta[wave][u] >> 17) continue;   // its job is done: nobody reads these characters
         const int p0 = (int)(b - s_off[wave][u]);
         uint32_t c[4], q[4];
-        if (src.l2 == 0 && len > 0) {
-            const int l1 = (int)src.l1;   // = len
-            // window of the read, in read coordinates: 5p = right clip as is, 3p = left clip backwards (Q14)
-            const int64_t s = side == 0 ? (int64_t)src.q1len - l1 + p0 : (int64_t)l1 - 16 - p0;
-            const uint8_t *qbase = R.pool_quals + src.o1, *bbase = R.pool_bases + (src.o1 >> 1);   // pool offsets are even
-            const uint4 qw = d_window16(qbase, s, (int64_t)src.q1len);
-            const int64_t bs = s >> 1;    // floor: s is negative when a 3p word ends inside this chunk
-            const uint4 bw = d_window16(bbase, bs, (int64_t)((src.q1len + 1) >> 1));
-            uint32_t p0w = bw.x, p1w = bw.y;
-            if (s & 1) {   // the window starts at the low nibble of its first byte: move the nibble stream up by one
-                p0w = ((bw.x << 4) & 0xF0F0F0F0u) | ((__builtin_amdgcn_alignbyte(bw.y, bw.x, 1) >> 4) & 0x0F0F0F0Fu);
-                p1w = ((bw.y << 4) & 0xF0F0F0F0u) | ((__builtin_amdgcn_alignbyte(bw.z, bw.y, 1) >> 4) & 0x0F0F0F0Fu);
-            }
-            d_unpack8(p0w, &c[0], &c[1]);
-            d_unpack8(p1w, &c[2], &c[3]);
-            q[0] = qw.x; q[1] = qw.y; q[2] = qw.z; q[3] = qw.w;
-            if (side) {
-                const uint32_t c0 = d_bswap(c[3]), c1 = d_bswap(c[2]), c2 = d_bswap(c[1]), c3 = d_bswap(c[0]);
-                c[0] = c0; c[1] = c1; c[2] = c2; c[3] = c3;
-                const uint32_t q0 = d_bswap(q[3]), q1 = d_bswap(q[2]), q2 = d_bswap(q[1]), q3 = d_bswap(q[0]);
-                q[0] = q0; q[1] = q1; q[2] = q2; q[3] = q3;
-            }
-            const int n = len - p0;   // characters of the word in this chunk (>= 1); the rest is padding: 0xFF / quality 0
-#pragma unroll
-            for (int i = 0; i < 4; i++) {
-                const int vb = n - 4 * i;
-                const uint32_t m = vb >= 4 ? 0xFFFFFFFFu : (vb <= 0 ? 0u : (1u << (8 * vb)) - 1u);
-                c[i] = (c[i] & m) | ~m; q[i] &= m;
-            }
-        } else {
-#pragma unroll
-            for (int i = 0; i < 4; i++) {
-                c[i] = 0; q[i] = 0;
-                for (int k = 0; k < 4; k++) {
-                    uint8_t cc, qv;
-                    d_word_char(R, src, side, len, p0 + 4 * i + k, &cc, &qv);
-                    c[i] |= (uint32_t)cc << (8 * k); q[i] |= (uint32_t)qv << (8 * k);
-                }
-            }
-        }
+        d_word_chunk(R, src, len, side, p0, c, q);
         *reinterpret_cast<uint4 *>(W.ch + b) = make_uint4(c[0], c[1], c[2], c[3]);
         *reinterpret_cast<uint4 *>(W.q + b) = make_uint4(q[0], q[1], q[2], q[3]);
     }
@@ -1384,7 +1398,7 @@ extern "C" int mfk_debug_sj(unsigned long long *out) {
 #ifndef SJ_WAVES
 #define SJ_WAVES 4
 #endif
-__global__ __launch_bounds__(SJ_THREADS) __attribute__((amdgpu_waves_per_eu(SJ_WAVES, SJ_WAVES))) void k_job_small(DevParams P, Words W, Jobs J, ConsensusIO io, CMeta *meta, uint32_t lds_bytes, int pass) {
+__global__ __launch_bounds__(SJ_THREADS) __attribute__((amdgpu_waves_per_eu(SJ_WAVES, SJ_WAVES))) void k_job_small(DevReads RD, DevParams P, Words W, Jobs J, ConsensusIO io, CMeta *meta, uint32_t lds_bytes, int pass, int fused) {
     extern __shared__ __align__(16) unsigned char smem[];
     // static LDS is part of every workgroup's footprint (four workgroups per CU: 40 KB each): indices and lengths are bytes
     // (at most SJ_MAX_R = 256 words of at most SJ_MAX_LEN = 255 characters)
@@ -1422,17 +1436,46 @@ __global__ __launch_bounds__(SJ_THREADS) __attribute__((amdgpu_waves_per_eu(SJ_W
     const uint64_t goff0 = W.off[w0];
     const uint32_t C = (uint32_t)(W.off[w0 + R] - goff0);     // characters of the job, every word padded to 16
     int mylen = 0;
+    uint32_t myloff = 0;
+    WordSrc mysrc;
+    mysrc.o1 = mysrc.o2 = 0; mysrc.l1 = mysrc.l2 = mysrc.q1len = mysrc.q2len = 0;
     if ((uint32_t)tid < R) {
         mylen = (int)W.len[w0 + tid];
+        myloff = (uint32_t)((W.off[w0 + tid] - goff0) >> 4);
+        if (fused) mysrc = W.src[w0 + tid];   // (with the two loads above in one round trip)
         s_len[tid] = (uint8_t)mylen;   // a longer word makes the job fail just below
-        s_loff[tid] = (uint16_t)((W.off[w0 + tid] - goff0) >> 4);
+        s_loff[tid] = (uint16_t)myloff;
     }
     const uint32_t lkey = sj_block_max(((uint32_t)mylen << 16) | (0xFFFFu - (uint32_t)tid), s_red);   // longest word, the first of them
     const uint32_t maxlen = lkey >> 16;
     if (maxlen > SJ_MAX_LEN) SJ_FAIL(true);
     if (C + 4096u > lds_bytes) SJ_FAIL(false);
     uint8_t *ch = smem;   // characters of the job's words (the qualities are read once, by the vote, straight from memory)
-    {
+    // fused fill (the usual case: k_word_fill has not run): the characters come straight from the sequence pool, 16 per thread
+    // and step as k_word_fill makes them; W.ch / W.q are written only for jobs that end up with the device-wide kernels.
+    // The qualities go to W.q as k_word_fill writes them (the vote reads them once, from there or staged in LDS); the
+    // characters never leave the chip.
+    const int side_j = (int)(job & 1u);
+    if (fused) {
+        // the words' sources go through LDS (behind the characters: the tables that live there are laid out later), so that a
+        // thread can take any chunk: all chunks of the job are in flight together, two dependent round trips in all
+        WordSrc *ssrc = reinterpret_cast<WordSrc *>(smem + SJ_A16(C));
+        if (SJ_A16(C) + R * (uint32_t)sizeof(WordSrc) > lds_bytes) SJ_FAIL(false);
+        if ((uint32_t)tid < R) ssrc[tid] = mysrc;
+        __syncthreads();
+        const uint32_t nch = C >> 4;
+#pragma unroll 4
+        for (uint32_t i = tid; i < nch; i += SJ_THREADS) {
+            uint32_t u = 0;   // the word of chunk i: the last one that starts at or before it
+#pragma unroll
+            for (uint32_t step = SJ_MAX_R / 2; step; step >>= 1) if (u + step < R && (uint32_t)s_loff[u + step] <= i) u += step;
+            const WordSrc sw = ssrc[u];
+            uint32_t c4[4], q4[4];
+            d_word_chunk(RD, sw, (int)s_len[u], side_j, (int)((i - (uint32_t)s_loff[u]) << 4), c4, q4);
+            reinterpret_cast<uint4 *>(ch)[i] = make_uint4(c4[0], c4[1], c4[2], c4[3]);
+            *reinterpret_cast<uint4 *>(W.q + goff0 + ((uint64_t)i << 4)) = make_uint4(q4[0], q4[1], q4[2], q4[3]);
+        }
+    } else {
         const uint4 *src = reinterpret_cast<const uint4 *>(W.ch + goff0);
         for (uint32_t i = tid; i < (C >> 4); i += SJ_THREADS) reinterpret_cast<uint4 *>(ch)[i] = src[i];
     }
@@ -1977,8 +2020,16 @@ int run_consensus(mfk_ctx *ctx, const DevReads &R, const DevParams &P, Consensus
     W.ch = aalloc<uint8_t>(ctx, (size_t)total_chars + 64); W.q = aalloc<uint8_t>(ctx, (size_t)total_chars + 64);
     if (total_chars >= 0xFFFFFFF0ull) { snprintf(ctx->err, sizeof ctx->err, "more than 2^32 clipped bases at the surviving sites of one call"); return 1; }
     if (!W.ch || !W.q) return 1;
-    PROF_LAUNCH(k_word_fill, dim3(ww), dim3(256), 0, st, R, W);
-    KCHK();
+    // The characters of a job that k_job_small takes are made inside it, straight from the pool (no 2 bytes per clipped base
+    // written here and read back there); k_word_fill runs first only when every job goes to the device-wide kernels, and
+    // afterwards for the jobs k_job_small leaves over.
+    const char *ns_env0 = getenv("MFK_NO_SMALL_JOBS"), *nf_env = getenv("MFK_NO_FUSED_FILL");
+    const bool no_small0 = ns_env0 && *ns_env0 && *ns_env0 != '0';
+    const bool fused = !no_small0 && hm.n_small && !(nf_env && *nf_env && *nf_env != '0');
+    if (!fused) {
+        PROF_LAUNCH(k_word_fill, dim3(ww), dim3(256), 0, st, R, W, (const uint32_t *)nullptr);
+        KCHK();
+    }
     const uint32_t max_len = hm.max_len ? hm.max_len : 1;
     io.cons_stride = (max_len + 7) & ~7u;
     io.cons_chars = aalloc<char>(ctx, (size_t)J.n * io.cons_stride);
@@ -2015,7 +2066,7 @@ int run_consensus(mfk_ctx *ctx, const DevReads &R, const DevParams &P, Consensus
                     if (!hm.n_retry) break;
                     HIPCHK(hipMemsetAsync(&meta->n_retry, 0, 4, st));
                 }
-                PROF_LAUNCH(k_job_small, dim3(J.n), dim3(SJ_THREADS), rung[pass], st, P, W, J, io, meta, rung[pass], pass);
+                PROF_LAUNCH(k_job_small, dim3(J.n), dim3(SJ_THREADS), rung[pass], st, R, P, W, J, io, meta, rung[pass], pass, fused ? 1 : 0);
                 KCHK();
                 if (int rc = read_back(ctx, meta, &hm, sizeof hm)) return rc;
             }
@@ -2023,6 +2074,10 @@ int run_consensus(mfk_ctx *ctx, const DevReads &R, const DevParams &P, Consensus
     }
     if (!hm.n_big) return 0;
     // ---- the device-wide kernels, for the jobs left: they see R = 0 for every job that is done ------------------------
+    if (fused) {   // their words' characters and qualities
+        PROF_LAUNCH(k_word_fill, dim3(ww), dim3(256), 0, st, R, W, (const uint32_t *)J.Rbig);
+        KCHK();
+    }
     J.R = J.Rbig;
     {
         FillGroup z(ctx, 0);

@@ -1,7 +1,11 @@
 #!/bin/bash
-# C5 iteration loop on the GPU box: parity of both consensus paths + the full-size digests, then the per-kernel table.
-#   gpurun --timeout 900 -- 'bash scripts/gpu_c5.sh TAG'
-tag=${1:-x}
-timeout -k 10 400 python -u -m pytest tests/test_gpu_fullsize.py -x -q --timeout 300 --timeout-method thread -m gpu -k "small_job or digest" 2>&1 | tail -4 &&
-timeout -k 10 400 python bench.py --config C5_meta_50mb --steps 10 --no-cpu-baseline --dump-profile gpurun_out/r02_c5_${tag}_hip_events.txt > gpurun_out/r02_c5_${tag}.json 2> gpurun_out/r02_c5_${tag}.err &&
-head -14 gpurun_out/r02_c5_${tag}_hip_events.txt && tail -1 gpurun_out/r02_c5_${tag}_hip_events.txt
+# GPU box: full GPU suite, then the per-kernel tables of C5 and C2
+cd "$GRAFT_REPO_ROOT"
+O=gpurun_out/c5
+mkdir -p $O
+timeout -k 10 600 python3 -u -m pytest tests -m gpu -x -q --timeout 120 --timeout-method thread > $O/tests.log 2>&1 || { tail -30 $O/tests.log; exit 1; }
+tail -2 $O/tests.log
+timeout -k 10 400 python3 -u bench.py --quick --config C5_meta_50mb --steps 10 --warmup 3 --dump-profile $O/c5_events.txt > $O/c5_bench.json 2> $O/c5_bench.err || { tail -20 $O/c5_bench.err; exit 1; }
+head -24 $O/c5_events.txt; tail -1 $O/c5_events.txt
+timeout -k 10 300 python3 -u bench.py --quick --steps 20 --warmup 3 --dump-profile $O/c2_events.txt > $O/c2_bench.json 2> $O/c2_bench.err || { tail -20 $O/c2_bench.err; exit 1; }
+tail -1 $O/c2_events.txt

@@ -117,6 +117,11 @@ def test_small_job_kernel_and_device_wide_kernels_agree(hip, oracle, monkeypatch
     b = hip.run_findflanks(rd, params)
     monkeypatch.delenv("MFK_NO_SMALL_JOBS")
     assert a["seqs"] == b["seqs"] and a["flanks"].tobytes() == b["flanks"].tobytes() and list(a["stats"][:12]) == list(b["stats"][:12])
+    # k_job_small on characters that k_word_fill wrote to memory first (round 2's flow) instead of making them itself from the pool
+    monkeypatch.setenv("MFK_NO_FUSED_FILL", "1")
+    c = hip.run_findflanks(rd, params)
+    monkeypatch.delenv("MFK_NO_FUSED_FILL")
+    assert a["seqs"] == c["seqs"] and a["flanks"].tobytes() == c["flanks"].tobytes() and list(a["stats"][:13]) == list(c["stats"][:13])
     want = oracle.run_findflanks(oracle.reads(packed), params)
     assert a["seqs"] == want["seqs"] and a["flanks"].tobytes() == want["flanks"].tobytes() and len(a["flanks"]) > 0
     assert list(a["stats"][:12]) == list(want["stats"][:12])
