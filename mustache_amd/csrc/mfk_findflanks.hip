@@ -793,7 +793,12 @@ __global__ __launch_bounds__(256) void k_rows_fill(DevReads R, ActTab A, uint32_
 static const char BASE_ASCII[] = "=ACMGRSVTWYHKDBN";
 
 extern "C" int mfk_findflanks(mfk_ctx *ctx, const mfk_reads *reads, const mfk_params *params, int stop_after, int64_t *n_sites_out, int64_t *n_flanks_out, int64_t *seq_bytes_out) {
+    return findflanks_impl(ctx, reads, params, stop_after, n_sites_out, n_flanks_out, seq_bytes_out, nullptr);
+}
+
+int findflanks_impl(mfk_ctx *ctx, const mfk_reads *reads, const mfk_params *params, int stop_after, int64_t *n_sites_out, int64_t *n_flanks_out, int64_t *seq_bytes_out, FlankHandoff *fh) {
     if (!ctx || !reads || !params) return 1;
+    if (fh) fh->active = false;
     HIPCHK(hipSetDevice(ctx->device));
     ctx->err[0] = 0;
     ctx->sites.clear(); ctx->flanks.clear(); ctx->seqs.clear();
@@ -995,6 +1000,15 @@ extern "C" int mfk_findflanks(mfk_ctx *ctx, const mfk_reads *reads, const mfk_pa
         PROF_LAUNCH(k_rows_fill, dim3(nblocks(n_act, 4)), dim3(256), 0, st, R, A, n_act, (const int32_t *)io.cons_count, (const int32_t *)io.cons_len, (const char *)io.cons_chars, io.cons_stride,
                     (const uint64_t *)o_rows, (const uint64_t *)o_bytes, d_sites, d_flanks, d_seqs);
         KCHK();
+    }
+    if (dev_rows && fh) {
+        // mfk_flankpairs: the pairing stage takes the rows where they are and reads everything back with its own read-backs
+        fh->active = true; fh->n_act = n_act;
+        fh->d_sites = d_sites; fh->d_flanks = d_flanks; fh->d_seqs = d_seqs;
+        fh->d_rows_total = o_rows + n_act; fh->d_bytes_total = o_bytes + n_act;
+        fh->d_stats = d_stats; fh->d_cons_err = io.err_dev;
+        ht.lap("rows handed over on the device");
+        return 0;
     }
     HIPCHK(hipEventRecord(ctx->ev1, st));
     // ---- results to the host -------------------------------------------------------------------------------------

@@ -163,6 +163,22 @@ int dev_sort_pairs64(mfk_ctx *ctx, uint64_t *keys_in, uint64_t *keys_out, uint32
 int dev_excl_scan32(mfk_ctx *ctx, const uint32_t *in, uint32_t *out, size_t n);   // out has n+1 entries: out[n] = total
 int dev_excl_scan64(mfk_ctx *ctx, const uint32_t *in, uint64_t *out, size_t n);   // 64-bit sums, out[n] = total
 
+// mfk_flankpairs with thousands of sites: findflanks leaves its rows on the device (k_rows_fill) and the pairing stage reads
+// them there; what findflanks would have read back (row totals, counters, error words, the three tables) travels with the
+// pairing stage's own read-backs instead of draining the queue twice in between
+struct FlankHandoff {
+    bool active;                       // set by findflanks_impl when it handed over instead of reading back
+    uint32_t n_act;                    // at most n_act site rows and 2 n_act flank rows
+    const mfk_site *d_sites; const mfk_flank *d_flanks; const char *d_seqs;
+    const uint64_t *d_rows_total;      // site rows | flank rows << 24
+    const uint64_t *d_bytes_total;     // consensus characters
+    const uint32_t *d_stats;           // MFK_N_STATS counters of the findflanks kernels
+    const uint32_t *d_cons_err;        // error word of the consensus stage (may be null)
+};
+int findflanks_impl(mfk_ctx *ctx, const mfk_reads *reads, const mfk_params *params, int stop_after, int64_t *n_sites_out, int64_t *n_flanks_out, int64_t *seq_bytes_out, FlankHandoff *fh);
+int pairflanks_impl(mfk_ctx *ctx, const mfk_reads *reads, const mfk_params *params, const mfk_flank *flanks, const char *flank_seqs, int64_t n_flanks,
+                    const int32_t *h_contig_rank, const uint8_t *genome, const int64_t *h_genome_off, int64_t *n_pairs_out, int64_t *str_bytes_out, FlankHandoff *fh);
+
 // consensus stage (mfk_consensus.hip): fills, per active site k and side s, cons_count / cons_len / n_pass_len /
 // n_pass_both and the consensus characters (ASCII) at cons_chars + job * cons_stride
 struct ConsensusIO {

@@ -60,6 +60,23 @@ __global__ void k_pair_window(FlankDev F, int maxdr, int sorted, uint32_t *count
     if (!FILL) count[a] = c;
 }
 
+// mfk_flankpairs hand-over: the flank rows k_rows_fill left on the device -> the columns the kernels here read.  The table is
+// sized by an upper bound (two rows per active site); rows behind the last one sort behind every contig and are neither 5p nor
+// 3p, so no search lands on them and no candidate holds one.
+__global__ void k_flank_cols(const mfk_flank *rows, const uint64_t *rows_total, uint32_t cap, int32_t *tab, int64_t *soff) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= cap) return;
+    const uint32_t nf = (uint32_t)(*rows_total >> 24);
+    if (i < nf) {
+        const mfk_flank f = rows[i];
+        tab[i] = f.contig_id; tab[cap + i] = f.pos; tab[2 * (size_t)cap + i] = f.orient; tab[3 * (size_t)cap + i] = f.consensus_softclip_count;
+        tab[4 * (size_t)cap + i] = f.total_count; tab[5 * (size_t)cap + i] = f.seq_len; soff[i] = f.seq_off;
+    } else {
+        tab[i] = 0x7FFFFFFF; tab[cap + i] = 0x7FFFFFFF; tab[2 * (size_t)cap + i] = 0; tab[3 * (size_t)cap + i] = 0;
+        tab[4 * (size_t)cap + i] = 0; tab[5 * (size_t)cap + i] = 0; soff[i] = 0;
+    }
+}
+
 // ---- inverted repeats ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ int d_ir_code(char ch) {
     switch (ch) { case 'A': case 'a': return 0; case 'C': case 'c': return 1; case 'G': case 'g': return 2; case 'T': case 't': return 3; default: return 4; }
@@ -713,7 +730,15 @@ extern "C" int mfk_ir_detect(mfk_ctx *ctx, const char *seqs, const int64_t *off,
 
 extern "C" int mfk_pairflanks(mfk_ctx *ctx, const mfk_reads *reads, const mfk_params *params, const mfk_flank *flanks, const char *flank_seqs, int64_t n_flanks,
                               const int32_t *h_contig_rank, const uint8_t *genome, const int64_t *h_genome_off, int64_t *n_pairs_out, int64_t *str_bytes_out) {
+    return pairflanks_impl(ctx, reads, params, flanks, flank_seqs, n_flanks, h_contig_rank, genome, h_genome_off, n_pairs_out, str_bytes_out, nullptr);
+}
+
+// fh (mfk_flankpairs, thousands of sites): the flank table is on the device, behind findflanks kernels that are still running;
+// this call continues in the same arena and on the same stream, and reads findflanks' results back with its own.
+int pairflanks_impl(mfk_ctx *ctx, const mfk_reads *reads, const mfk_params *params, const mfk_flank *flanks, const char *flank_seqs, int64_t n_flanks,
+                    const int32_t *h_contig_rank, const uint8_t *genome, const int64_t *h_genome_off, int64_t *n_pairs_out, int64_t *str_bytes_out, FlankHandoff *fh) {
     if (!ctx || !reads || !params || n_flanks < 0) return 1;
+    const bool dev_in = fh && fh->active;
     std::vector<int32_t> ir_tab;
     ir_tab.swap(ctx->ir_ov);                              // the external table (if any) serves exactly this call
     HIPCHK(hipSetDevice(ctx->device));
@@ -722,19 +747,28 @@ extern "C" int mfk_pairflanks(mfk_ctx *ctx, const mfk_reads *reads, const mfk_pa
     memset(ctx->pstats, 0, sizeof ctx->pstats);
     if (n_pairs_out) *n_pairs_out = 0;
     if (str_bytes_out) *str_bytes_out = 0;
-    if (n_flanks == 0) return 0;
+    if (n_flanks == 0 && !dev_in) return 0;
     HostTimer ht("pairflanks");
     if (params->max_direct_repeat_length > 65000 || params->max_direct_repeat_length < 0) { snprintf(ctx->err, sizeof ctx->err, "max_direct_repeat_length out of range"); return 1; }
-    arena_reset(ctx);
+    if (!dev_in) arena_reset(ctx);
     DevReads R; DevParams P;
-    if (int rc = upload_reads(ctx, reads, params, &R, &P)) return rc;
+    if (int rc = upload_reads(ctx, reads, params, &R, &P)) return rc;   // (hand-over: same header bytes as findflanks uploaded, nothing is copied)
     const size_t pin_off = upload_reads_pinned_bytes(reads->n_contigs);   // the flank staging block goes behind upload_reads' bytes
     hipStream_t st = ctx->stream;
-    const uint32_t nF = (uint32_t)n_flanks;
+    const uint32_t nF = dev_in ? 2u * fh->n_act : (uint32_t)n_flanks;   // hand-over: an upper bound, the rows behind the last one are inert
     const int nc = reads->n_contigs;
+    // findflanks' results that still sit on the device (hand-over): sizes known after the first read-back below, tables added
+    // to the last one
+    bool ff_pending = false; size_t ff_ns = 0, ff_nf = 0, ff_nb = 0;
+    auto add_ff_tables = [&](ReadBatch &rb) {
+        if (!ff_pending) return;
+        rb.add(fh->d_sites, ctx->sites.data(), ff_ns * sizeof(mfk_site)); rb.add(fh->d_flanks, ctx->flanks.data(), ff_nf * sizeof(mfk_flank));
+        if (ff_nb) rb.add(fh->d_seqs, &ctx->seqs[0], ff_nb);
+        ff_pending = false;
+    };
     // ---- flank table to the device: one staging block in pinned memory, one copy --------------------------------------
     int sorted = 1; int64_t seq_total = 0;
-    for (uint32_t i = 0; i < nF; i++) {
+    for (uint32_t i = 0; i < nF && !dev_in; i++) {
         const mfk_flank &f = flanks[i];
         if (f.contig_id < 0 || f.contig_id >= nc) { snprintf(ctx->err, sizeof ctx->err, "flank %u: contig id %d out of range", i, f.contig_id); return 1; }
         if (f.seq_off < 0 || f.seq_len < 0) { snprintf(ctx->err, sizeof ctx->err, "flank %u: negative sequence offset or length", i); return 1; }
@@ -746,7 +780,7 @@ extern "C" int mfk_pairflanks(mfk_ctx *ctx, const mfk_reads *reads, const mfk_pa
     // the flank table.  That takes two kernels, a scan and a read-back of the candidate count off the head of the call.
     std::vector<uint32_t> host_c5, host_c3;
     const char *nh_env = getenv("MFK_NO_HOST_PAIRS");   // tests: force the device path for small tables too
-    const bool host_pairs = nF <= PW_HOST_MAX && !(nh_env && *nh_env && *nh_env != '0');
+    const bool host_pairs = !dev_in && nF <= PW_HOST_MAX && !(nh_env && *nh_env && *nh_env != '0');
     if (host_pairs)
         for (uint32_t a = 0; a < nF; a++) {
             if (flanks[a].orient != 5) continue;
@@ -754,14 +788,19 @@ extern "C" int mfk_pairflanks(mfk_ctx *ctx, const mfk_reads *reads, const mfk_pa
             for (uint32_t b = 0; b < nF; b++)
                 if (flanks[b].orient == 3 && flanks[b].contig_id == flanks[a].contig_id && (int64_t)flanks[b].pos >= min_pos && flanks[b].pos < flanks[a].pos) { host_c5.push_back(a); host_c3.push_back(b); }
         }
-    const size_t o_soff = 0, o_goff = o_soff + (size_t)nF * 8, o_tab = o_goff + ((size_t)nc + 1) * 8, o_rank = o_tab + 6 * (size_t)nF * 4;
+    // (hand-over: only the genome offsets and the contig ranks come from the host; the flank columns are made on the device)
+    const size_t nFu = dev_in ? 0 : (size_t)nF;
+    const size_t o_soff = 0, o_goff = o_soff + nFu * 8, o_tab = o_goff + ((size_t)nc + 1) * 8, o_rank = o_tab + 6 * nFu * 4;
     const size_t o_c5 = o_rank + (size_t)nc * 4, o_c3 = o_c5 + host_c5.size() * 4;
     const size_t o_seqs = o_c3 + host_c3.size() * 4, up_bytes = ((o_seqs + (size_t)seq_total + 1) + 255) & ~(size_t)255;
     char *hp = (char *)pinned_buf(ctx, pin_off + up_bytes);
     char *d_up = aalloc<char>(ctx, up_bytes);
     if (!hp || !d_up) return 1;
     hp += pin_off;
-    {
+    if (dev_in) {
+        memcpy(hp + o_goff, h_genome_off, ((size_t)nc + 1) * 8);
+        memcpy(hp + o_rank, h_contig_rank, (size_t)nc * 4);
+    } else {
         int64_t *hoff = (int64_t *)(hp + o_soff); int32_t *h = (int32_t *)(hp + o_tab);
         for (uint32_t i = 0; i < nF; i++) {
             const mfk_flank &f = flanks[i];
@@ -775,9 +814,15 @@ extern "C" int mfk_pairflanks(mfk_ctx *ctx, const mfk_reads *reads, const mfk_pa
     }
     ht.lap("staging");
     if (int rc = upload_pinned(ctx, d_up, hp, up_bytes)) return rc;   // pinned bytes stay untouched until the final read-back, which is ordered behind this copy
-    int32_t *d_tab = (int32_t *)(d_up + o_tab); int64_t *d_soff = (int64_t *)(d_up + o_soff); char *d_seqs = d_up + o_seqs;
+    int32_t *d_tab = (int32_t *)(d_up + o_tab); int64_t *d_soff = (int64_t *)(d_up + o_soff); const char *d_seqs = d_up + o_seqs;
     int32_t *d_rank = (int32_t *)(d_up + o_rank); int64_t *d_goff = (int64_t *)(d_up + o_goff);
-    HIPCHK(hipEventRecord(ctx->ev0, st));
+    if (dev_in) {
+        d_tab = aalloc<int32_t>(ctx, 6 * (size_t)nF); d_soff = aalloc<int64_t>(ctx, nF); d_seqs = fh->d_seqs;
+        if (!d_tab || !d_soff) return 1;
+        PROF_LAUNCH(k_flank_cols, dim3(nblocks(nF, 256)), dim3(256), 0, st, fh->d_flanks, fh->d_rows_total, nF, d_tab, d_soff);
+        KCHK();
+    } else
+        HIPCHK(hipEventRecord(ctx->ev0, st));   // (hand-over: the call's device time runs from findflanks' first kernel)
     FlankDev F; F.n = nF; F.contig = d_tab; F.pos = d_tab + nF; F.orient = d_tab + 2 * (size_t)nF; F.ccount = d_tab + 3 * (size_t)nF;
     F.total = d_tab + 4 * (size_t)nF; F.seq_len = d_tab + 5 * (size_t)nF; F.seq_off = d_soff; F.seqs = d_seqs;
     // ---- candidate pairs ----------------------------------------------------------------------------------------------
@@ -791,7 +836,26 @@ extern "C" int mfk_pairflanks(mfk_ctx *ctx, const mfk_reads *reads, const mfk_pa
         PROF_LAUNCH(k_pair_window<false>, dim3(fb), dim3(256), 0, st, F, P.maxdr, sorted, cnt, (const uint32_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr);
         KCHK();
         if (int rc = dev_excl_scan32(ctx, cnt, coff, nF)) return rc;
-        if (int rc = read_back(ctx, coff + nF, &nP, 4)) return rc;
+        if (!dev_in) { if (int rc = read_back(ctx, coff + nF, &nP, 4)) return rc; }
+        else {
+            // one read-back for the candidate count and for everything findflanks would have read back by now
+            uint32_t f_stats[MFK_N_STATS], f_scan_err = 0, f_cons_err = 0; uint64_t t_rows = 0, t_bytes = 0;
+            {
+                ReadBatch rb(ctx);
+                rb.add(coff + nF, &nP, 4); rb.add(fh->d_stats, f_stats, sizeof f_stats); rb.add(ctx->scan_err, &f_scan_err, 4);
+                if (fh->d_cons_err) rb.add(fh->d_cons_err, &f_cons_err, 4);
+                rb.add(fh->d_rows_total, &t_rows, 8); rb.add(fh->d_bytes_total, &t_bytes, 8);
+                if (int rc = rb.flush()) return rc;
+            }
+            if (int rc = check_scan_error(ctx, f_scan_err)) return rc;
+            if (f_cons_err & 2u) { snprintf(ctx->err, sizeof ctx->err, "a clipped read at a surviving site has no sequence in the pool (pack with pool='clipped')"); return 2; }
+            ff_ns = (size_t)(t_rows & 0xFFFFFFull); ff_nf = (size_t)(t_rows >> 24); ff_nb = (size_t)t_bytes;
+            ctx->sites.resize(ff_ns); ctx->flanks.resize(ff_nf); ctx->seqs.resize(ff_nb);
+            ff_pending = true;
+            for (int i = 0; i < 10; i++) ctx->stats[i] = f_stats[i];
+            ctx->stats[12] = (int64_t)((uint64_t)f_stats[12] | ((uint64_t)f_stats[13] << 32));
+            ctx->stats[11] = (int64_t)ff_nf;
+        }
     }
     ctx->pstats[0] = nP;
     ht.lap("candidates + read-back");
@@ -937,7 +1001,8 @@ extern "C" int mfk_pairflanks(mfk_ctx *ctx, const mfk_reads *reads, const mfk_pa
             if (!h_perr && !(!ir_tab.empty() && h_ps[15])) {
                 ctx->pairs.resize(nFin); ctx->strs.resize((size_t)h_total);
                 ReadBatch rb(ctx);
-                rb.add(d_pairs, ctx->pairs.data(), (size_t)nFin * sizeof(mfk_pair)); rb.add(d_strs, &ctx->strs[0], (size_t)h_total);
+                rb.add(d_pairs, ctx->pairs.data(), (size_t)nFin * sizeof(mfk_pair)); if (h_total) rb.add(d_strs, &ctx->strs[0], (size_t)h_total);
+                add_ff_tables(rb);
                 if (int rc = rb.flush()) return rc;
                 ht.lap("results read-back (rows made on the device)");
                 ctx->pstats[1] = nK; ctx->pstats[2] = h_ps[2]; ctx->pstats[3] = h_ps[3]; ctx->pstats[4] = nFin;
@@ -961,11 +1026,15 @@ extern "C" int mfk_pairflanks(mfk_ctx *ctx, const mfk_reads *reads, const mfk_pa
         rb.add(c5, h_c5.data(), nP * 4); rb.add(c3, h_c3.data(), nP * 4); rb.add(ir, h_ir.data(), 6 * (size_t)nP * 4);
         rb.add(d_pstats, h_ps, sizeof h_ps);
         rb.add(ctx->scan_err, &h_scan_err, 4);
+        add_ff_tables(rb);
         ht.lap("enqueue");
         if (int rc = rb.flush()) return rc;
         ht.lap("results read-back");
-    } else
+    } else {
         HIPCHK(hipEventRecord(ctx->ev1, st));
+        if (ff_pending) { ReadBatch rb(ctx); add_ff_tables(rb); if (int rc = rb.flush()) return rc; }
+    }
+    if (dev_in) { flanks = ctx->flanks.data(); flank_seqs = ctx->seqs.data(); }   // the host loop below reads the table findflanks made
     if (int rc = check_scan_error(ctx, h_scan_err)) return rc;
     ctx->pstats[1] = nK;
     const bool had_table = !ir_tab.empty();
@@ -1025,12 +1094,20 @@ extern "C" int mfk_flankpairs(mfk_ctx *ctx, const mfk_reads *reads, const mfk_pa
     if (!ctx) return 1;
     if (n_pairs) *n_pairs = 0;
     if (str_bytes) *str_bytes = 0;
-    if (int rc = mfk_findflanks(ctx, reads, params, MFK_STAGE_ALL, n_sites, n_flanks, seq_bytes)) return rc;
-    const double ms_find = ctx->last_ms;
+    const char *nh = getenv("MFK_NO_HANDOFF");   // test hook: always through the host table
+    const bool no_handoff = nh && *nh && *nh != '0';
+    FlankHandoff fh; memset(&fh, 0, sizeof fh);
+    if (int rc = findflanks_impl(ctx, reads, params, MFK_STAGE_ALL, n_sites, n_flanks, seq_bytes, no_handoff ? nullptr : &fh)) return rc;
+    const double ms_find = fh.active ? 0.0 : ctx->last_ms;
     ctx->pairs.clear(); ctx->strs.clear();
     memset(ctx->pstats, 0, sizeof ctx->pstats);
-    int rc = mfk_pairflanks(ctx, reads, params, ctx->flanks.data(), ctx->seqs.data(), (int64_t)ctx->flanks.size(), h_contig_rank, genome, h_genome_off, n_pairs, str_bytes);
+    int rc = pairflanks_impl(ctx, reads, params, ctx->flanks.data(), ctx->seqs.data(), (int64_t)ctx->flanks.size(), h_contig_rank, genome, h_genome_off, n_pairs, str_bytes, &fh);
     ctx->last_ms += ms_find;
+    if (fh.active) {   // findflanks' sizes are known only now
+        if (n_sites) *n_sites = (int64_t)ctx->sites.size();
+        if (n_flanks) *n_flanks = (int64_t)ctx->flanks.size();
+        if (seq_bytes) *seq_bytes = (int64_t)ctx->seqs.size();
+    }
     return rc;
 }
 

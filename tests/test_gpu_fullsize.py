@@ -188,3 +188,38 @@ def test_documented_limits_fail_with_messages(hip, oracle):
     # unharmed
     a, pf, off, opf = _both(hip, oracle, packed, genome)
     assert a["flanks"].tobytes() == off["flanks"].tobytes() and pf["strs"] == opf["strs"]
+
+
+@pytest.mark.parametrize("pf_kw,what", [(dict(), "thousands of candidate pairs: pair rows made on the device"),
+                                        (dict(max_direct_repeat_length=3), "a few hundred candidates: pair rows made by the host loop"),
+                                        (dict(max_direct_repeat_length=0), "no candidate pair at all"),
+                                        (dict(min_softclip_ratio=0.995), "nearly every site dies in the ratio filter: a handful of flank rows")])
+def test_fused_call_hands_the_flank_table_over_on_the_device(hip, monkeypatch, pf_kw, what):
+    """mfk_flankpairs with thousands of active sites: findflanks leaves its rows on the device, the pairing stage reads them there
+    and brings every table back with its own read-backs.  Same bytes and counters as the two separate calls (which go through
+    the host table), and as the fused call with the hand-over switched off."""
+    import torch
+    packed, genome, truth = synth_packed(contig_lens=(6_000_000,), coverage=40, n_insertions=2600, seed=31)
+    g, goff = pfh.genome_arrays(genome, packed.contig_names)
+    ranks = pfh.contig_ranks(packed.contig_names)
+    rd = device_reads(hip, packed, "cuda:0")
+    gd = torch.from_numpy(g).to("cuda:0")
+    params = lib.make_params(**pf_kw)
+    ff = hip.run_findflanks(rd, params)
+    pf = hip.run_pairflanks(rd, params, ff["flanks"], ff["seqs"], ranks, gd, goff)
+    assert int(ff["stats"][3]) > 2048, "the case is meant to have more than 2048 active sites"
+    ff2, pf2 = hip.run_flankpairs(rd, params, ranks, gd, goff)
+    monkeypatch.setenv("MFK_NO_HANDOFF", "1")
+    ff3, pf3 = hip.run_flankpairs(rd, params, ranks, gd, goff)
+    monkeypatch.delenv("MFK_NO_HANDOFF")
+    for a, b in ((ff2, pf2), (ff3, pf3)):
+        assert a["sites"].tobytes() == ff["sites"].tobytes() and a["flanks"].tobytes() == ff["flanks"].tobytes() and a["seqs"] == ff["seqs"]
+        assert list(a["stats"][:13]) == list(ff["stats"][:13])
+        assert b["pairs"].tobytes() == pf["pairs"].tobytes() and b["strs"] == pf["strs"] and list(b["stats"][:5]) == list(pf["stats"][:5])
+    if not pf_kw:
+        assert len(pf["pairs"]) > 2000
+    if pf_kw.get("max_direct_repeat_length") == 0:
+        assert len(pf["pairs"]) == 0 and len(ff["flanks"]) > 4000
+    # a second fused call right behind (the arena is reused): same again
+    ff4, pf4 = hip.run_flankpairs(rd, params, ranks, gd, goff)
+    assert ff4["flanks"].tobytes() == ff["flanks"].tobytes() and pf4["pairs"].tobytes() == pf["pairs"].tobytes() and pf4["strs"] == pf["strs"]
