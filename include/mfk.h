@@ -285,6 +285,25 @@ int mfk_allgather_fetch_all(mfk_ctx *ctx, void *rows, void *blob);
  * gather histories still agree on the size (they must: ncclAllGather with unequal counts is undefined). */
 int64_t mfk_allgather_next_bytes(mfk_ctx *ctx);
 
+/* Sharded path, host tables (no ctx, no device work; NO COUNTERPART IN THE REFERENCE): the selection and merge loops around
+ * mfk_allgather_sites (mustache_amd/dist.py states the same in numpy; tests compare the two).  A shard owns, per contig, the
+ * positions own_lo[c] <= pos < own_hi[c] (an empty interval where it owns nothing).
+ *   mfk_flanks_owned      rows of a flank table the shard owns, their sequences compacted in row order -> row count
+ *   mfk_flank_runs_owned  rows of the MERGED table the shard pairs: every run (same contig, gaps <= reach = maxdr + 1,
+ *                         pairflanks.py:155-157) that holds an owned position -> indices
+ *   mfk_pairs_owned       pairs whose 5p flank the shard owns, flank indices mapped back to the merged table (index_map),
+ *                         the four strings of a pair compacted in the library's order
+ *   mfk_flanks_merge / mfk_pairs_merge   tables of all ranks back to back (as mfk_allgather_fetch_all delivers them): string
+ *                         offsets re-based in place; returns 1 if the rows are then in table order ((contig, pos); (contig name
+ *                         rank, pos_5p, pos_3p), pairflanks.py:248), 0 if the caller still has to sort (whole-contig shards). */
+int64_t mfk_flanks_owned(const mfk_flank *rows, int64_t n, const char *seqs, const int32_t *own_lo, const int32_t *own_hi, int32_t n_contigs,
+                         mfk_flank *out, char *out_seqs, int64_t *out_seq_bytes);
+int64_t mfk_flank_runs_owned(const mfk_flank *rows, int64_t n, const int32_t *own_lo, const int32_t *own_hi, int32_t n_contigs, int32_t reach, int64_t *sel);
+int64_t mfk_pairs_owned(const mfk_pair *rows, int64_t n, const char *strs, const int32_t *own_lo, const int32_t *own_hi, int32_t n_contigs,
+                        const int64_t *index_map, mfk_pair *out, char *out_strs, int64_t *out_str_bytes);
+int mfk_flanks_merge(mfk_flank *rows, const int64_t *counts, int32_t world);
+int mfk_pairs_merge(mfk_pair *rows, const int64_t *counts, int32_t world, const int32_t *contig_rank, int32_t n_contigs);
+
 /* time spent in device work of the last compute call, milliseconds (HIP events on the ctx stream) */
 double mfk_last_device_ms(mfk_ctx *ctx);
 

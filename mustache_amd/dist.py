@@ -206,10 +206,76 @@ def plan_shards(packed, world_size, sharding="coordinate", h=None, small_contig_
 # ---------------------------------------------------------------------------------------------------------------------
 # stages
 # ---------------------------------------------------------------------------------------------------------------------
+# The selection / merge loops below exist twice: in numpy (this file: the readable statement, and what runs when libmfk.so is
+# not built) and in C inside libmfk.so (mfk_tables.hip: mfk_flanks_owned, mfk_flank_runs_owned, mfk_pairs_owned, mfk_flanks_merge,
+# mfk_pairs_merge), which is what the sharded stages call: at 20 000 flank rows and 10 000 pairs the numpy loops were 2.8 ms of
+# a 7.4 ms step.  MFK_NUMPY_MERGE=1 forces the numpy statement; tests/test_dist.py compares the two.
+_tables_so = None
+
+
+def _tables():
+    global _tables_so
+    import os
+    if os.environ.get("MFK_NUMPY_MERGE", "0") not in ("", "0"):
+        return None
+    if _tables_so is None:
+        import ctypes as C
+        try:
+            so = C.CDLL(_lib.LIB_PATH)
+            p, i64, i32 = C.c_void_p, C.c_int64, C.c_int32
+            so.mfk_flanks_owned.restype = i64
+            so.mfk_flanks_owned.argtypes = [p, i64, p, p, p, i32, p, p, C.POINTER(i64)]
+            so.mfk_flank_runs_owned.restype = i64
+            so.mfk_flank_runs_owned.argtypes = [p, i64, p, p, i32, i32, p]
+            so.mfk_pairs_owned.restype = i64
+            so.mfk_pairs_owned.argtypes = [p, i64, p, p, p, i32, p, p, p, C.POINTER(i64)]
+            so.mfk_flanks_merge.restype = C.c_int
+            so.mfk_flanks_merge.argtypes = [p, p, i32]
+            so.mfk_pairs_merge.restype = C.c_int
+            so.mfk_pairs_merge.argtypes = [p, p, i32, p, i32]
+            _tables_so = so
+        except (OSError, AttributeError):
+            _tables_so = False
+    return _tables_so or None
+
+
+def _own_bounds(plan, n_contigs):
+    """(own_lo, own_hi) int32 per contig for the C loops, or None when a contig appears in two pieces (not made by plan_shards)."""
+    key = ("_bounds", n_contigs)
+    got = getattr(plan, "_cbounds", None)
+    if got is not None and got[0] == key:
+        return got[1]
+    lo, hi = np.zeros(n_contigs, dtype=np.int32), np.zeros(n_contigs, dtype=np.int32)
+    seen, out = set(), None
+    for c, a, b in plan.pieces:
+        if c in seen:
+            break
+        seen.add(c)
+        if 0 <= c < n_contigs:
+            lo[c], hi[c] = max(a, -2**31), min(b, 2**31 - 1)
+    else:
+        out = (lo, hi)
+    plan._cbounds = (key, out)
+    return out
+
+
+def _n_contigs_of(plan, *id_arrays):
+    top = max([c for c, _, _ in plan.pieces] + [int(a.max()) for a in id_arrays if len(a)] + [0])
+    return top + 1
+
+
 def _fast_copy(rows):
     """Copy of a structured array through its bytes (numpy copies structured elements one by one: 3 ms per 20 000 rows)."""
     rows = np.ascontiguousarray(rows)
     return rows.view(np.uint8).copy().view(rows.dtype) if len(rows) else rows.copy()
+
+
+def _concat_rows(parts, dtype):
+    """Concatenation of structured arrays through their bytes (np.concatenate copies structured elements one by one)."""
+    views = [np.ascontiguousarray(np.asarray(r, dtype=dtype)).view(np.uint8) for r in parts if len(r)]
+    if not views:
+        return np.zeros(0, dtype=dtype)
+    return np.concatenate(views).view(dtype)
 
 
 def _fast_take(rows, order):
@@ -282,6 +348,20 @@ def shard_findflanks(binding, reads_struct, plan, params):
 
 def _own_flanks(res, plan):
     fl = res["flanks"]
+    so = _tables()
+    if so is not None and len(fl):
+        import ctypes as C
+        fl = np.ascontiguousarray(fl, dtype=_lib.FLANK_DTYPE)
+        bounds = _own_bounds(plan, _n_contigs_of(plan, fl["contig_id"]))
+        if bounds is not None:
+            seqs = res["seqs"]
+            sb = np.frombuffer(seqs, dtype=np.uint8) if len(seqs) else np.zeros(1, np.uint8)
+            out = np.empty(len(fl), dtype=_lib.FLANK_DTYPE)
+            ob = np.empty(max(len(seqs), 1), dtype=np.uint8)
+            nb = C.c_int64(0)
+            k = so.mfk_flanks_owned(fl.ctypes.data, len(fl), sb.ctypes.data, bounds[0].ctypes.data, bounds[1].ctypes.data, len(bounds[0]),
+                                    out.ctypes.data, ob.ctypes.data, C.byref(nb))
+            return out[:k], ob[:nb.value].tobytes()
     mine = _fast_take(fl, np.flatnonzero(plan.owns(fl["contig_id"], fl["pos"]))) if len(fl) else fl
     return _compact(mine, res["seqs"], _FLANK_STR)
 
@@ -289,6 +369,15 @@ def _own_flanks(res, plan):
 def merge_flanks(parts, compacted=False):
     """Per-rank (rows, seqs) -> the flank table of the unsharded run: contigs in BAM header order (first-seen order of a
     sorted BAM, findflanks.py:640-666), positions ascending, 5p before 3p (kept from the rank that owns the position)."""
+    so = _tables()
+    if so is not None and compacted and parts:
+        tab = _concat_rows([r for r, _ in parts], _lib.FLANK_DTYPE)                              # (a copy: the offsets are re-based in place)
+        counts = np.array([[len(r), len(b)] for r, b in parts], dtype=np.int64)
+        blob = b"".join(bytes(b) for _, b in parts)
+        if so.mfk_flanks_merge(tab.ctypes.data, counts.ctypes.data, len(parts)):
+            return tab, blob
+        order = _stable_order(tab["contig_id"], tab["pos"])                                      # whole-contig shards: sort, then compact
+        return _compact(tab if order is None else _fast_take(tab, order), blob, _FLANK_STR)
     rows, blobs, off = [], [], 0
     for r, b in parts:
         r = _fast_copy(np.asarray(r, dtype=_lib.FLANK_DTYPE))
@@ -307,9 +396,16 @@ def _flank_rows_for(plan, tab, reach):
     """Rows of the merged flank table a rank hands to ``mfk_pairflanks``: on each contig it owns a piece of, every run of
     flanks with gaps <= reach (= maxdr + 1: candidate pairs, and through shared flanks the greedy assignment, never cross a
     wider gap, pairflanks.py:155-157, 229-245) that holds an owned position."""
-    keep = np.zeros(len(tab), dtype=bool)
     if len(tab) == 0:
         return np.zeros(0, dtype=np.int64)
+    so = _tables()
+    if so is not None:
+        tab_c = np.ascontiguousarray(tab, dtype=_lib.FLANK_DTYPE)
+        bounds = _own_bounds(plan, _n_contigs_of(plan, tab_c["contig_id"]))
+        if bounds is not None:
+            sel = np.empty(len(tab_c), dtype=np.int64)
+            k = so.mfk_flank_runs_owned(tab_c.ctypes.data, len(tab_c), bounds[0].ctypes.data, bounds[1].ctypes.data, len(bounds[0]), int(reach), sel.ctypes.data)
+            return sel[:k]
     cid, pos = tab["contig_id"], tab["pos"].astype(np.int64)
     new_run = np.ones(len(tab), dtype=bool)
     new_run[1:] = (cid[1:] != cid[:-1]) | (pos[1:] - pos[:-1] > reach)
@@ -333,10 +429,25 @@ def shard_pairflanks(binding, reads_struct, plan, params, tab, seqs, contig_rank
     res = binding.run_pairflanks(reads_struct, params, rows_in, seqs, contig_rank, genome, genome_off)
     t2 = time.perf_counter()
     pr = res["pairs"]
-    mine = _fast_take(pr, np.flatnonzero(plan.owns(pr["contig_id"], pr["pos_5p"]))) if len(pr) else pr
-    mine["index_5p"] = sel[mine["index_5p"]]
-    mine["index_3p"] = sel[mine["index_3p"]]
-    out = _compact(mine, res["strs"], _PAIR_STR)
+    so = _tables()
+    bounds = _own_bounds(plan, _n_contigs_of(plan, pr["contig_id"])) if so is not None and len(pr) else None
+    if bounds is not None:
+        import ctypes as C
+        pr = np.ascontiguousarray(pr, dtype=_lib.PAIR_DTYPE)
+        strs = res["strs"]
+        sb = np.frombuffer(strs, dtype=np.uint8) if len(strs) else np.zeros(1, np.uint8)
+        sel64 = np.ascontiguousarray(sel, dtype=np.int64)
+        rows_out = np.empty(len(pr), dtype=_lib.PAIR_DTYPE)
+        ob = np.empty(max(len(strs), 1), dtype=np.uint8)
+        nb = C.c_int64(0)
+        k = so.mfk_pairs_owned(pr.ctypes.data, len(pr), sb.ctypes.data, bounds[0].ctypes.data, bounds[1].ctypes.data, len(bounds[0]),
+                               sel64.ctypes.data, rows_out.ctypes.data, ob.ctypes.data, C.byref(nb))
+        out = rows_out[:k], ob[:nb.value].tobytes()
+    else:
+        mine = _fast_take(pr, np.flatnonzero(plan.owns(pr["contig_id"], pr["pos_5p"]))) if len(pr) else pr
+        mine["index_5p"] = sel[mine["index_5p"]]
+        mine["index_3p"] = sel[mine["index_3p"]]
+        out = _compact(mine, res["strs"], _PAIR_STR)
     if _timing:
         STATS["merge_s"] += (t1 - t0) + (time.perf_counter() - t2)
     return out
@@ -345,6 +456,17 @@ def shard_pairflanks(binding, reads_struct, plan, params, tab, seqs, contig_rank
 def merge_pairs(parts, contig_rank, compacted=False):
     """Per-rank (rows, strs) -> the pair table of the unsharded run: sorted by (contig name, pos_5p, pos_3p)
     (pairflanks.py:248)."""
+    so = _tables()
+    if so is not None and compacted and parts:
+        tab = _concat_rows([r for r, _ in parts], _lib.PAIR_DTYPE)
+        counts = np.array([[len(r), len(b)] for r, b in parts], dtype=np.int64)
+        blob = b"".join(bytes(b) for _, b in parts)
+        cr = np.ascontiguousarray(contig_rank, dtype=np.int32)
+        if so.mfk_pairs_merge(tab.ctypes.data, counts.ctypes.data, len(parts), cr.ctypes.data, len(cr)):
+            return tab, blob
+        rank = cr[tab["contig_id"]] if len(tab) else np.zeros(0, np.int64)
+        order = _stable_order(rank, tab["pos_5p"], tab["pos_3p"])
+        return _compact(tab if order is None else _fast_take(tab, order), blob, _PAIR_STR)
     rows, blobs, off = [], [], 0
     for r, b in parts:
         r = _fast_copy(np.asarray(r, dtype=_lib.PAIR_DTYPE))

@@ -134,3 +134,83 @@ def test_take_ranges_equals_slices(oracle):
         old = int(idx[k_new[j]])
         jo = int(np.searchsorted(packed.cx_read, old))
         assert np.array_equal(sub.blk_start[sub.cx_off[j]:sub.cx_off[j + 1]], packed.blk_start[packed.cx_off[jo]:packed.cx_off[jo + 1]])
+
+
+def test_c_table_loops_equal_the_numpy_statement(monkeypatch):
+    """mfk_flanks_owned / mfk_flank_runs_owned / mfk_pairs_owned / mfk_flanks_merge / mfk_pairs_merge (libmfk.so, host code, no
+    GPU needed) against the numpy loops of mustache_amd/dist.py on random tables: several contigs, pieces that cut a contig,
+    contigs a shard owns nothing of, None strings (negative lengths), empty tables, parts in and out of table order."""
+    import numpy as np
+    from mustache_amd import dist as md, lib
+    assert md._tables() is not None, "libmfk.so must be built"
+    rng = np.random.default_rng(8)
+
+    def random_flanks(n, nc):
+        t = np.zeros(n, dtype=lib.FLANK_DTYPE)
+        t["contig_id"] = np.sort(rng.integers(0, nc, n))
+        t["pos"] = rng.integers(-1, 5000, n)
+        order = np.lexsort((t["pos"], t["contig_id"]))
+        t = t[order]
+        t["orient"] = rng.choice([5, 3], n)
+        t["seq_len"] = rng.integers(0, 60, n)
+        perm = rng.permutation(n)                                     # strings scattered in the blob
+        off = np.zeros(n, dtype=np.int64)
+        off[perm] = np.concatenate([[0], np.cumsum(t["seq_len"][perm])[:-1]])
+        t["seq_off"] = off
+        return t, bytes(rng.integers(65, 70, int(t["seq_len"].sum()) + 3, dtype=np.uint8))
+
+    def random_pairs(n, nc, nsel):
+        p = np.zeros(n, dtype=lib.PAIR_DTYPE)
+        p["contig_id"] = np.sort(rng.integers(0, nc, n))
+        p["pos_5p"] = rng.integers(0, 5000, n)
+        p["pos_3p"] = p["pos_5p"] - rng.integers(1, 20, n)
+        p["index_5p"], p["index_3p"] = rng.integers(0, nsel, n), rng.integers(0, nsel, n)
+        o = 0
+        for fo, fl in md._PAIR_STR:
+            p[fl] = rng.integers(-1, 30, n)
+        lens = np.stack([np.maximum(p[fl], 0) for _, fl in md._PAIR_STR], 1).reshape(-1)
+        offs = np.concatenate([[0], np.cumsum(lens)[:-1]]).reshape(n, 4)
+        for j, (fo, _) in enumerate(md._PAIR_STR):
+            p[fo] = offs[:, j]
+        return p, bytes(rng.integers(65, 70, int(lens.sum()) + 1, dtype=np.uint8))
+
+    def both(fn):
+        a = fn()
+        monkeypatch.setenv("MFK_NUMPY_MERGE", "1")
+        b = fn()
+        monkeypatch.delenv("MFK_NUMPY_MERGE")
+        return a, b
+
+    for n, nc in [(0, 3), (1, 1), (300, 4), (2000, 7)]:
+        plan = md.ShardPlan([(1, 700, 5001), (2, -1, 5001), (3, -1, 1200)] if nc > 3 else [(0, -1, 2500)], [(0, 1)])
+        tab, seqs = random_flanks(n, nc)
+        (r1, s1), (r2, s2) = both(lambda: md._own_flanks({"flanks": tab, "seqs": seqs}, plan))
+        assert r1.tobytes() == r2.tobytes() and s1 == s2 and (n < 100 or 0 < len(r1) < n)
+        for reach in (0, 21):
+            a, b = both(lambda: md._flank_rows_for(plan, tab, reach))
+            assert np.array_equal(a, b)
+        sel = md._flank_rows_for(plan, tab, 21)
+        if len(sel) == 0:
+            continue
+        pr, strs = random_pairs(max(n // 2, 1), nc, len(sel))
+
+        class FakeBinding:
+            def run_pairflanks(self, *a, **k):
+                return {"pairs": pr.copy(), "strs": strs, "stats": np.zeros(16, np.int64)}
+        params = lib.make_params()
+        (p1, t1), (p2, t2) = both(lambda: md.shard_pairflanks(FakeBinding(), None, plan, params, tab, seqs, np.arange(nc), None, None))
+        assert p1.tobytes() == p2.tobytes() and t1 == t2
+        # merges: three parts in table order, then the same parts in another order (whole-contig shards)
+        cuts = [0, len(r1) // 3, 2 * len(r1) // 3, len(r1)]
+        parts = [md._compact(r1[cuts[i]:cuts[i + 1]], s1, md._FLANK_STR) for i in range(3)]
+        for ps in (parts, parts[::-1]):
+            (m1, b1), (m2, b2) = both(lambda: md.merge_flanks(ps, compacted=True))
+            assert m1.tobytes() == m2.tobytes() and b1 == b2
+        ranks = rng.permutation(nc).astype(np.int32)
+        order = np.lexsort((p1["pos_3p"], p1["pos_5p"], ranks[p1["contig_id"]]))
+        sp, st = md._compact(md._fast_take(p1, order), t1, md._PAIR_STR)
+        cuts = [0, len(sp) // 2, len(sp)]
+        pparts = [md._compact(sp[cuts[i]:cuts[i + 1]], st, md._PAIR_STR) for i in range(2)]
+        for ps in (pparts, pparts[::-1]):
+            (m1, b1), (m2, b2) = both(lambda: md.merge_pairs(ps, ranks, compacted=True))
+            assert m1.tobytes() == m2.tobytes() and b1 == b2
