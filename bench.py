@@ -37,8 +37,31 @@ HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s 
 VALU_PEAK_TOPS = 256 * 4 * 32 * 2.4e9 / 1e12
 # VALU instructions one wave issues per unit of work, from the rocprofv3 SQ_INSTS_VALU pass of the same command
 # (profiles/r02_pmc_valu.json, scripts/pmc_table.py) divided by the work counter the kernel keeps (stats[12])
-VALU_MODELS_FILE = os.path.join(ROOT, "profiles", "r02_valu_models.json")
-PMC_TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+VALU_MODELS_FILE = os.path.join(ROOT, "profiles", "r03_valu_models.json")
+PMC_TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
+# Both tables come from files (a PMC pass cannot run inside a timed run): they are used only when the library they were measured
+# on is the library that runs now (sha256 recorded by scripts/pmc_table.py); otherwise the line says so and carries no number.
+
+
+def lib_sha16():
+    from mustache_amd import lib
+    try:
+        with open(lib.LIB_PATH, "rb") as fh:
+            return hashlib.sha256(fh.read()).hexdigest()[:16]
+    except OSError:
+        return None
+
+
+def from_file(path, config):
+    """(table of one config, provenance string) of a PMC-derived file; an empty table when it was measured on another build."""
+    tab = _json_file(path).get(config, {})
+    meta = tab.get("_meta", {}) if isinstance(tab, dict) else {}
+    name = os.path.relpath(path, ROOT)
+    if not tab:
+        return {}, "no PMC table for %s in %s" % (config, name)
+    if meta.get("lib_sha256_16") != lib_sha16():
+        return {}, "STALE, not used: %s was measured on library %s, this run uses %s (run scripts/profile_round.sh)" % (name, meta.get("lib_sha256_16"), lib_sha16())
+    return tab, "from_file %s, measured on this library build (sha256 %s): %s" % (name, meta.get("lib_sha256_16"), meta.get("what", ""))
 SCAN_KERNELS = ["k_scan_clips", "k_clip_events_bkt", "k_clip_events"]   # _bkt: bucketed path; plain: list + rocPRIM sort fallback
 
 
@@ -84,20 +107,20 @@ def kernel_entry(names, table, share, meta, config):
     e = {"kernel": "+".join(r[0] for r in rows), "avg_ms": round(ms / launches, 5), "launches_per_step": launches,
          "share_of_device_time": round(sum(share.get(r[0], 0.0) for r in rows), 3)}
     ab = [algorithmic_bytes(r[0], meta) for r in rows]
-    traffic = _json_file(PMC_TRAFFIC_FILE).get(config, {})
+    traffic, traffic_src = from_file(PMC_TRAFFIC_FILE, config)
     def pmc(name):      # the PMC table spells every template argument ("k_direct_repeats<0, 384>"), the event table the first
         hit = traffic.get(name) or next((v for k, v in traffic.items() if name.endswith(">") and k.startswith(name[:-1] + ",")), {})
         return hit.get("traffic_bytes")
     tr = [pmc(r[0]) for r in rows]
-    valu = _json_file(VALU_MODELS_FILE)
-    m = (valu.get(config, {}).get(rows[0][0]) or valu.get(rows[0][0])) if len(rows) == 1 else None   # per config where the cost per unit depends on the data shape
+    valu, valu_src = from_file(VALU_MODELS_FILE, config)
+    m = valu.get(rows[0][0]) if len(rows) == 1 else None   # per config: the cost per unit depends on the data shape
     tr_sum = sum(tr) if all(t is not None for t in tr) else None
     if all(a is not None for a in ab):
         ach = sum(ab) / (ms * 1e-3) / 1e9
         e.update({"bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5),
                   "algorithmic_bytes_per_step": sum(ab),
                   "traffic": tr_sum,
-                  "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, profiles/r02_pmc_traffic.json"})
+                  "traffic_source": traffic_src})
         if any(r[0] == "k_classify" for r in rows):
             e["note"] = "algorithmic bytes from an ESTIMATED number of (site, read) visits: sites after the first neighbour filter x 3 positions x coverage"
     elif m and meta["work"].get(m["work_counter"]):
@@ -106,10 +129,11 @@ def kernel_entry(names, table, share, meta, config):
         ach = ops / (ms * 1e-3) / 1e12
         e.update({"bound": "valu", "achieved": round(ach, 3), "peak": round(VALU_PEAK_TOPS, 1), "unit": "Tlane-op/s",
                   "frac": round(ach / VALU_PEAK_TOPS, 5), "work_units_per_step": units, "work_unit": m["unit"],
-                  "valu_insts_per_unit": m["valu_insts_per_unit"], "model_source": m.get("source"), "traffic": tr_sum,
-                  "note": m.get("note")})
+                  "valu_insts_per_unit": m["valu_insts_per_unit"], "valu_model_source": valu_src, "model_detail": m.get("source"), "traffic": tr_sum,
+                  "traffic_source": traffic_src, "note": m.get("note")})
     else:
-        e.update({"bound": "valu", "achieved": None, "peak": round(VALU_PEAK_TOPS, 1), "unit": "Tlane-op/s", "frac": None, "traffic": tr_sum})
+        e.update({"bound": "valu", "achieved": None, "peak": round(VALU_PEAK_TOPS, 1), "unit": "Tlane-op/s", "frac": None, "traffic": tr_sum,
+                  "traffic_source": traffic_src, "valu_model_source": valu_src})
     return e
 
 
@@ -235,6 +259,8 @@ def time_config(hip, name, pool, device, steps=20, warmup=3, isolates=12):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     row = {"workload": name if batch is None else "%s (%d isolates in one call)" % (name, isolates), "reads": packed.n_reads,
+           "multi_gpu_mode": {"C3_klebsiella": "--sharding coordinate (one contig holds > 95 % of the reads: whole-contig shards cannot scale; coordinate cuts keep the plasmids whole)",
+                              "C5_meta_50mb": "--sharding coordinate", "C4_ecoli_batch": "--sharding sample (--isolates per GPU)"}.get(name, "--sharding sample"),
            "ms_per_step": round(dt / steps * 1e3, 4), "reads_per_s": round(packed.n_reads * steps / dt, 1), "steps": steps,
            "device_span_ms": round(dev_ms / steps, 4),   # first to last HIP event of findflanks + of pairflanks (mfk_last_device_ms of the fused call)
            "insertions": len(truth), "flank_rows": int(len(ff["flanks"])),
@@ -549,8 +575,13 @@ def main():
                 meta_w = dict(meta, timed_steps=warm_calls)
                 roofline["top5_by_time"] = [kernel_entry([r[0]], full_table, share, meta_w, args.config) for r in full_table[:5]]
                 roofline["work_counters_per_step"] = work
-                roofline["whole_step"] = {"algorithmic_bytes": int(reads_here * 1 + meta["clipped_reads"] * 23 + meta["events"] * 24),
-                                          "GBps": round((reads_here * 1 + meta["clipped_reads"] * 23 + meta["events"] * 24) / (ms_per_step * 1e-3) / 1e9, 1),
+                own = int(reads_here * 1 + meta["clipped_reads"] * 23 + meta["events"] * 24)
+                # 24 B record + 1.5 B per clipped base + 8 B per extra block per read (= 25.6 B/read there), 13 B per
+                # (site, overlapping read) of loop B, and per candidate pair 104 B + (13 + 150 x 1.5 + 8) B per read over it
+                d8 = int(reads_here * 25.6 + meta["join_visits"] * 13 + int(st_pf[0]) * (104 + (13 + 233) * int(cfg["coverage"]) * 200 / 150))
+                roofline["whole_step"] = {"algorithmic_bytes": own, "GBps": round(own / (ms_per_step * 1e-3) / 1e9, 1), "frac_of_hbm_peak": round(own / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                                          "survey_8d_model": {"bytes": d8, "GBps": round(d8 / (ms_per_step * 1e-3) / 1e9, 1), "frac_of_hbm_peak": round(d8 / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                                                              "what": "SURVEY 8(d)'s per-read figure (25.6 B/read + 13 B per site x read visit + the pairing stage's per-pair bytes): what a 24-byte-record layout would move; the SoA layout of this build moves `algorithmic_bytes`"},
                                           "note": "the step is a chain of dependent launches over a few dozen sites: launch- and latency-bound, not HBM-bound"}
         if args.dump_profile:
             with open(args.dump_profile, "w") as fh:

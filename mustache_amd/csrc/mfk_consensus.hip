@@ -1951,8 +1951,17 @@ __global__ __launch_bounds__(SJ_THREADS) __attribute__((amdgpu_waves_per_eu(SJ_W
 // A launch whose static + dynamic LDS passes the default 64 KB per workgroup needs the kernel's limit raised first; what the
 // device cannot give (160 KB per CU on gfx950) is an error of the call with a message, not a failed launch.
 static int ensure_lds(mfk_ctx *ctx, const void *func, size_t dynamic_bytes, const char *name) {
+    // the static part of a kernel never changes: asked once per kernel (two kernels use this), not on every call
+    static const void *known[4] = {nullptr, nullptr, nullptr, nullptr};
+    static size_t known_static[4] = {0, 0, 0, 0};
     hipFuncAttributes fa;
-    HIPCHK(hipFuncGetAttributes(&fa, func));
+    int slot = -1;
+    for (int i = 0; i < 4; i++) if (known[i] == func) { slot = i; break; }
+    if (slot >= 0) fa.sharedSizeBytes = known_static[slot];
+    else {
+        HIPCHK(hipFuncGetAttributes(&fa, func));
+        for (int i = 0; i < 4; i++) if (!known[i]) { known_static[i] = fa.sharedSizeBytes; known[i] = func; break; }
+    }
     const size_t need = fa.sharedSizeBytes + dynamic_bytes;
     if (need <= 64 * 1024) return 0;
     int optin = 0;

@@ -107,6 +107,9 @@ __device__ void d_ir_detect(const uint8_t *code, int L, uint8_t *S, uint8_t *mas
         __syncthreads();
         const int cA = cm[iA], cB = cm[iB];
         const int wantA = cA < 4 ? 3 - cA : 16, wantB = cB < 4 ? 3 - cB : 16;   // the code that pairs with the row's base (none for N)
+        // The column character of a row moves one position per diagonal: lane i's next one is lane i + 1's current one, so it
+        // travels with the scores in the same DPP shift (bits 8..11 of the packed pair; a score is below 256) instead of
+        // coming from LDS every diagonal (the load's latency, not the arithmetic, set the pace of a diagonal).
         int cjA = cm[iA + 1], cjB = cm[iB + 1];
         unsigned pA = 0, pB = 0;               // S(i, i+d-1) | S(i, i+d-2) << 16
         int bestvA = 0, bestdA = 0, bestvB = 0, bestdB = 0;   // per row: highest score and the first diagonal that reached it (= smallest j)
@@ -114,10 +117,12 @@ __device__ void d_ir_detect(const uint8_t *code, int L, uint8_t *S, uint8_t *mas
         uint8_t *sA = S + iA * L + iA;         // S(iA, iA + d) = sA[d]
         uint8_t *sB = S + iB * L + iB;         // rows beyond the matrix write behind it: S has IR_S entries
         for (int d = 1; d < L; d++) {
-            unsigned nA = (unsigned)__builtin_amdgcn_update_dpp(0, (int)pA, 0x130 /* wave_shl:1: lane i <- lane i+1 */, 0xF, 0xF, false);
-            const unsigned fromB = (unsigned)__builtin_amdgcn_readfirstlane((int)pB);
-            if (lane == 63) nA = fromB;
-            const int ncjA = cm[iA + d + 1];   // next diagonal's column character: issued now, used in the next iteration
+            const unsigned xA = pA | ((unsigned)cjA << 8), xB = pB | ((unsigned)cjB << 8);
+            unsigned gA = (unsigned)__builtin_amdgcn_update_dpp(0, (int)xA, 0x130 /* wave_shl:1: lane i <- lane i+1 */, 0xF, 0xF, false);
+            const unsigned fromB = (unsigned)__builtin_amdgcn_readfirstlane((int)xB);
+            if (lane == 63) gA = fromB;
+            const unsigned nA = gA & 0x00FF00FFu;
+            const int ncjA = (int)((gA >> 8) & 15u);         // next diagonal's column character
             const int m = cjA == wantA ? MATCH : MISMATCH;   // a masked column (bit 3) never equals wantA
             int vA = (int)(nA >> 16) + m;                    // S(i+1, j-1) is 0 on the first two diagonals by construction
             const int up = (int)(nA & 0xFFFF) - GAP, left = (int)(pA & 0xFFFF) - GAP;
@@ -128,8 +133,10 @@ __device__ void d_ir_detect(const uint8_t *code, int L, uint8_t *S, uint8_t *mas
             pA = (pA << 16) | (unsigned)vA;
             cjA = ncjA;
             if (d < nB) {   // wave-uniform: rows 64.. have cells only on the first L - 64 diagonals; same branch-free step
-                const unsigned nBv = (unsigned)__builtin_amdgcn_update_dpp(0, (int)pB, 0x130, 0xF, 0xF, false);
-                const int ncjB = cm[iB + d + 1];
+                unsigned gB = (unsigned)__builtin_amdgcn_update_dpp(0, (int)xB, 0x130, 0xF, 0xF, false);
+                if (lane == 63) gB = 12u << 8;               // behind the last row: masked N
+                const unsigned nBv = gB & 0x00FF00FFu;
+                const int ncjB = (int)((gB >> 8) & 15u);
                 const int mb = cjB == wantB ? MATCH : MISMATCH;
                 int vB = (int)(nBv >> 16) + mb;
                 const int upb = (int)(nBv & 0xFFFF) - GAP, leftb = (int)(pB & 0xFFFF) - GAP;
@@ -139,7 +146,7 @@ __device__ void d_ir_detect(const uint8_t *code, int L, uint8_t *S, uint8_t *mas
                 if (vB > bestvB) { bestvB = vB; bestdB = d; }
                 pB = (pB << 16) | (unsigned)vB;
                 cjB = ncjB;
-            }
+            } else cjB = 12;   // columns behind the sequence: masked N (row A's lane 63 takes its next character from here)
         }
         unsigned bestkey = 0;   // score << 16 | (255 - j) << 8 | i : highest score, then smallest j, then largest i
         if (bestvB > 0) bestkey = ((unsigned)bestvB << 16) | ((unsigned)(255 - (iB + bestdB)) << 8) | (unsigned)iB;
@@ -409,12 +416,22 @@ __global__ __launch_bounds__(1024) void k_spanning(DevReads R, DevParams P, Flan
     __syncthreads();
     uint32_t mine = 0;
     for (int64_t r = range[0] + threadIdx.x; r < range[1]; r += blockDim.x) {
-        if (!d_overlaps(R, r, start)) continue;
-        uint8_t f = R.flags[r];
-        if (!d_passes(R, P, r, f) || !d_spans(R, P, r, f, pos3, pos5)) continue;
+        // the columns every test looks at, loaded together and pinned before the first branch (one round trip instead of a chain
+        // of three: positions, then flags, then mapping quality); the two coordinates settle nearly every read of an insertion
+        // site (its reads end AT the junction, they do not span it), the rest is looked at only for the few that are left
+        int32_t rs = R.ref_start[r], re = R.ref_end[r];
+        uint32_t f32 = R.flags[r], mq = R.mapq[r];
+        int32_t lk = R.link[r];
+        asm volatile("" : "+v"(rs), "+v"(re), "+v"(f32), "+v"(mq), "+v"(lk));
+        if ((re <= rs ? rs + 1 : re) <= start) continue;                 // d_overlaps
+        if (!(rs < pos3 - 10 && re > pos5 + 10 + 1)) continue;           // pairflanks.py:381-383 (quirk P7)
+        const uint8_t f = (uint8_t)f32;
+        if ((int)mq < P.minq) continue;                                   // d_passes: mapping quality, then the inner length of a
+        if (d_lkind(f) && d_rkind(f) && (int)R.qlen[r] - d_rlen(R, r, f) - d_llen(R, r, f) < P.minial) continue;   // read clipped at both ends
+        if (d_large_insertion_at(R, P, r, f, pos3) || d_large_insertion_at(R, P, r, f, pos5)) continue;
         bool dup = false;
         int64_t prev = r;
-        for (int64_t p = R.link[r]; p >= 0 && p < prev; prev = p, p = R.link[p]) {
+        for (int64_t p = lk; p >= 0 && p < prev; prev = p, p = R.link[p]) {
             if ((int32_t)R.contig_id[p] != contig) continue;
             if (!(R.ref_start[p] < end && d_overlaps(R, p, start))) continue;
             uint8_t fp = R.flags[p];

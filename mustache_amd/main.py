@@ -71,7 +71,10 @@ def findflanks(bamfile, min_softclip_length, min_softclip_count, min_alignment_q
 @click.option("--device", default="cuda:0", help="GPU to run on (not in the reference).")
 @click.option("--ir-backend", "ir_backend", type=click.Choice(["builtin", "einverted"]), default="builtin",
               help="Inverted-repeat detector: the library's own (default) or EMBOSS einverted as the reference runs it "
-                   "(needs the executable on PATH; not in the reference).")
+                   "(needs the executable on PATH; not in the reference).  PARITY NOTE: with 'builtin' the columns has_IR, IR_length, "
+                   "IR_5p and IR_3p follow this build's restatement of einverted's model (DESIGN.md section 6), which could not be checked "
+                   "against EMBOSS (absent from the build image and the reference tree); every other column is pinned to the reference. "
+                   "Use 'einverted' for reference-identical IR columns.")
 def pairflanks(flanksfile, bamfile, genome, max_direct_repeat_length, min_alignment_quality,
                min_alignment_inner_length, max_junction_spanning_prop, large_insertion_cutoff, output_file, exclude_flags, device,
                ir_backend):

@@ -33,6 +33,8 @@ def main():
                 table[f[0]] = int(f[2]) // 3           # launches per step (three bracketed steps)
         models = {}
         for kernel, v in valu[config].items():
+            if kernel == "_meta":
+                continue
             k = kernel.split("<")[0] if kernel.startswith("k_direct") else kernel
             if k.startswith(SKIP) or not v.get("valu_insts_per_launch"):
                 continue
@@ -47,10 +49,11 @@ def main():
                               "source": "profiles/%s_pmc_valu.json (rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES, %s): %d wave instructions per launch x %d launches per step / %d %s per step"
                                         % (tag, config, v["valu_insts_per_launch"], launches, units, counter.replace("_", " ")),
                               "note": "issue-rate roof; the kernel is a chain of dependent loads and LDS steps per job, so the distance to the roof is occupancy and latency, not arithmetic"}
+        models["_meta"] = valu[config].get("_meta", {})
         out[config] = models
     path = os.path.join(ROOT, "profiles", tag + "_valu_models.json")
     json.dump(out, open(path, "w"), indent=1, sort_keys=True)
-    print(path, {c: len(m) for c, m in out.items()})
+    print(path, {c: len(m) - 1 for c, m in out.items()})
 
 
 if __name__ == "__main__":

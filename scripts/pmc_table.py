@@ -38,12 +38,21 @@ def per_launch(directory, counter):
     return {k: tot[k] / cnt[k] for k in tot}, dict(cnt)
 
 
+def lib_sha():
+    """sha256 of the library the passes ran on: bench.py uses a table only on the build it was measured on."""
+    import hashlib
+    p = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "mustache_amd", "csrc", "libmfk.so")
+    with open(p, "rb") as fh:
+        return hashlib.sha256(fh.read()).hexdigest()[:16]
+
+
 def update(path, config, entry):
     try:
         with open(path) as fh:
             tab = json.load(fh)
     except (OSError, ValueError):
         tab = {}
+    entry["_meta"] = {"lib_sha256_16": lib_sha(), "what": "rocprofv3 --pmc passes of `bench.py --quick --config %s` on this build (scripts/profile_round.sh)" % config}
     tab[config] = entry
     with open(path, "w") as fh:
         json.dump(tab, fh, indent=1, sort_keys=True)
@@ -60,14 +69,14 @@ def main():
         entry[k] = {"fetch_size_kb": round(f.get(k, 0.0), 2), "write_size_kb": round(w.get(k, 0.0), 2), "fetch_multiplier": mult,
                     "traffic_bytes": int(round((f.get(k, 0.0) * mult + w.get(k, 0.0)) * 1024))}
     update(out, config, entry)
-    print(json.dumps({k: v["traffic_bytes"] for k, v in entry.items()}, indent=1))
+    print(json.dumps({k: v["traffic_bytes"] for k, v in entry.items() if k != "_meta"}, indent=1))
     if len(sys.argv) >= 7:
         valu_dir, out_valu = sys.argv[5:7]
         (v, calls), (wv, _) = per_launch(valu_dir, "SQ_INSTS_VALU"), per_launch(valu_dir, "SQ_WAVES")
         entry = {k: {"valu_insts_per_launch": int(round(v[k])), "waves_per_launch": int(round(wv.get(k, 0))), "launches_seen": calls[k]}
                  for k in sorted(v) if k.startswith("k_") or k.startswith("rocprim")}
         update(out_valu, config, entry)
-        print(json.dumps({k: e["valu_insts_per_launch"] for k, e in entry.items()}, indent=1))
+        print(json.dumps({k: e["valu_insts_per_launch"] for k, e in entry.items() if k != "_meta"}, indent=1))
 
 
 if __name__ == "__main__":

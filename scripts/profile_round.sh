@@ -1,8 +1,8 @@
 #!/bin/bash
 # Round profile of one config (run on the GPU box): HIP-event table, rocprofv3 kernel stats and the three PMC passes.
-#   bash scripts/profile_round.sh r02 C2_saureus_1000x c2      (round tag, bench config, short tag)
+#   bash scripts/profile_round.sh r03 C2_saureus_1000x c2      (round tag, bench config, short tag)
 set -e
-R=${1:-r02}; CFG=${2:-C2_saureus_1000x}; T=${3:-c2}
+R=${1:-r03}; CFG=${2:-C2_saureus_1000x}; T=${3:-c2}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/round_$T
 rm -rf $O && mkdir -p $O
