@@ -199,6 +199,7 @@ def cpu_legs(packed, genome, truth, params, n_insertions, cores):
                      % (sub.n_reads, min(n_insertions, len(pos)), 100.0 * sub.n_reads / packed.n_reads, dt1)}
     if cores > 1:
         h = md.halo(params.min_distance_to_mate, params.max_direct_repeat_length)
+        md._tables()      # the table loops of the sharded path (host code of libmfk.so): opened once here, inherited by the workers
         _cpu.update(ora=ora, sample=sub, params=params, ranks=ranks, g=g, goff=goff, plans=md.plan_shards(sub, cores, "coordinate", h))
         t0 = time.perf_counter()
         with mp.get_context("fork").Pool(cores) as pool:

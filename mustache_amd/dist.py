@@ -221,6 +221,9 @@ def _tables():
     if _tables_so is None:
         import ctypes as C
         try:
+            # torch's own copy of the HIP runtime has to be in the process BEFORE libmfk.so is opened (lib.load does the same):
+            # opened first, libmfk.so would pull in the system's libamdhip64 and a later lib.load finds "no usable HIP device"
+            import torch  # noqa: F401
             so = C.CDLL(_lib.LIB_PATH)
             p, i64, i32 = C.c_void_p, C.c_int64, C.c_int32
             so.mfk_flanks_owned.restype = i64
