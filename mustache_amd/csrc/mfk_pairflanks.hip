@@ -85,7 +85,13 @@ __device__ __forceinline__ int d_ir_code(char ch) {
 // one wave per sequence.  s: LDS copy of the sequence codes; S: LDS L x L score matrix, one byte per cell (a score is at most
 // 3 x 50 pairs of a 100-base sequence and never negative), so that eleven workgroups share a CU instead of six.
 // out[6]: has_ir, arm1 start/end, arm2 start/end (1-based inclusive), number of repeats reported
-__device__ void d_ir_detect(const uint8_t *code, int L, uint8_t *S, uint8_t *mask, int32_t *rep /* 4*IR_MAXREP, LDS */, int32_t *out) {
+// early: stop as soon as no ACCEPTED repeat can follow (pairflanks needs has_IR and the arms, not the number of repeats): a
+// repeat is accepted only if its outer cell (arm1 start, arm2 end) lies in the corner i <= 14, j >= L - 16 (pairflanks.py:253-266),
+// a repeat is reported only with a score >= 15 in that cell, and masking more positions can only lower a score (the recurrence
+// is monotone).  So once every corner cell of a pass is below the threshold, this pass and all later ones report nothing that
+// the acceptance loop would take, and has / arms are final.  Pairs without a terminal repeat then cost one pass instead of up to
+// eight (chance repeats of five pairs elsewhere in 100 bases are common).  out[5] is then the number found so far.
+__device__ void d_ir_detect(const uint8_t *code, int L, uint8_t *S, uint8_t *mask, int32_t *rep /* 4*IR_MAXREP, LDS */, int32_t *out, bool early = false) {
     const int MATCH = 3, MISMATCH = -4, GAP = 12, THRESHOLD = 15;
     const int lane = threadIdx.x & 63;
     for (int i = lane; i < L; i += 64) mask[i] = 0;
@@ -158,6 +164,15 @@ __device__ void d_ir_detect(const uint8_t *code, int L, uint8_t *S, uint8_t *mas
         for (int o = 32; o > 0; o >>= 1) { unsigned other = __shfl_xor(bestkey, o, 64); if (other > bestkey) bestkey = other; }
         int best = (int)(bestkey >> 16);
         if (best < THRESHOLD) break;
+        if (early) {
+            int cmax = 0;
+            for (int t = lane; t < 15 * 16; t += 64) {
+                const int i = t >> 4, j = L - 16 + (t & 15);
+                if (i < L && j > i) { const int v = S[i * L + j]; cmax = v > cmax ? v : cmax; }
+            }
+            for (int o = 32; o > 0; o >>= 1) { const int other = __shfl_xor(cmax, o, 64); cmax = other > cmax ? other : cmax; }
+            if (cmax < THRESHOLD) break;
+        }
         if (lane == 0) {
             int bi = (int)(bestkey & 255), bj = 255 - (int)((bestkey >> 8) & 255);
             int i = bi, j = bj, ii = bi, jj = bj;
@@ -238,7 +253,7 @@ __global__ __launch_bounds__(64) void k_inverted_repeat(FlankDev F, const uint32
         code[i] = (uint8_t)d_ir_code(ch);
     }
     __syncthreads();
-    d_ir_detect(code, L, S, mask, rep, out + 6 * (size_t)k);
+    d_ir_detect(code, L, S, mask, rep, out + 6 * (size_t)k, true);
     if (threadIdx.x == 0) { keys[k] = d_assign_key(F, a, b, out + 6 * (size_t)k); vals[k] = k; }
 }
 

@@ -370,6 +370,20 @@ class Binding:
         return float(self.last_device_ms(self.ctx))
 
 
+def tune_allocator():
+    """For processes that call the library in a loop (bench.py, the CLI over a cohort): the result tables of a call are megabytes
+    of fresh numpy memory, which glibc hands out as new anonymous mappings and returns to the kernel when they are freed, so
+    every call pays their page faults again (0.15 ms per 4 MB here).  Raising the mmap / trim thresholds keeps freed blocks in the
+    heap.  Process-wide policy, so only entry points call it, never an import.  MFK_NO_MALLOC_TUNE=1 leaves malloc alone."""
+    if os.environ.get("MFK_NO_MALLOC_TUNE", "0") not in ("", "0"):
+        return False
+    try:
+        libc = C.CDLL(None)
+        return bool(libc.mallopt(-3, 1 << 28)) and bool(libc.mallopt(-1, 1 << 28))      # M_MMAP_THRESHOLD, M_TRIM_THRESHOLD
+    except (OSError, AttributeError):
+        return False
+
+
 def host_header(packed):
     a = packed.a
     return {"contig_len": a["contig_len"], "contig_read_start": a["contig_read_start"],
