@@ -306,6 +306,10 @@ int mfk_pairs_merge(mfk_pair *rows, const int64_t *counts, int32_t world, const 
 
 /* time spent in device work of the last compute call, milliseconds (HIP events on the ctx stream) */
 double mfk_last_device_ms(mfk_ctx *ctx);
+/* on (the default): findflanks / pairflanks / recall record an event before their first and behind their last kernel, which is
+ * what mfk_last_device_ms reports.  off: those two records per stage are skipped (a few microseconds of host time each, which a
+ * loop over sub-millisecond calls notices) and mfk_last_device_ms returns 0. */
+int mfk_span_timing(mfk_ctx *ctx, int on);
 
 /* per-kernel timing for bench.py: when enabled, every kernel launch of the compute calls is bracketed by HIP events on
  * the ctx stream and the durations are accumulated per kernel name.  enable(…, on) also clears the totals.

@@ -19,7 +19,7 @@ mfk_ctx *mfk_create(int device_id) {
     ctx->hdr_dev = nullptr; ctx->hdr_cap = 0;
     ctx->gather_flag = nullptr; ctx->gather_flag_dev = nullptr;
     ctx->gather_seq = 0;
-    ctx->scan_state = nullptr; ctx->scan_err = nullptr; ctx->call_ok = true;
+    ctx->scan_state = nullptr; ctx->scan_err = nullptr; ctx->call_ok = true; ctx->span_on = true;
     { const char *e0 = getenv("MFK_SCAN_EPOCH0"); ctx->scan_epoch = e0 ? (uint32_t)atoi(e0) & 0xFFFFu : 0u; }   // test hook: start near the wrap
     ctx->fill_stream = nullptr;
     ctx->na_pinned = nullptr;
@@ -80,6 +80,7 @@ void mfk_destroy(mfk_ctx *ctx) {
 const char *mfk_last_error(mfk_ctx *ctx) { return ctx ? ctx->err : "null ctx"; }
 int mfk_version(void) { return 1; }
 double mfk_last_device_ms(mfk_ctx *ctx) { return ctx ? ctx->last_ms : 0.0; }
+int mfk_span_timing(mfk_ctx *ctx, int on) { if (!ctx) return 1; ctx->span_on = on != 0; if (!on) ctx->last_ms = 0.0; return 0; }
 
 int mfk_profile_enable(mfk_ctx *ctx, int on) {
     if (!ctx) return 1;

@@ -812,7 +812,7 @@ int findflanks_impl(mfk_ctx *ctx, const mfk_reads *reads, const mfk_params *para
     DevReads R; DevParams P;
     if (int rc = upload_reads(ctx, reads, params, &R, &P)) return rc;
     hipStream_t st = ctx->stream;
-    HIPCHK(hipEventRecord(ctx->ev0, st));
+    SPAN_EVENT(ev0);
     // (stage 1 below) -------------------------------------------------------------------------------
     const int64_t ngroups = (R.n + 15) >> 4;
     unsigned nblk = (unsigned)((ngroups + SCAN_THREADS - 1) / SCAN_THREADS);
@@ -1010,7 +1010,7 @@ int findflanks_impl(mfk_ctx *ctx, const mfk_reads *reads, const mfk_params *para
         ht.lap("rows handed over on the device");
         return 0;
     }
-    HIPCHK(hipEventRecord(ctx->ev1, st));
+    SPAN_EVENT(ev1);
     // ---- results to the host -------------------------------------------------------------------------------------
     uint32_t h_stats[MFK_N_STATS], h_scan_err = 0;
     if (dev_rows) {
@@ -1038,7 +1038,7 @@ int findflanks_impl(mfk_ctx *ctx, const mfk_reads *reads, const mfk_params *para
         ctx->stats[12] = (int64_t)((uint64_t)h_stats[12] | ((uint64_t)h_stats[13] << 32));
         prof_collect(ctx);
         float ms = 0.f;
-        if (hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1) == hipSuccess) ctx->last_ms = ms;
+        if (ctx->span_on && hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1) == hipSuccess) ctx->last_ms = ms;
     } else {
     std::vector<uint32_t> gpos(n_act), cnt2(2 * (size_t)n_act), stv(n_act), counts(8 * (size_t)n_act);
     std::vector<int32_t> contig(n_act);
@@ -1068,7 +1068,7 @@ int findflanks_impl(mfk_ctx *ctx, const mfk_reads *reads, const mfk_params *para
     ctx->stats[12] = (int64_t)((uint64_t)h_stats[12] | ((uint64_t)h_stats[13] << 32));
     prof_collect(ctx);
     float ms = 0.f;
-    if (hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1) == hipSuccess) ctx->last_ms = ms;
+    if (ctx->span_on && hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1) == hipSuccess) ctx->last_ms = ms;
     if (io.err_flags & 2u) { snprintf(ctx->err, sizeof ctx->err, "a clipped read at a surviving site has no sequence in the pool (pack with pool='clipped')"); return 2; }
     if (n_act > 0) {
         // contig_base on the host (same formula as upload_reads)
@@ -1149,14 +1149,14 @@ extern "C" int mfk_recall(mfk_ctx *ctx, const mfk_reads *reads, const mfk_params
     int32_t *hs = (int32_t *)(hp + pin_off);
     for (int64_t i = 0; i < n_sites; i++) { hs[2 * i] = h_contig_id[i]; hs[2 * i + 1] = h_pos[i]; }
     HIPCHK(hipMemcpyAsync(d_sites, hs, bytes, hipMemcpyHostToDevice, st));
-    HIPCHK(hipEventRecord(ctx->ev0, st));
+    SPAN_EVENT(ev0);
     PROF_LAUNCH(k_recall, dim3((unsigned)n_sites), dim3(n_sites >= 2048 ? 256 : 1024), 0, st, R, P, (const int32_t *)d_sites, (uint32_t)n_sites, d_counts);
     KCHK();
-    HIPCHK(hipEventRecord(ctx->ev1, st));
+    SPAN_EVENT(ev1);
     if (int rc = read_back(ctx, d_counts, h_counts, 10 * (size_t)n_sites * 4)) return rc;
     prof_collect(ctx);
     float ms = 0.f;
-    if (hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1) == hipSuccess) ctx->last_ms = ms;
+    if (ctx->span_on && hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1) == hipSuccess) ctx->last_ms = ms;
     ctx->call_ok = true;
     return 0;
 }
@@ -1225,14 +1225,14 @@ extern "C" int mfk_recall_noalloc(mfk_ctx *ctx, const mfk_reads *reads, const mf
     for (int64_t i = 0; i < n_sites; i++) { h_sites[2 * i] = h_contig_id[i]; h_sites[2 * i + 1] = h_pos[i]; }
     HIPCHK(hipMemcpyAsync(d_hdr, h_hdr, (used + 15) & ~(size_t)15, hipMemcpyHostToDevice, st));
     HIPCHK(hipMemcpyAsync(d_sites, h_sites, (size_t)n_sites * 8, hipMemcpyHostToDevice, st));
-    HIPCHK(hipEventRecord(ctx->ev0, st));
+    SPAN_EVENT(ev0);
     hipLaunchKernelGGL(k_recall, dim3((unsigned)n_sites), dim3(n_sites >= 2048 ? 256 : 1024), 0, st, R, P, (const int32_t *)d_sites, (uint32_t)n_sites, (int32_t *)d_cnt);
     KCHK();
-    HIPCHK(hipEventRecord(ctx->ev1, st));
+    SPAN_EVENT(ev1);
     HIPCHK(hipMemcpyAsync(h_cnt, d_cnt, (size_t)n_sites * 40, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     memcpy(h_counts, h_cnt, (size_t)n_sites * 40);
     float ms = 0.f;
-    if (hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1) == hipSuccess) ctx->last_ms = ms;
+    if (ctx->span_on && hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1) == hipSuccess) ctx->last_ms = ms;
     return 0;
 }

@@ -46,6 +46,7 @@ struct mfk_ctx {
     hipStream_t fill_stream;   // while set, FillGroup launches go to this stream instead of `stream` (fills that overlap the kernels before their first consumer)
     unsigned long long *scan_state; uint32_t scan_epoch;   // tile aggregates of k_scan_chain, tagged with the call's epoch (never cleared between calls)
     uint32_t *scan_err;             // device word behind the aggregates: set when a workgroup of k_scan_chain gave up waiting for a predecessor
+    bool span_on;                   // the two events that bracket a call's device work are recorded (mfk_last_device_ms); mfk_span_timing turns them off
     bool call_ok;                   // the previous compute call ran to its end: its side streams are joined (else arena_reset drains them)
     double last_ms;
     std::vector<Chunk> chunks;      // device arena
@@ -96,6 +97,8 @@ struct mfk_ctx {
     } while (0)
 
 #define KCHK() HIPCHK(hipGetLastError())
+// first / last event of a call's device work: two API calls (4 us each here) that a caller in a tight loop can do without
+#define SPAN_EVENT(ev) do { if (ctx->span_on) HIPCHK(hipEventRecord(ctx->ev, st)); else ctx->last_ms = 0.0; } while (0)
 
 void prof_begin(mfk_ctx *ctx, const char *name, hipStream_t stream = nullptr);   // events go to `stream` (default: the ctx stream)
 void prof_end(mfk_ctx *ctx, hipStream_t stream = nullptr);

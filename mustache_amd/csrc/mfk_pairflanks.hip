@@ -748,14 +748,14 @@ extern "C" int mfk_ir_detect(mfk_ctx *ctx, const char *seqs, const int64_t *off,
     if (!d_seqs || !d_off || !d_out) return 1;
     HIPCHK(hipMemcpyAsync(d_seqs, seqs, (size_t)total, hipMemcpyHostToDevice, st));
     HIPCHK(hipMemcpyAsync(d_off, off, ((size_t)n + 1) * 8, hipMemcpyHostToDevice, st));
-    HIPCHK(hipEventRecord(ctx->ev0, st));
+    SPAN_EVENT(ev0);
     PROF_LAUNCH(k_ir_seqs, dim3((unsigned)n), dim3(64), 0, st, (const char *)d_seqs, (const int64_t *)d_off, (uint32_t)n, d_out);
     KCHK();
-    HIPCHK(hipEventRecord(ctx->ev1, st));
+    SPAN_EVENT(ev1);
     HIPCHK(hipMemcpyAsync(out, d_out, 6 * (size_t)n * 4, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     float ms = 0.f;
-    if (hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1) == hipSuccess) ctx->last_ms = ms;
+    if (ctx->span_on && hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1) == hipSuccess) ctx->last_ms = ms;
     ctx->call_ok = true;
     return 0;
 }
@@ -854,7 +854,7 @@ int pairflanks_impl(mfk_ctx *ctx, const mfk_reads *reads, const mfk_params *para
         PROF_LAUNCH(k_flank_cols, dim3(nblocks(nF, 256)), dim3(256), 0, st, fh->d_flanks, fh->d_rows_total, nF, d_tab, d_soff);
         KCHK();
     } else
-        HIPCHK(hipEventRecord(ctx->ev0, st));   // (hand-over: the call's device time runs from findflanks' first kernel)
+        SPAN_EVENT(ev0);   // (hand-over: the call's device time runs from findflanks' first kernel)
     FlankDev F; F.n = nF; F.contig = d_tab; F.pos = d_tab + nF; F.orient = d_tab + 2 * (size_t)nF; F.ccount = d_tab + 3 * (size_t)nF;
     F.total = d_tab + 4 * (size_t)nF; F.seq_len = d_tab + 5 * (size_t)nF; F.seq_off = d_soff; F.seqs = d_seqs;
     // ---- candidate pairs ----------------------------------------------------------------------------------------------
@@ -1020,7 +1020,7 @@ int pairflanks_impl(mfk_ctx *ctx, const mfk_reads *reads, const mfk_params *para
             PROF_LAUNCH(k_prow_fill, dim3(pb), dim3(256), 0, st, F, (const uint32_t *)fin, (const uint32_t *)fin_span, nfin_p, (const uint32_t *)c5, (const uint32_t *)c3, (const int32_t *)ir,
                         (const int32_t *)meta, (const char *)dr, stride, (const uint64_t *)poff, d_pairs, d_strs);
             KCHK();
-            HIPCHK(hipEventRecord(ctx->ev1, st));
+            SPAN_EVENT(ev1);
             uint32_t h_perr = 0; uint64_t h_total = 0;
             {
                 ReadBatch rb(ctx);
@@ -1040,7 +1040,7 @@ int pairflanks_impl(mfk_ctx *ctx, const mfk_reads *reads, const mfk_params *para
                 ctx->pstats[1] = nK; ctx->pstats[2] = h_ps[2]; ctx->pstats[3] = h_ps[3]; ctx->pstats[4] = nFin;
                 prof_collect(ctx);
                 float ms = 0.f;
-                if (hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1) == hipSuccess) ctx->last_ms = ms;
+                if (ctx->span_on && hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1) == hipSuccess) ctx->last_ms = ms;
                 ctx->call_ok = true;
                 if (n_pairs_out) *n_pairs_out = (int64_t)ctx->pairs.size();
                 if (str_bytes_out) *str_bytes_out = (int64_t)ctx->strs.size();
@@ -1048,7 +1048,7 @@ int pairflanks_impl(mfk_ctx *ctx, const mfk_reads *reads, const mfk_params *para
             }
             // an error among the final pairs (rare): the host loop below reports it in the reference's words
         }
-        HIPCHK(hipEventRecord(ctx->ev1, st));
+        SPAN_EVENT(ev1);
         h_fin.resize(nP); h_span.resize(nP); h_meta.resize(3 * (size_t)nP); h_dr.resize((size_t)nP * stride);
         h_c5.resize(nP); h_c3.resize(nP); h_ir.resize(6 * (size_t)nP);
         ReadBatch rb(ctx);
@@ -1063,7 +1063,7 @@ int pairflanks_impl(mfk_ctx *ctx, const mfk_reads *reads, const mfk_params *para
         if (int rc = rb.flush()) return rc;
         ht.lap("results read-back");
     } else {
-        HIPCHK(hipEventRecord(ctx->ev1, st));
+        SPAN_EVENT(ev1);
         if (ff_pending) { ReadBatch rb(ctx); add_ff_tables(rb); if (int rc = rb.flush()) return rc; }
     }
     if (dev_in) { flanks = ctx->flanks.data(); flank_seqs = ctx->seqs.data(); }   // the host loop below reads the table findflanks made
@@ -1074,7 +1074,7 @@ int pairflanks_impl(mfk_ctx *ctx, const mfk_reads *reads, const mfk_params *para
     ctx->pstats[2] = h_ps[2]; ctx->pstats[3] = h_ps[3]; ctx->pstats[4] = nFin;
     prof_collect(ctx);
     float ms = 0.f;
-    if (hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1) == hipSuccess) ctx->last_ms = ms;
+    if (ctx->span_on && hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1) == hipSuccess) ctx->last_ms = ms;
     // ---- rows ------------------------------------------------------------------------------------------------------------
     ctx->pairs.reserve(nFin);
     ctx->strs.reserve((size_t)nFin * 64);

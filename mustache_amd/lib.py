@@ -136,6 +136,10 @@ class Binding:
             f("allgather_fetch", C.c_int, [_p, C.c_int, _p, _p])
             f("allgather_fetch_all", C.c_int, [_p, _p, _p])
             f("allgather_next_bytes", C.c_int64, [_p])
+        if hasattr(self.so, prefix + "span_timing"):
+            fn = getattr(self.so, prefix + "span_timing")
+            fn.restype, fn.argtypes = C.c_int, [_p, C.c_int]
+            self._span_timing = fn
         if hasattr(self.so, prefix + "profile_enable"):
             f("profile_enable", C.c_int, [_p, C.c_int])
             f("profile_fetch", C.c_int, [_p, _p, C.c_int64, _p, _p, C.c_int64, C.POINTER(C.c_int64)])
@@ -365,6 +369,11 @@ class Binding:
                                        C.byref(n)))
         lst = names.value.decode().split("\n")[:n.value]
         return {nm: (float(ms[i]), int(calls[i])) for i, nm in enumerate(lst)}
+
+    def span_timing(self, on=True):
+        """Record (default) or skip the two events per stage behind device_ms(); off saves their host time in tight loops."""
+        if hasattr(self, "_span_timing"):
+            self._check(self._span_timing(self.ctx, 1 if on else 0))
 
     def device_ms(self):
         return float(self.last_device_ms(self.ctx))
