@@ -933,10 +933,24 @@ int pairflanks_impl(mfk_ctx *ctx, const mfk_reads *reads, const mfk_params *para
         }
         // Side streams: direct repeats and spanning reads of every candidate (they depend on the positions only), each on
         // its own stream.  Main stream: inverted repeats -> assign_pairs.  (Timing events of a launch go to the stream of that launch.)
-        hipStream_t sb = ctx->stream2, sc = ctx->stream3;
+        // A few dozen candidates (a single isolate): the inverted-repeat alignment is as long as the two other kernels together, so
+        // ONE side stream carries both (three stream operations less for the host, which sets the pace of so short a call).
+        const bool one_side = nP <= PA_SMALL;
+        hipStream_t sb = ctx->stream2, sc = one_side ? ctx->stream2 : ctx->stream3;
         HIPCHK(hipEventRecord(ctx->ev_fork, st));
         HIPCHK(hipStreamWaitEvent(sb, ctx->ev_fork, 0));
-        HIPCHK(hipStreamWaitEvent(sc, ctx->ev_fork, 0));
+        if (!one_side) HIPCHK(hipStreamWaitEvent(sc, ctx->ev_fork, 0));
+        // the inverted-repeat alignment first: it is the longest chain of the stage and everything on this stream waits for it
+        if (ir_tab.empty()) {
+            PROF_LAUNCH(k_inverted_repeat, dim3(nP), dim3(64), 0, st, F, (const uint32_t *)c5, (const uint32_t *)c3, nP, ir, keys, vals);
+            KCHK();
+        } else {
+            int32_t *d_tab_ir = aalloc<int32_t>(ctx, ir_tab.size());
+            if (!d_tab_ir) return 1;
+            HIPCHK(hipMemcpyAsync(d_tab_ir, ir_tab.data(), ir_tab.size() * 4, hipMemcpyHostToDevice, st));   // ir_tab lives until the call returns
+            PROF_LAUNCH(k_ir_lookup, dim3(pb), dim3(256), 0, st, F, (const uint32_t *)c5, (const uint32_t *)c3, nP, (const int32_t *)d_tab_ir, (uint32_t)(ir_tab.size() / 7), ir, keys, vals, d_pstats + 15);
+            KCHK();
+        }
         if (dr_split > 1) {
             prof_begin(ctx, "k_direct_repeats<1>", sb);
                 hipLaunchKernelGGL((k_direct_repeats<1, DR_SEGS>), dim3(nP, dr_split), dim3(1024), 0, sb, R, F, nP, (const uint32_t *)c5, (const uint32_t *)c3,
@@ -962,20 +976,10 @@ int pairflanks_impl(mfk_ctx *ctx, const mfk_reads *reads, const mfk_params *para
             }
             KCHK();
         }
-        HIPCHK(hipEventRecord(ctx->ev_join, sb));
+        if (!one_side) HIPCHK(hipEventRecord(ctx->ev_join, sb));
         PROF_LAUNCH(k_spanning, dim3(nP), dim3(nP >= 2048 ? 256 : 1024), 0, sc, R, P, F, (const uint32_t *)c5, (const uint32_t *)c3, nP, span_all);
         KCHK();
-        HIPCHK(hipEventRecord(ctx->ev_join3, sc));
-        if (ir_tab.empty()) {
-            PROF_LAUNCH(k_inverted_repeat, dim3(nP), dim3(64), 0, st, F, (const uint32_t *)c5, (const uint32_t *)c3, nP, ir, keys, vals);
-            KCHK();
-        } else {
-            int32_t *d_tab_ir = aalloc<int32_t>(ctx, ir_tab.size());
-            if (!d_tab_ir) return 1;
-            HIPCHK(hipMemcpyAsync(d_tab_ir, ir_tab.data(), ir_tab.size() * 4, hipMemcpyHostToDevice, st));   // ir_tab lives until the call returns
-            PROF_LAUNCH(k_ir_lookup, dim3(pb), dim3(256), 0, st, F, (const uint32_t *)c5, (const uint32_t *)c3, nP, (const int32_t *)d_tab_ir, (uint32_t)(ir_tab.size() / 7), ir, keys, vals, d_pstats + 15);
-            KCHK();
-        }
+        HIPCHK(hipEventRecord(one_side ? ctx->ev_join : ctx->ev_join3, sc));
         const uint32_t *nK_p = kscan + nP;
         if (nP <= PA_SMALL) {
             // few candidates (a deep isolate): assign_pairs in one launch, the junction filter in another
@@ -983,7 +987,7 @@ int pairflanks_impl(mfk_ctx *ctx, const mfk_reads *reads, const mfk_params *para
                         best5, best3, used5, used3, kept, kscan + nP);
             KCHK();
             HIPCHK(hipStreamWaitEvent(st, ctx->ev_join, 0));
-            HIPCHK(hipStreamWaitEvent(st, ctx->ev_join3, 0));
+            if (!one_side) HIPCHK(hipStreamWaitEvent(st, ctx->ev_join3, 0));
             PROF_LAUNCH(k_pair_finish_small, dim3(1), dim3(PA_MAX), 0, st, P, F, (const uint32_t *)kept, (const uint32_t *)c5, (const uint32_t *)c3, nK_p, (const int32_t *)ir,
                         (const uint32_t *)span_all, fin, fin_span, jscan + nP, d_pstats);
             KCHK();
