@@ -308,6 +308,49 @@ __global__ __launch_bounds__(1024) void k_assign(const uint32_t *order, const ui
     for (uint32_t p = threadIdx.x; p < n; p += blockDim.x) kflag[p] = state[p] == 1 ? 1u : 0u;
 }
 
+// assign_pairs without a device-wide sort and without one workgroup walking every candidate (thousands of candidates, flank
+// table sorted by (contig, position)).  The greedy exclusion (pairflanks.py:233-245) couples two candidates only through a
+// shared flank, and such candidates are neighbours in the candidate list: the candidates of a 5p flank are one stretch of it (3p
+// rows ascending), the windows of successive 5p flanks are intervals whose two ends only move forward, so two 5p flanks that
+// share a 3p flank share it with every 5p flank between them.  A stretch of the list therefore starts a new COMPONENT exactly
+// where the 5p flank changes and its first 3p row lies behind the previous candidate's 3p row.  Inside a component the
+// outcome depends only on the order of ITS candidates in the stable sort by (IR_length desc, diffcount asc, difflength asc) =
+// order by (key, candidate index).  One thread per component: pick the best candidate not yet decided, keep it if both its
+// flanks are free, until none is left (components are a handful of candidates; quadratic in their size).
+// state[c]: 1 kept, 2 excluded; kflag[c] = kept.
+__global__ void k_assign_seg(const uint64_t *keys, const uint32_t *c5, const uint32_t *c3, uint32_t n, uint8_t *used5, uint8_t *used3, uint8_t *state, uint32_t *kflag) {
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    if (p && !(c5[p] != c5[p - 1] && c3[p - 1] < c3[p])) return;   // not the first candidate of a component
+    uint32_t e = p + 1;
+    while (e < n && !(c5[e] != c5[e - 1] && c3[e - 1] < c3[e])) e++;
+    for (uint32_t q = p; q < e; q++) state[q] = 0;
+    for (uint32_t left = e - p; left; left--) {
+        uint32_t best = p; uint64_t bk = ~0ull; bool have = false;
+        for (uint32_t q = p; q < e; q++) {
+            if (state[q]) continue;
+            const uint64_t k = keys[q];
+            if (!have || k < bk) { have = true; bk = k; best = q; }   // ties: the earlier candidate (stable sort)
+        }
+        const uint32_t a = c5[best], b = c3[best];
+        if (used5[a] || used3[b]) state[best] = 2;
+        else { state[best] = 1; used5[a] = 1; used3[b] = 1; }
+    }
+    for (uint32_t q = p; q < e; q++) kflag[q] = state[q] == 1 ? 1u : 0u;
+}
+
+// its kept pairs -> keys for sort_values(['contig','pos_5p','pos_3p']) (candidate order instead of k_assign's sorted order)
+__global__ void k_kept_keys_seg(FlankDev F, const uint32_t *c5, const uint32_t *c3, const uint32_t *kflag, const uint32_t *scan, uint32_t n,
+                                const int32_t *contig_rank, uint64_t *keys, uint32_t *vals) {
+    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n || !kflag[c]) return;
+    const uint32_t a = c5[c], b = c3[c], o = scan[c];
+    uint32_t diff = (uint32_t)(F.pos[a] - F.pos[b]);
+    if (diff > 0xFFFF) diff = 0xFFFF;
+    keys[o] = ((uint64_t)(uint32_t)contig_rank[F.contig[a]] << 48) | ((uint64_t)(uint32_t)(F.pos[a] + 1) << 16) | (uint64_t)(0xFFFFu - diff);
+    vals[o] = c;
+}
+
 // kept pairs in sorted_pairs order -> keys for sort_values(['contig','pos_5p','pos_3p']) (pairflanks.py:248)
 __global__ void k_kept_keys(FlankDev F, const uint32_t *order, const uint32_t *c5, const uint32_t *c3, const uint8_t *state, const uint32_t *scan, uint32_t n,
                             const int32_t *contig_rank, uint64_t *keys, uint32_t *vals) {
@@ -901,7 +944,7 @@ int pairflanks_impl(mfk_ctx *ctx, const mfk_reads *reads, const mfk_params *para
         uint64_t *keys = aalloc<uint64_t>(ctx, nP), *keys2 = aalloc<uint64_t>(ctx, nP), *kk2 = aalloc<uint64_t>(ctx, nP), *kk = nullptr;
         uint32_t *vals = aalloc<uint32_t>(ctx, nP), *order = aalloc<uint32_t>(ctx, nP);
         uint32_t *best5 = aalloc<uint32_t>(ctx, nF), *best3 = aalloc<uint32_t>(ctx, nF);
-        uint8_t *used5 = aalloc<uint8_t>(ctx, nF), *used3 = aalloc<uint8_t>(ctx, nF), *state = aalloc<uint8_t>(ctx, nP);
+        uint8_t *used5 = nullptr, *used3 = nullptr, *state = aalloc<uint8_t>(ctx, nP);   // used5 / used3: zero-filled below (k_assign_seg takes them as they are)
         uint32_t *kflag = aalloc<uint32_t>(ctx, nP), *kscan = aalloc<uint32_t>(ctx, (size_t)nP + 1), *jscan = aalloc<uint32_t>(ctx, (size_t)nP + 1);
         uint32_t *kept = aalloc<uint32_t>(ctx, nP), *spanning = aalloc<uint32_t>(ctx, nP), *span_all = aalloc<uint32_t>(ctx, nP);
         uint32_t *fin = aalloc<uint32_t>(ctx, nP), *fin_span = aalloc<uint32_t>(ctx, nP);
@@ -921,10 +964,10 @@ int pairflanks_impl(mfk_ctx *ctx, const mfk_reads *reads, const mfk_params *para
             if (dr_split < 1) dr_split = 1;
         }
         FillGroup z(ctx, 0), f(ctx, 0xFF);
-        z.want(&d_pstats, MFK_N_STATS); z.want(&kv, nP); z.want(&jflag, nP); z.want(&dr, (size_t)nP * stride);
+        z.want(&d_pstats, MFK_N_STATS); z.want(&kv, nP); z.want(&jflag, nP); z.want(&dr, (size_t)nP * stride); z.want(&used5, nF); z.want(&used3, nF);
         f.want(&kk, nP);   // unused sort keys stay ~0 and sort behind the kept pairs
         if (dr_split > 1) { z.want(&g_sum, (size_t)nP * DR_ACC); z.want(&g_err, nP); f.want(&g_first, (size_t)nP * DR_ACC); }
-        if (!c5 || !c3 || !ir || !keys || !keys2 || !kk2 || !vals || !order || !best5 || !best3 || !used5 || !used3 || !state || !kflag || !kscan || !jscan ||
+        if (!c5 || !c3 || !ir || !keys || !keys2 || !kk2 || !vals || !order || !best5 || !best3 || !state || !kflag || !kscan || !jscan ||
             !kept || !spanning || !span_all || !fin || !fin_span || !meta || fill_commit2(z, f)) return 1;
         const unsigned pb = nblocks(nP, 256);
         if (!host_pairs) {
@@ -992,12 +1035,22 @@ int pairflanks_impl(mfk_ctx *ctx, const mfk_reads *reads, const mfk_params *para
                         (const uint32_t *)span_all, fin, fin_span, jscan + nP, d_pstats);
             KCHK();
         } else {
+        const char *na_env = getenv("MFK_NO_SEG_ASSIGN");   // test hook: the sort + one-workgroup rounds for a sorted table too
+        if (sorted && !(na_env && *na_env && *na_env != '0')) {
+            // (used5 / used3 start at zero: part of the zero-filled block above)
+            PROF_LAUNCH(k_assign_seg, dim3(pb), dim3(256), 0, st, (const uint64_t *)keys, (const uint32_t *)c5, (const uint32_t *)c3, nP, used5, used3, state, kflag);
+            KCHK();
+            if (int rc = dev_excl_scan32(ctx, kflag, kscan, nP)) return rc;
+            PROF_LAUNCH(k_kept_keys_seg, dim3(pb), dim3(256), 0, st, F, (const uint32_t *)c5, (const uint32_t *)c3, (const uint32_t *)kflag, (const uint32_t *)kscan, nP, (const int32_t *)d_rank, kk, kv);
+            KCHK();
+        } else {
         if (int rc = dev_sort_pairs64(ctx, keys, keys2, vals, order, nP, 0, 56)) return rc;
         PROF_LAUNCH(k_assign, dim3(1), dim3(1024), 0, st, (const uint32_t *)order, (const uint32_t *)c5, (const uint32_t *)c3, nP, nF, best5, best3, used5, used3, state, kflag);
         KCHK();
         if (int rc = dev_excl_scan32(ctx, kflag, kscan, nP)) return rc;
         PROF_LAUNCH(k_kept_keys, dim3(pb), dim3(256), 0, st, F, (const uint32_t *)order, (const uint32_t *)c5, (const uint32_t *)c3, (const uint8_t *)state, (const uint32_t *)kscan, nP, (const int32_t *)d_rank, kk, kv);
         KCHK();
+        }
         if (int rc = dev_sort_pairs64(ctx, kk, kk2, kv, kept, nP, 0, 64)) return rc;
         HIPCHK(hipStreamWaitEvent(st, ctx->ev_join, 0));
         HIPCHK(hipStreamWaitEvent(st, ctx->ev_join3, 0));

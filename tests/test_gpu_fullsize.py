@@ -220,6 +220,11 @@ def test_fused_call_hands_the_flank_table_over_on_the_device(hip, monkeypatch, p
         assert len(pf["pairs"]) > 2000
     if pf_kw.get("max_direct_repeat_length") == 0:
         assert len(pf["pairs"]) == 0 and len(ff["flanks"]) > 4000
+    # assign_pairs per component of candidates that share flanks (k_assign_seg) against the device-wide sort + one-workgroup rounds
+    monkeypatch.setenv("MFK_NO_SEG_ASSIGN", "1")
+    pf5 = hip.run_pairflanks(rd, params, ff["flanks"], ff["seqs"], ranks, gd, goff)
+    monkeypatch.delenv("MFK_NO_SEG_ASSIGN")
+    assert pf5["pairs"].tobytes() == pf["pairs"].tobytes() and pf5["strs"] == pf["strs"] and list(pf5["stats"][:5]) == list(pf["stats"][:5])
     # a second fused call right behind (the arena is reused): same again
     ff4, pf4 = hip.run_flankpairs(rd, params, ranks, gd, goff)
     assert ff4["flanks"].tobytes() == ff["flanks"].tobytes() and pf4["pairs"].tobytes() == pf["pairs"].tobytes() and pf4["strs"] == pf["strs"]
