@@ -2069,16 +2069,31 @@ int run_consensus(mfk_ctx *ctx, const DevReads &R, const DevParams &P, Consensus
             const uint32_t per_wg = (160u * 1024u / SJ_WAVES) & ~255u;
             const uint32_t rung[3] = {ctx->sj_static + 8192 < per_wg ? ((per_wg - ctx->sj_static) & ~255u) : 32 * 1024,
                                       ctx->sj_static + 8192 < 40960 ? ((40960 - ctx->sj_static) & ~255u) : 32 * 1024, lds1};
+            // When even a job of max_R words of max_len characters that are ALL leaves fits the last rung, every job is done after
+            // the last pass whatever the first one leaves over: the passes are queued back to back (a later pass returns at once
+            // where nothing is left to retry) and the read-back between them, which only decides whether to go on, is not needed.
+            // A shallow isolate (a hundred words per site-side) is that case; a 200x sample is not (its bound is above 128 KB although
+            // its jobs need 16-28 KB), there the outcome of a pass is read back as before.
+            bool sure = false;
+            if (hm.max_R <= SJ_MAX_R && hm.max_len <= SJ_MAX_LEN) {
+                const size_t Rm = hm.max_R, Lm = hm.max_len ? hm.max_len : 1, a16 = 15;
+                const size_t chars = (Rm * ((Lm + a16) & ~a16) + a16) & ~a16, adjb = (Rm * ((Rm + 31) / 32) * 4 + a16) & ~a16, bestb = (Lm + 1 + a16) & ~a16;
+                const size_t Mb = Rm * ((Rm + a16) & ~a16);
+                size_t x1 = ((Rm * Rm + a16) & ~a16) + 16 * Lm, x2 = 3072 + 64, x3 = 4 * ((Lm + 63) / 64) * 128;
+                const size_t X = x1 > x2 ? (x1 > x3 ? x1 : x3) : (x2 > x3 ? x2 : x3);
+                sure = chars + 4096 <= lds1 && chars + adjb + bestb + Mb + X + Rm * sizeof(WordSrc) + 256 <= lds1;
+            }
             for (int pass = 0; pass < 3; pass++) {
                 if (pass == 1 && rung[1] <= rung[0]) continue;   // the first rung already is four per CU
-                if (pass > 0) {
+                if (pass > 0 && !sure) {
                     if (!hm.n_retry) break;
                     HIPCHK(hipMemsetAsync(&meta->n_retry, 0, 4, st));
                 }
                 PROF_LAUNCH(k_job_small, dim3(J.n), dim3(SJ_THREADS), rung[pass], st, R, P, W, J, io, meta, rung[pass], pass, fused ? 1 : 0);
                 KCHK();
-                if (int rc = read_back(ctx, meta, &hm, sizeof hm)) return rc;
+                if (!sure) { if (int rc = read_back(ctx, meta, &hm, sizeof hm)) return rc; }
             }
+            if (sure) { hm.n_big = 0; io.sure_small = true; }   // (checked with the results: meta->n_big comes back beside the error word)
         }
     }
     if (!hm.n_big) return 0;

@@ -1006,7 +1006,7 @@ int findflanks_impl(mfk_ctx *ctx, const mfk_reads *reads, const mfk_params *para
         fh->active = true; fh->n_act = n_act;
         fh->d_sites = d_sites; fh->d_flanks = d_flanks; fh->d_seqs = d_seqs;
         fh->d_rows_total = o_rows + n_act; fh->d_bytes_total = o_bytes + n_act;
-        fh->d_stats = d_stats; fh->d_cons_err = io.err_dev;
+        fh->d_stats = d_stats; fh->d_cons_err = io.err_dev; fh->sure_small = io.sure_small;
         ht.lap("rows handed over on the device");
         return 0;
     }
@@ -1019,10 +1019,12 @@ int findflanks_impl(mfk_ctx *ctx, const mfk_reads *reads, const mfk_params *para
             ReadBatch rb(ctx);
             rb.add(d_stats, h_stats, sizeof h_stats);
             rb.add(ctx->scan_err, &h_scan_err, 4);
-            if (io.err_dev) rb.add(io.err_dev, &io.err_flags, 4);
+            if (io.err_dev) rb.add(io.err_dev, io.err_words, 16);
             rb.add(o_rows + n_act, &t_rows, 8); rb.add(o_bytes + n_act, &t_bytes, 8);
             if (int rc = rb.flush()) return rc;
         }
+        io.err_flags = io.err_words[0];
+        if (io.sure_small && io.err_words[3]) { snprintf(ctx->err, sizeof ctx->err, "internal: a consensus job did not finish in k_job_small although its size bound said it would"); return 11; }
         if (int rc = check_scan_error(ctx, h_scan_err)) return rc;
         if (io.err_flags & 2u) { snprintf(ctx->err, sizeof ctx->err, "a clipped read at a surviving site has no sequence in the pool (pack with pool='clipped')"); return 2; }
         const size_t ns = (size_t)(t_rows & 0xFFFFFFull), nf = (size_t)(t_rows >> 24);
@@ -1048,7 +1050,7 @@ int findflanks_impl(mfk_ctx *ctx, const mfk_reads *reads, const mfk_params *para
         ReadBatch rb(ctx);
         rb.add(d_stats, h_stats, sizeof h_stats);
         rb.add(ctx->scan_err, &h_scan_err, 4);
-        if (io.err_dev) rb.add(io.err_dev, &io.err_flags, 4);
+        if (io.err_dev) rb.add(io.err_dev, io.err_words, 16);
         if (n_act > 0) {
             rb.add(A.gpos, gpos.data(), n_act * 4); rb.add(A.contig, contig.data(), n_act * 4);
             rb.add(A.cnt2, cnt2.data(), 2 * (size_t)n_act * 4); rb.add(A.st, stv.data(), n_act * 4);
@@ -1063,6 +1065,8 @@ int findflanks_impl(mfk_ctx *ctx, const mfk_reads *reads, const mfk_params *para
         if (int rc = rb.flush()) return rc;
     }
     ht.lap("results read-back");
+    io.err_flags = io.err_words[0];
+    if (io.sure_small && io.err_words[3]) { snprintf(ctx->err, sizeof ctx->err, "internal: a consensus job did not finish in k_job_small although its size bound said it would"); return 11; }
     if (int rc = check_scan_error(ctx, h_scan_err)) return rc;
     for (int i = 0; i < 10; i++) ctx->stats[i] = h_stats[i];
     ctx->stats[12] = (int64_t)((uint64_t)h_stats[12] | ((uint64_t)h_stats[13] << 32));

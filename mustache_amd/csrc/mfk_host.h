@@ -176,7 +176,8 @@ struct FlankHandoff {
     const uint64_t *d_rows_total;      // site rows | flank rows << 24
     const uint64_t *d_bytes_total;     // consensus characters
     const uint32_t *d_stats;           // MFK_N_STATS counters of the findflanks kernels
-    const uint32_t *d_cons_err;        // error word of the consensus stage (may be null)
+    const uint32_t *d_cons_err;        // error word of the consensus stage (may be null); 4 words: err, max_len, max_R, n_big
+    bool sure_small;                   // n_big must come back 0 (ConsensusIO::sure_small)
 };
 int findflanks_impl(mfk_ctx *ctx, const mfk_reads *reads, const mfk_params *params, int stop_after, int64_t *n_sites_out, int64_t *n_flanks_out, int64_t *seq_bytes_out, FlankHandoff *fh);
 int pairflanks_impl(mfk_ctx *ctx, const mfk_reads *reads, const mfk_params *params, const mfk_flank *flanks, const char *flank_seqs, int64_t n_flanks,
@@ -194,7 +195,8 @@ struct ConsensusIO {
     // outputs, indexed by job = 2*k + side (side 0 = 5p, 1 = 3p)
     int32_t *cons_count, *cons_len; uint32_t *n_pass_len, *n_pass_both;
     char *cons_chars; uint32_t cons_stride;
-    const uint32_t *err_dev; uint32_t err_flags;   // device error word of the consensus stage, read back with the results
+    const uint32_t *err_dev; uint32_t err_flags;   // device error word of the consensus stage, read back with the results (4 words: err, max_len, max_R, n_big)
+    uint32_t err_words[4]; bool sure_small;        // sure_small: k_job_small was queued without reading its outcome back; n_big must come back 0
     unsigned long long *work;                      // device counter: columns x limbs of the edit-distance recurrences run (stats[12])
 };
 int run_consensus(mfk_ctx *ctx, const DevReads &R, const DevParams &P, ConsensusIO &io);

@@ -914,16 +914,17 @@ int pairflanks_impl(mfk_ctx *ctx, const mfk_reads *reads, const mfk_params *para
         if (!dev_in) { if (int rc = read_back(ctx, coff + nF, &nP, 4)) return rc; }
         else {
             // one read-back for the candidate count and for everything findflanks would have read back by now
-            uint32_t f_stats[MFK_N_STATS], f_scan_err = 0, f_cons_err = 0; uint64_t t_rows = 0, t_bytes = 0;
+            uint32_t f_stats[MFK_N_STATS], f_scan_err = 0, f_cons[4] = {0, 0, 0, 0}; uint64_t t_rows = 0, t_bytes = 0;
             {
                 ReadBatch rb(ctx);
                 rb.add(coff + nF, &nP, 4); rb.add(fh->d_stats, f_stats, sizeof f_stats); rb.add(ctx->scan_err, &f_scan_err, 4);
-                if (fh->d_cons_err) rb.add(fh->d_cons_err, &f_cons_err, 4);
+                if (fh->d_cons_err) rb.add(fh->d_cons_err, f_cons, 16);
                 rb.add(fh->d_rows_total, &t_rows, 8); rb.add(fh->d_bytes_total, &t_bytes, 8);
                 if (int rc = rb.flush()) return rc;
             }
             if (int rc = check_scan_error(ctx, f_scan_err)) return rc;
-            if (f_cons_err & 2u) { snprintf(ctx->err, sizeof ctx->err, "a clipped read at a surviving site has no sequence in the pool (pack with pool='clipped')"); return 2; }
+            if (fh->sure_small && f_cons[3]) { snprintf(ctx->err, sizeof ctx->err, "internal: a consensus job did not finish in k_job_small although its size bound said it would"); return 11; }
+            if (f_cons[0] & 2u) { snprintf(ctx->err, sizeof ctx->err, "a clipped read at a surviving site has no sequence in the pool (pack with pool='clipped')"); return 2; }
             ff_ns = (size_t)(t_rows & 0xFFFFFFull); ff_nf = (size_t)(t_rows >> 24); ff_nb = (size_t)t_bytes;
             ctx->sites.resize(ff_ns); ctx->flanks.resize(ff_nf); ctx->seqs.resize(ff_nb);
             ff_pending = true;
