@@ -34,6 +34,18 @@ extern "C" {
 #define MFK_FLAG_COMPLEX 16             /* more than one aligned block: see cx_ / blk_ tables            */
 #define MFK_FLAG_POOL 32                /* query sequence + qualities are in the pool                     */
 
+/* One lenient-clipped read (flags & 15 != 0) as findflanks' event kernel wants it: the fields of the nine columns it
+ * would otherwise gather one sparse 64-byte sector at a time, in 16 bytes.  Optional, see mfk_reads.clip_rec. */
+typedef struct mfk_clip_rec {
+    uint32_t read;                 /* index of the read in the columns                                   */
+    int32_t ref_start, ref_end;
+    uint16_t contig_id;
+    uint8_t mapq;
+    uint8_t inner;                 /* min(255, qlen - left clip length - right clip length) when both ends are
+                                      clipped (sctools.py:166-180, lengths as in sctools.py:111-142), else 255 */
+} mfk_clip_rec;
+#define MFK_CLIP_TILE 4096         /* reads per entry of mfk_reads.clip_tile                             */
+
 /* Packed alignments, coordinate-sorted, 22 bytes per read in nine SoA columns (see DESIGN.md "Data layout"). */
 typedef struct mfk_reads {
     int64_t n_reads;
@@ -64,6 +76,13 @@ typedef struct mfk_reads {
     const uint8_t *pool_bases;     /* 4-bit BAM base codes "=ACMGRSVTWYHKDBN", base k in byte k>>1, even k in the high
                                       nibble (the BAM seq encoding)                                      */
     const uint8_t *pool_quals;     /* one byte per base                                                  */
+    /* Optional dense copy of the clipped reads (has no counterpart in the reference; clip_rec == NULL = columns only,
+     * same results).  mfk_findflanks / mfk_flankpairs / mfk_count_* read it instead of gathering the columns.  The
+     * caller guarantees that it restates the columns: record k is the k-th read with flags & 15 != 0.               */
+    int64_t n_clip;                /* number of reads with flags & 15 != 0                               */
+    const mfk_clip_rec *clip_rec;  /* DEVICE, n_clip records in read order, 16-byte aligned; or NULL      */
+    const uint32_t *clip_tile;     /* DEVICE, (n_reads + 4095) / 4096 + 1 entries: clip_tile[t] = number of such reads
+                                      among reads [0, 4096 t)                                            */
 } mfk_reads;
 
 /* CLI parameters of both commands (mustache/main.py:68-78, 102-107). */

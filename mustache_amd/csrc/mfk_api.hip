@@ -426,6 +426,12 @@ int prepare_reads(mfk_ctx *ctx, const mfk_reads *in, const mfk_params *pr, DevRe
     R->blk_start = in->blk_start; R->blk_end = in->blk_end; R->blk_ins = in->blk_ins;
     R->n_pool = in->n_pool; R->pool_read = in->pool_read; R->pool_off = in->pool_off;
     R->pool_bases = in->pool_bases; R->pool_quals = in->pool_quals;
+    R->n_clip = 0; R->clip_rec = nullptr; R->clip_tile = nullptr;
+    if (in->clip_rec) {
+        if (!in->clip_tile || in->n_clip < 0 || in->n_clip > in->n_reads) { snprintf(ctx->err, sizeof ctx->err, "clip_rec needs clip_tile and 0 <= n_clip <= n_reads (got n_clip %lld)", (long long)in->n_clip); return 1; }
+        if (((uintptr_t)in->clip_rec & 15) != 0) { snprintf(ctx->err, sizeof ctx->err, "clip_rec must be 16-byte aligned"); return 1; }
+        R->n_clip = in->n_clip; R->clip_rec = in->clip_rec; R->clip_tile = in->clip_tile;
+    }
     const int nc = in->n_contigs;
     int64_t pad = (int64_t)pr->min_distance_to_mate + pr->max_direct_repeat_length + 64;
     if (pad < 64) pad = 64;

@@ -27,6 +27,9 @@ struct DevReads {
     const uint32_t *pool_read;
     const uint64_t *pool_off;
     const uint8_t *pool_bases, *pool_quals;
+    int64_t n_clip;                  // optional dense records of the clipped reads (mfk.h mfk_clip_rec), or clip_rec == nullptr
+    const mfk_clip_rec *clip_rec;
+    const uint32_t *clip_tile;
 };
 
 struct DevParams {

@@ -50,7 +50,9 @@ __device__ __forceinline__ uint4 d_load_flags16(const DevReads &R, int64_t g, in
     return v;
 }
 
-// list entry: read index | flags << 32.  The list has LIST_SEGS segments of seg_cap entries, each with its own counter
+// list entry: read index | flags << 32; with the packer's dense clip records (mfk_reads.clip_rec) the low word is the
+// read's index in THAT table instead: clip_tile[tile] clipped reads lie before this 4096-read tile, and the in-tile prefix
+// sum that places the entries is also the read's rank among the tile's clipped reads.  The list has LIST_SEGS segments of seg_cap entries, each with its own counter
 // (a cache line apart): a workgroup reserves room with one atomic per tile, and thousands of those on ONE address would
 // serialise in the L2 and cost more than the whole stream.
 #define LIST_SEGS 64
@@ -82,6 +84,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_clips(DevReads R, uint64_
         uint32_t slot = block_excl_scan(__popc(cmap), sh, &total);
         if (total) {   // block-uniform
             if (threadIdx.x == 0) s_base = atomicAdd(&seg_count[seg * SEG_PAD], total);
+            uint32_t ci = R.clip_rec ? R.clip_tile[tile] + slot : 0;
             __syncthreads();
             slot += s_base;
             const uint64_t lo = (uint64_t)v.x | ((uint64_t)v.y << 32), hi = (uint64_t)v.z | ((uint64_t)v.w << 32);
@@ -89,12 +92,50 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_clips(DevReads R, uint64_
                 const int k = __builtin_ctz(cmap);
                 cmap &= cmap - 1;
                 const uint64_t f = ((k < 8 ? lo : hi) >> ((k & 7) * 8)) & 0xFF;
-                if (slot < seg_cap) list[slot] = (uint64_t)(r0 + k) | (f << 32);
-                slot++;
+                if (slot < seg_cap) list[slot] = (R.clip_rec ? (uint64_t)ci : (uint64_t)(r0 + k)) | (f << 32);
+                slot++; ci++;
             }
         }
         __syncthreads();   // s_base / sh are reused by the next tile
     }
+}
+
+// What k_clip_events / k_clip_events_bkt need of one listed read.  Two sources with the same content: the SoA columns (one
+// sparse gather per column and read: every one costs a whole 64-byte sector of HBM traffic) or, when the caller passed
+// them, the packer's dense 16-byte clip records (four to a sector, neighbours in the list are neighbours in the table).
+struct ClipFields { uint32_t r, base; int32_t rs, re; int mq; bool ok, ial_bad; };
+__device__ __forceinline__ ClipFields d_clip_fields(const DevReads &R, const DevParams &P, uint64_t e, int lk, int rk) {
+    ClipFields c;
+    const bool both = lk && rk;
+    c.ok = true;
+    if (R.clip_rec) {
+        const uint32_t ci = (uint32_t)e;
+        c.ok = (int64_t)ci < R.n_clip;
+        const uint4 q = c.ok ? reinterpret_cast<const uint4 *>(R.clip_rec)[ci] : make_uint4(0, 0, 0, 0);
+        c.r = q.x; c.rs = (int32_t)q.y; c.re = (int32_t)q.z; c.mq = (int)((q.w >> 16) & 0xFF);
+        const uint32_t cid = q.w & 0xFFFFu;
+        c.ok = c.ok && cid < (uint32_t)R.n_contigs && (int64_t)c.r < R.n;
+        c.base = c.ok ? R.contig_base[cid] : 0;
+        c.ial_bad = false;
+        if (both && c.ok) {
+            if (P.minial <= 255) c.ial_bad = (int)(q.w >> 24) < P.minial;   // the record holds min(inner length, 255)
+            else {
+                const int fo = R.first_op_len[c.r], lo = R.last_op_len[c.r];
+                c.ial_bad = (int)R.qlen[c.r] - (rk == 1 ? lo : 1) - (lk == 1 ? fo : 1) < P.minial;
+            }
+        }
+        return c;
+    }
+    const int64_t r = (int64_t)(e & 0x7fffffffu);
+    c.r = (uint32_t)r;
+    // Only the columns this read's clip kinds need, all issued together: none of these loads depends on another
+    c.mq = R.mapq[r];
+    const int ql = both ? R.qlen[r] : 0, fo = both ? R.first_op_len[r] : 0, lo = both ? R.last_op_len[r] : 0;
+    c.rs = lk ? R.ref_start[r] : 0; c.re = rk ? R.ref_end[r] : 0;
+    c.base = R.contig_base[R.contig_id[r]];
+    const int llen = lk == 1 ? fo : (lk == 2 ? 1 : 0), rlen = rk == 1 ? lo : (rk == 2 ? 1 : 0);   // d_llen / d_rlen
+    c.ial_bad = both && ql - rlen - llen < P.minial;                                               // d_passes
+    return c;
 }
 
 // grid (x, LIST_SEGS): workgroup (x, seg) takes every gridDim.x-th 256-entry slice of list segment seg
@@ -111,25 +152,17 @@ __global__ __launch_bounds__(256) void k_clip_events(DevReads R, DevParams P, co
         const uint32_t i = b0 + threadIdx.x;
         if (i < n) {
             const uint64_t e = list[i];
-            const int64_t r = (int64_t)(e & 0x7fffffffu);
             const uint8_t f = (uint8_t)(e >> 32);
-            // Only the columns this read's clip kinds need (every column touched costs a whole cache line of HBM traffic
-            // for one sparse read), all issued together: none of these loads depends on another
             const int lk = d_lkind(f), rk = d_rkind(f);
-            const bool both = lk && rk;
-            const int mq = R.mapq[r];
-            const int ql = both ? R.qlen[r] : 0, fo = both ? R.first_op_len[r] : 0, lo = both ? R.last_op_len[r] : 0;
-            const int32_t rs = lk ? R.ref_start[r] : 0, re = rk ? R.ref_end[r] : 0;
-            const uint32_t base = R.contig_base[R.contig_id[r]];
-            const int llen = lk == 1 ? fo : (lk == 2 ? 1 : 0), rlen = rk == 1 ? lo : (rk == 2 ? 1 : 0);   // d_llen / d_rlen
-            if (mq >= P.minq && !(both && ql - rlen - llen < P.minial)) {                               // d_passes
+            const ClipFields c = d_clip_fields(R, P, e, lk, rk);
+            if (c.ok && c.mq >= P.minq && !c.ial_bad) {                                                   // d_passes
                 if (rk) {   // right clip -> 5p site (findflanks.py:117-118, 594-597); d_rsite
-                    const int32_t site = rk == 1 ? re : re - 1;
-                    stage[atomicAdd(&s_n, 1u)] = ((uint64_t)(base + (uint32_t)(site + 1)) << 32) | (uint64_t)(uint32_t)r;
+                    const int32_t site = rk == 1 ? c.re : c.re - 1;
+                    stage[atomicAdd(&s_n, 1u)] = ((uint64_t)(c.base + (uint32_t)(site + 1)) << 32) | (uint64_t)c.r;
                 }
                 if (lk) {   // left clip -> 3p site (findflanks.py:120-121, 599-602); d_lsite
-                    const int32_t site = lk == 1 ? rs - 1 : rs;
-                    stage[atomicAdd(&s_n, 1u)] = ((uint64_t)(base + (uint32_t)(site + 1)) << 32) | (1ull << 31) | (uint64_t)(uint32_t)r;
+                    const int32_t site = lk == 1 ? c.rs - 1 : c.rs;
+                    stage[atomicAdd(&s_n, 1u)] = ((uint64_t)(c.base + (uint32_t)(site + 1)) << 32) | (1ull << 31) | (uint64_t)c.r;
                 }
             }
         }
@@ -193,18 +226,12 @@ __global__ __launch_bounds__(256) void k_clip_events_bkt(DevReads R, DevParams P
         bool h5 = false, h3 = false;
         if (i < n) {
             const uint64_t e = list[i];
-            const int64_t r = (int64_t)(e & 0x7fffffffu);
             const uint8_t f = (uint8_t)(e >> 32);
             const int lk = d_lkind(f), rk = d_rkind(f);
-            const bool both = lk && rk;
-            const int mq = R.mapq[r];
-            const int ql = both ? R.qlen[r] : 0, fo = both ? R.first_op_len[r] : 0, lo = both ? R.last_op_len[r] : 0;
-            const int32_t rs = lk ? R.ref_start[r] : 0, re = rk ? R.ref_end[r] : 0;
-            const uint32_t base = R.contig_base[R.contig_id[r]];
-            const int llen = lk == 1 ? fo : (lk == 2 ? 1 : 0), rlen = rk == 1 ? lo : (rk == 2 ? 1 : 0);
-            if (mq >= P.minq && !(both && ql - rlen - llen < P.minial)) {
-                if (rk) { const int32_t site = rk == 1 ? re : re - 1; k5 = ((uint64_t)(base + (uint32_t)(site + 1)) << 32) | (uint64_t)(uint32_t)r; h5 = true; }
-                if (lk) { const int32_t site = lk == 1 ? rs - 1 : rs; k3 = ((uint64_t)(base + (uint32_t)(site + 1)) << 32) | (1ull << 31) | (uint64_t)(uint32_t)r; h3 = true; }
+            const ClipFields c = d_clip_fields(R, P, e, lk, rk);
+            if (c.ok && c.mq >= P.minq && !c.ial_bad) {
+                if (rk) { const int32_t site = rk == 1 ? c.re : c.re - 1; k5 = ((uint64_t)(c.base + (uint32_t)(site + 1)) << 32) | (uint64_t)c.r; h5 = true; }
+                if (lk) { const int32_t site = lk == 1 ? c.rs - 1 : c.rs; k3 = ((uint64_t)(c.base + (uint32_t)(site + 1)) << 32) | (1ull << 31) | (uint64_t)c.r; h3 = true; }
             }
         }
         // bucket = position range of the flat axis

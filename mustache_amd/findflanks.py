@@ -50,9 +50,11 @@ def index_path(table_file, enabled=True):
     return str(table_file) + ".mfki"
 
 
-def device_reads(binding, packed: PackedReads, device):
-    """Move a PackedReads to ``device`` and describe it to the library."""
-    tensors = packed.to_torch(device)
+def device_reads(binding, packed: PackedReads, device, clip_rec=True):
+    """Move a PackedReads to ``device`` and describe it to the library.  clip_rec: attach the dense clip records
+    (``PackedReads.clip_records``, include/mfk.h mfk_clip_rec): worth their one host pass when the reads stay resident for
+    more than one call; the one-shot commands, whose time is the decode, leave them out."""
+    tensors = packed.to_torch(device, clip_rec=clip_rec)
     return binding.reads_struct(tensors, packed.n_reads, packed.max_span, _lib.host_header(packed))
 
 
@@ -133,7 +135,7 @@ def _findflanks(bamfile, min_softclip_length, min_softclip_count, min_alignment_
                 st["seconds_total"], st["n_threads"], st["seconds_inflate"], st["seconds_parse"], st["seconds_link"],
                 st["n_records"] / max(st["seconds_total"], 1e-9) / 1e6))
     t1 = time.perf_counter()
-    rs = device_reads(binding, packed, device)
+    rs = device_reads(binding, packed, device, clip_rec=False)
     if str(device).startswith("cuda"):
         import torch
         torch.cuda.synchronize()

@@ -28,7 +28,8 @@ class MfkReads(C.Structure):
                 ("h_contig_len", _p), ("h_contig_read_start", _p),
                 ("n_cx", C.c_int64), ("cx_read", _p), ("cx_off", _p),
                 ("n_blk", C.c_int64), ("blk_start", _p), ("blk_end", _p), ("blk_ins", _p),
-                ("n_pool", C.c_int64), ("pool_read", _p), ("pool_off", _p), ("pool_bases", _p), ("pool_quals", _p)]
+                ("n_pool", C.c_int64), ("pool_read", _p), ("pool_off", _p), ("pool_bases", _p), ("pool_quals", _p),
+                ("n_clip", C.c_int64), ("clip_rec", _p), ("clip_tile", _p)]
 
 
 class MfkParams(C.Structure):
@@ -188,6 +189,9 @@ class Binding:
         r.n_cx = int(host_hdr["n_cx"])
         r.n_blk = int(host_hdr["n_blk"])
         r.n_pool = int(host_hdr["n_pool"])
+        if arrays.get("clip_rec") is not None:     # optional dense records of the clipped reads (pack.PackedReads.clip_records)
+            r.n_clip = int(arrays["n_clip"])
+            r.clip_rec, r.clip_tile = _ptr(arrays["clip_rec"]), _ptr(arrays["clip_tile"])
         r._keep = (arrays, clen, crs)
         return r
 

@@ -30,6 +30,8 @@ that need them (clipped reads for findflanks; reads over direct-repeat windows f
 """
 from __future__ import annotations
 
+import os
+
 import numpy as np
 
 from .records import (CDEL, CDIFF, CEQUAL, CHARD_CLIP, CINS, CMATCH, CPAD, CREF_SKIP, CSOFT_CLIP, BASE_TO_CODE)
@@ -47,6 +49,10 @@ _SIDE_FIELDS = (("contig_len", np.int32), ("contig_read_start", np.int64), ("cx_
                 ("pool_read", np.uint32), ("pool_off", np.uint64), ("pool_bases", np.uint8), ("pool_quals", np.uint8))
 ALL_FIELDS = _HOT_FIELDS + _SIDE_FIELDS
 BYTES_PER_READ = sum(np.dtype(t).itemsize for _, t in _HOT_FIELDS)  # 22
+# include/mfk.h mfk_clip_rec / MFK_CLIP_TILE
+CLIP_REC = np.dtype([("read", np.uint32), ("ref_start", np.int32), ("ref_end", np.int32), ("contig_id", np.uint16),
+                     ("mapq", np.uint8), ("inner", np.uint8)])
+CLIP_TILE = 4096
 
 
 class PackError(ValueError):
@@ -107,6 +113,34 @@ class PackedReads:
 
     def nbytes_hot(self):
         return self.n_reads * BYTES_PER_READ
+
+    def clip_records(self):
+        """(clip_rec, clip_tile) of include/mfk.h: the lenient-clipped reads (flags & 15, sctools.py:17-31) restated as
+        dense 16-byte records in read order, and the number of them before every 4096-read tile.  findflanks' event
+        kernel reads these instead of gathering nine columns for one read in seventy.  Derived from the columns alone,
+        so every producer of a PackedReads (both packers, slices, cohorts, the generator) gets the same table."""
+        got = self.__dict__.get("_clip")
+        if got is None:
+            a = self.a
+            f = a["flags"]
+            clipped = (f & 15) != 0
+            idx = np.flatnonzero(clipped)
+            rec = np.zeros(idx.shape[0], dtype=CLIP_REC)
+            rec["read"] = idx
+            for k in ("ref_start", "ref_end", "contig_id", "mapq"):
+                rec[k] = a[k][idx]
+            fl = f[idx]
+            lk, rk = fl & 3, (fl >> 2) & 3
+            llen = np.where(lk == 1, a["first_op_len"][idx], 1).astype(np.int64)
+            rlen = np.where(rk == 1, a["last_op_len"][idx], 1).astype(np.int64)
+            inner = np.clip(a["qlen"][idx].astype(np.int64) - llen - rlen, 0, 255)
+            rec["inner"] = np.where((lk != 0) & (rk != 0), inner, 255)
+            n = self.n_reads
+            per_tile = np.add.reduceat(clipped.astype(np.uint32), np.arange(0, n, CLIP_TILE)) if n else np.zeros(0, np.uint32)
+            tile = np.zeros((n + CLIP_TILE - 1) // CLIP_TILE + 1, dtype=np.uint32)
+            np.cumsum(per_tile, out=tile[1:])
+            got = self.__dict__["_clip"] = (rec, tile)
+        return got
 
     def save(self, path):
         np.savez(path, contig_names=np.array(self.contig_names), max_span=np.int64(self.max_span), **self.a)
@@ -198,9 +232,17 @@ class PackedReads:
         nib = (self.a["pool_bases"][idx >> 1] >> ((~idx & 1) * 4)) & 15
         return "".join(BASE_CODES[c] for c in nib), [int(q) for q in self.a["pool_quals"][o0:o1]]
 
-    def to_torch(self, device):
+    def to_torch(self, device, clip_rec=True):
+        """Every array on ``device``.  clip_rec: also the dense clip records (``clip_records``); MFK_NO_CLIP_REC=1
+        leaves them out whatever the caller says (the library then gathers the columns: same results)."""
         import torch
         out = {}
+        if clip_rec and os.environ.get("MFK_NO_CLIP_REC", "0") in ("", "0"):
+            rec, tile = self.clip_records()
+            out["n_clip"] = int(rec.shape[0])
+            raw = rec.view(np.uint8) if rec.shape[0] else np.zeros(16, np.uint8)
+            out["clip_rec"] = torch.from_numpy(np.ascontiguousarray(raw)).to(device)
+            out["clip_tile"] = torch.from_numpy(tile.view(np.int32)).to(device)
         for k, _ in ALL_FIELDS:
             arr = np.ascontiguousarray(self.a[k])
             # torch has no uint16/32/64 arithmetic but can hold the bits; reinterpret as signed of the same width

@@ -216,7 +216,7 @@ def _pairflanks(flanksfile, bamfile, genome, max_direct_repeat_length, min_align
         else:
             raise ValueError("decoder must be 'native' or 'python', not %r" % (decoder,))
     t1 = time.perf_counter()
-    rs = device_reads(binding, packed, device)
+    rs = device_reads(binding, packed, device, clip_rec=False)
     gdev = torch.from_numpy(g).to(device)
     torch.cuda.synchronize()
     t2 = time.perf_counter()

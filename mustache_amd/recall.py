@@ -66,5 +66,5 @@ def _recall(pairsfile, bamfile, min_alignment_quality, min_alignment_inner_lengt
                               min_alignment_inner_length=min_alignment_inner_length,
                               large_insertion_cutoff=large_insertion_cutoff)
     packed = pack_bam(bamfile, pool="none")        # libmfkio.so: multi-threaded BGZF inflate + packing
-    rs = device_reads(binding, packed, device)
+    rs = device_reads(binding, packed, device, clip_rec=False)
     return recall_packed(binding, rs, packed.contig_names, params, pairs, output_file, verbose)

@@ -43,9 +43,9 @@ def test_oracle_exports_the_same_signatures(oracle):
 
 def test_struct_layouts(tmp_path):
     src = tmp_path / "sz.c"
-    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "%s"\nint main(){printf("%%zu %%zu %%zu %%zu %%zu %%zu %%zu\\n",'
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "%s"\nint main(){printf("%%zu %%zu %%zu %%zu %%zu %%zu %%zu %%zu %%zu\\n",'
                    'sizeof(mfk_reads),sizeof(mfk_params),sizeof(mfk_site),sizeof(mfk_flank),sizeof(mfk_pair),'
-                   'offsetof(mfk_flank,seq_off),offsetof(mfk_pair,ir5_off));return 0;}\n' % HEADER)
+                   'offsetof(mfk_flank,seq_off),offsetof(mfk_pair,ir5_off),sizeof(mfk_clip_rec),offsetof(mfk_reads,n_clip));return 0;}\n' % HEADER)
     exe = tmp_path / "sz"
     subprocess.check_call(["gcc", "-o", str(exe), str(src)])
     sizes = [int(x) for x in subprocess.check_output([str(exe)]).split()]
@@ -56,6 +56,9 @@ def test_struct_layouts(tmp_path):
     assert sizes[4] == lib.PAIR_DTYPE.itemsize
     assert sizes[5] == lib.FLANK_DTYPE.fields["seq_off"][1]
     assert sizes[6] == lib.PAIR_DTYPE.fields["ir5_off"][1]
+    from mustache_amd import pack
+    assert sizes[7] == pack.CLIP_REC.itemsize == 16
+    assert sizes[8] == lib.MfkReads.n_clip.offset       # the optional trailing fields sit where the old struct ended
 
 
 def test_product_fails_loudly_without_gpu():

@@ -228,3 +228,36 @@ def test_fused_call_hands_the_flank_table_over_on_the_device(hip, monkeypatch, p
     # a second fused call right behind (the arena is reused): same again
     ff4, pf4 = hip.run_flankpairs(rd, params, ranks, gd, goff)
     assert ff4["flanks"].tobytes() == ff["flanks"].tobytes() and pf4["pairs"].tobytes() == pf["pairs"].tobytes() and pf4["strs"] == pf["strs"]
+
+
+@pytest.mark.parametrize("name,seed,minial", [("tiny", 31, 21), ("C3_klebsiella", 32, 21), ("C2_saureus_1000x", 33, 21),
+                                              ("deep", 34, 21), ("C3_klebsiella", 35, 300), ("tiny", 36, 0)])
+def test_dense_clip_records_change_nothing(hip, name, seed, minial):
+    """include/mfk.h mfk_clip_rec: the optional dense copy of the clipped reads is a layout, not an input -- with it, without
+    it, and with -minial beyond what a record's `inner` byte holds (the kernel then takes the lengths from the columns)
+    every stage gives the same bytes."""
+    import torch
+    packed, genome, _ = synth_packed(**(DEEP if name == "deep" else CONFIGS[name]), seed=seed)
+    params = lib.make_params(min_alignment_inner_length=minial)
+    g, goff = pfh.genome_arrays(genome, packed.contig_names)
+    ranks = pfh.contig_ranks(packed.contig_names)
+    gd = torch.from_numpy(g).to("cuda:0")
+    with_rec, without = device_reads(hip, packed, "cuda:0"), device_reads(hip, packed, "cuda:0", clip_rec=False)
+    assert with_rec.clip_rec and with_rec.n_clip == int(np.count_nonzero(packed.a["flags"] & 15)) and not without.clip_rec
+    a, ap = hip.run_flankpairs(with_rec, params, ranks, gd, goff)
+    b, bp = hip.run_flankpairs(without, params, ranks, gd, goff)
+    _same(a["flanks"], b["flanks"], lib.FLANK_DTYPE)
+    assert a["seqs"] == b["seqs"] and list(a["stats"][:12]) == list(b["stats"][:12])
+    _same(ap["pairs"], bp["pairs"], lib.PAIR_DTYPE)
+    assert ap["strs"] == bp["strs"]
+    for stage in (1, 2):                                   # the unfiltered / filtered site tables too
+        sa, sb = hip.run_findflanks(with_rec, params, stop_after=stage), hip.run_findflanks(without, params, stop_after=stage)
+        _same(sa["sites"], sb["sites"], lib.SITE_DTYPE)
+
+
+def test_clip_records_without_their_tile_table_are_refused(hip):
+    packed, _, _ = synth_packed(**CONFIGS["tiny"], seed=37)
+    rd = device_reads(hip, packed, "cuda:0")
+    rd.clip_tile = None
+    with pytest.raises(lib.MfkError, match="clip_tile"):
+        hip.run_findflanks(rd, lib.make_params())

@@ -104,3 +104,34 @@ def test_candidate_regions_equal_the_per_flank_loop():
         got = pfh.candidate_regions(tab, maxdr, glen)
         assert got.dtype == np.int32 and got.shape[1] == 5
         assert set(map(tuple, got.tolist())) == want and (len(want) > 0 or maxdr == 0)
+
+
+def test_clip_records_restate_the_columns():
+    """PackedReads.clip_records (include/mfk.h mfk_clip_rec / clip_tile) against the per-read statement."""
+    from mustache_amd.synth import CONFIGS, synth_packed
+    from mustache_amd.pack import CLIP_TILE
+    cfg = dict(CONFIGS["tiny"])
+    cfg["contig_lens"] = (9000, 5000, 3000)
+    packed, _, _ = synth_packed(**cfg, seed=5)
+    a = packed.a
+    rec, tile = packed.clip_records()
+    want = [r for r in range(packed.n_reads) if a["flags"][r] & 15]
+    assert rec["read"].tolist() == want and len(want) > 50
+    assert tile.shape[0] == (packed.n_reads + CLIP_TILE - 1) // CLIP_TILE + 1
+    for t in range(tile.shape[0]):
+        assert tile[t] == sum(1 for r in want if r < t * CLIP_TILE)
+    both = 0
+    for k, r in enumerate(want):
+        f = int(a["flags"][r])
+        lk, rk = f & 3, (f >> 2) & 3
+        inner = 255
+        if lk and rk:
+            both += 1
+            inner = min(255, int(a["qlen"][r]) - (int(a["first_op_len"][r]) if lk == 1 else 1)
+                        - (int(a["last_op_len"][r]) if rk == 1 else 1))
+        assert (int(rec["ref_start"][k]), int(rec["ref_end"][k]), int(rec["contig_id"][k]), int(rec["mapq"][k]), int(rec["inner"][k])) == \
+            (int(a["ref_start"][r]), int(a["ref_end"][r]), int(a["contig_id"][r]), int(a["mapq"][r]), inner)
+    empty = packed.take_ranges([]) if hasattr(packed, "take_ranges") else None
+    if empty is not None:
+        r0, t0 = empty.clip_records()
+        assert r0.shape[0] == 0 and t0.tolist() == [0]
