@@ -5,6 +5,8 @@ What the reference does with three tools, here on the raw BAM records (every fie
 byte; nothing is decoded that does not have to be):
 
 1. ``samtools view -b -h -F 0x900`` (samtools.py:9-18): drop secondary (0x100) and supplementary (0x800) alignments.
+   The input may be BAM or SAM text (plain or gzip-compressed), as samtools detects it; SAM lines are encoded to BAM records
+   the way htslib does (smallest integer type for ``i`` tags).
    Without this step a chimeric read gives three or more alignments of one query name at one site-side and findflanks
    stops with its READ NUMBER ERROR (findflanks.py:971-978, quirk Q3).
 2. paired data (format_for_mustache, formatbam.py:19-59): consecutive records are mates; each mapped mate gets the
@@ -42,10 +44,19 @@ def log(msg):
 
 
 def read_raw_bam(path):
-    """(header text, contigs [(name, length)], list of raw record bodies without their block_size field)."""
+    """(header text, contigs [(name, length)], list of raw record bodies without their block_size field).
+
+    The reference's first step, ``samtools view -b -h -F 0x900 {in_sam}`` (samtools.py:10), takes SAM text as well as BAM
+    (the CLI argument is called in_sam): a file that does not start with the gzip magic is read as SAM text."""
+    with open(path, "rb") as fh:
+        magic = fh.read(2)
+    if magic != b"\x1f\x8b":
+        return read_sam_text(path)
     with gzip.open(path, "rb") as fh:          # BGZF is a series of gzip members
         data = fh.read()
     if data[:4] != b"BAM\1":
+        if data[:1] == b"@" or data.count(b"\t", 0, 4096) >= 10:      # gzip-compressed SAM text
+            return read_sam_text(path, data)
         raise ValueError("%s is not a BAM file" % path)
     l_text, = struct.unpack_from("<i", data, 4)
     text = data[8:8 + l_text].decode("ascii", "replace").rstrip("\0")
@@ -67,6 +78,133 @@ def read_raw_bam(path):
         records.append(data[o + 4:o + 4 + size])
         o += 4 + size
     return text, contigs, records
+
+
+_CIGAR_OPS = {c: k for k, c in enumerate("MIDNSHP=X")}
+_BASE_CODE = {c: k for k, c in enumerate("=ACMGRSVTWYHKDBN")}
+_B_SUB = {"c": "<b", "C": "<B", "s": "<h", "S": "<H", "i": "<i", "I": "<I", "f": "<f"}
+
+
+def _sam_int_tag(v):
+    """An integer tag as htslib stores it: the smallest type that holds the value (sam.c, aux 'i' parsing)."""
+    if v < 0:
+        if v >= -128:
+            return b"c" + struct.pack("<b", v)
+        if v >= -32768:
+            return b"s" + struct.pack("<h", v)
+        if v >= -(1 << 31):
+            return b"i" + struct.pack("<i", v)
+        raise ValueError("integer tag %d does not fit 32 bits" % v)
+    if v <= 0xFF:
+        return b"C" + struct.pack("<B", v)
+    if v <= 0xFFFF:
+        return b"S" + struct.pack("<H", v)
+    if v <= 0xFFFFFFFF:
+        return b"I" + struct.pack("<I", v)
+    raise ValueError("integer tag %d does not fit 32 bits" % v)
+
+
+def _sam_tag(field):
+    try:
+        tag, typ, val = field.split(":", 2)
+    except ValueError:
+        raise ValueError("bad SAM tag %r" % field)
+    if len(tag) != 2:
+        raise ValueError("bad SAM tag %r" % field)
+    t = tag.encode()
+    if typ == "i":
+        return t + _sam_int_tag(int(val))
+    if typ == "Z":
+        return t + b"Z" + val.encode() + b"\0"
+    if typ == "A":
+        return t + b"A" + val.encode()[:1]
+    if typ == "f":
+        return t + b"f" + struct.pack("<f", float(val))
+    if typ == "H":
+        return t + b"H" + val.encode() + b"\0"
+    if typ == "B":
+        sub, *items = val.split(",")
+        if sub not in _B_SUB:
+            raise ValueError("bad SAM tag %r" % field)
+        conv = float if sub == "f" else int
+        return t + b"B" + sub.encode() + struct.pack("<i", len(items)) + b"".join(struct.pack(_B_SUB[sub], conv(x)) for x in items)
+    raise ValueError("bad SAM tag type in %r" % field)
+
+
+def sam_line_to_record(line, contig_index):
+    """One SAM alignment line as a raw BAM record body (SAM specification 1.4 -> 4.2; what ``samtools view -b`` writes)."""
+    f = line.split("\t")
+    if len(f) < 11:
+        raise ValueError("SAM line with %d fields (11 are mandatory): %r" % (len(f), line[:80]))
+    qname, flag, rname, pos, mapq, cigar, rnext, pnext, tlen, seq, qual = f[:11]
+    flag, pos, mapq, pnext, tlen = int(flag), int(pos) - 1, int(mapq), int(pnext) - 1, int(tlen)
+
+    def ref_id(name, same):
+        if name == "*":
+            return -1
+        if name == "=":
+            return same
+        if name not in contig_index:
+            raise ValueError("reference %r of read %s is not in the @SQ lines" % (name, qname))
+        return contig_index[name]
+    rid = ref_id(rname, -1)
+    nid = ref_id(rnext, rid)
+    cig, end = [], pos
+    if cigar != "*":
+        num = 0
+        for ch in cigar:
+            if ch.isdigit():
+                num = num * 10 + ord(ch) - 48
+            else:
+                if ch not in _CIGAR_OPS:
+                    raise ValueError("bad CIGAR %r of read %s" % (cigar, qname))
+                op = _CIGAR_OPS[ch]
+                cig.append((num << 4) | op)
+                if op in _REF_CONSUMING:
+                    end += num
+                num = 0
+    if end <= pos or (flag & 4):
+        end = pos + 1
+    if seq == "*":
+        seq = ""
+    codes = [_BASE_CODE.get(c, 15) for c in seq.upper()]
+    if len(codes) & 1:
+        codes.append(0)
+    seqb = bytes((codes[i] << 4) | codes[i + 1] for i in range(0, len(codes), 2))
+    if qual == "*" or not seq:
+        qualb = b"\xff" * len(seq)
+    else:
+        if len(qual) != len(seq):
+            raise ValueError("SEQ and QUAL of read %s differ in length" % qname)
+        qualb = bytes(ord(c) - 33 for c in qual)
+    name = (qname if qname != "*" else "*").encode() + b"\0"
+    body = struct.pack("<iiBBHHHiiii", rid, pos, len(name), mapq, _reg2bin(pos, end), len(cig), flag, len(seq), nid, pnext, tlen)
+    return body + name + struct.pack("<%dI" % len(cig), *cig) + seqb + qualb + b"".join(_sam_tag(t) for t in f[11:])
+
+
+def read_sam_text(path, data=None):
+    """SAM text -> the same triple as ``read_raw_bam``."""
+    if data is None:
+        with open(path, "rb") as fh:
+            data = fh.read()
+    head, contigs, records, index = [], [], [], {}
+    for ln in data.decode("ascii", "replace").split("\n"):
+        ln = ln.rstrip("\r")
+        if not ln:
+            continue
+        if ln.startswith("@") and not records:
+            head.append(ln)
+            if ln.startswith("@SQ"):
+                kv = dict(x.split(":", 1) for x in ln.split("\t")[1:] if ":" in x)
+                if "SN" not in kv or "LN" not in kv:
+                    raise ValueError("@SQ line without SN / LN in %s" % path)
+                index[kv["SN"]] = len(contigs)
+                contigs.append((kv["SN"], int(kv["LN"])))
+            continue
+        records.append(sam_line_to_record(ln, index))
+    if not head and not records:
+        raise ValueError("%s is neither a BAM file nor SAM text" % path)
+    return "\n".join(head) + ("\n" if head else ""), contigs, records
 
 
 def _core(rec):

@@ -89,6 +89,66 @@ def test_formatbam_paired(tmp_path):
         assert np.array_equal(have.a[k], want.a[k]), k
 
 
+def _sam_text(contigs, reads, header):
+    """The reads as an aligner's SAM text (1-based POS, '*' for absent fields)."""
+    from mustache_amd.records import cigar_to_string
+    lines = [header.rstrip("\n")]
+    for r in reads:
+        mapped = r.cigartuples is not None
+        tags = []
+        for k, v in r.tags.items():
+            tags.append("%s:Z:%s" % (k, v) if isinstance(v, str) else "%s:i:%d" % (k, int(v)))
+        lines.append("\t".join([r.query_name, str(r.flag), contigs[r.reference_id][0] if mapped else "*",
+                                str(r.reference_start + 1 if mapped else 0), str(r.mapping_quality if mapped else 0),
+                                cigar_to_string(r.cigartuples) if mapped else "*", "*", "0", "0", r.query_sequence,
+                                "".join(chr(int(q) + 33) for q in r.query_qualities)] + tags))
+    return "\n".join(lines) + "\n"
+
+
+@pytest.mark.parametrize("gz", [False, True])
+def test_formatbam_takes_sam_text(tmp_path, gz):
+    """`samtools view -b -h -F 0x900 {in_sam}` (samtools.py:10) reads SAM text as well as BAM: the same aligner output as
+    text gives the same formatted records (every field and tag) as it does as BAM."""
+    contigs, recs, primaries = _aligner_output("sim_b", seed=3)
+    header = "@HD\tVN:1.6\tSO:unsorted\n" + "".join("@SQ\tSN:%s\tLN:%d\n" % c for c in contigs) + "@PG\tID:aligner\n"
+    raw, sam = os.path.join(tmp_path, "raw.bam"), os.path.join(tmp_path, "raw.sam" + (".gz" if gz else ""))
+    _write(raw, contigs, recs, text=header)
+    text = _sam_text(contigs, recs, header).encode()
+    with (gzip.open(sam, "wb") if gz else open(sam, "wb")) as fh:
+        fh.write(text)
+    out_b, out_s = os.path.join(tmp_path, "b.bam"), os.path.join(tmp_path, "s.bam")
+    formatbam._formatbam(raw, out_b, False, False, verbose=False)
+    formatbam._formatbam(sam, out_s, False, False, verbose=False)
+    with bamio.BamReader(out_b) as b, bamio.BamReader(out_s) as s_:
+        assert b.text == s_.text and b.contigs == s_.contigs
+        rb, rs_ = list(b), list(s_)
+    assert len(rb) == len(rs_) == len(primaries)
+    for x, y in zip(rb, rs_):
+        assert (x.query_name, x.flag, x.reference_id, x.reference_start, x.mapping_quality, x.cigartuples, x.query_sequence,
+                list(x.query_qualities), x.tags) == \
+               (y.query_name, y.flag, y.reference_id, y.reference_start, y.mapping_quality, y.cigartuples, y.query_sequence,
+                list(y.query_qualities), y.tags)
+    have, want = pack_bam(out_s, pool="clipped"), pack_bam(out_b, pool="clipped")
+    for k, _ in ALL_FIELDS:
+        assert np.array_equal(have.a[k], want.a[k]), k
+    assert open(out_s + ".bai", "rb").read()[:4] == b"BAI\1"
+
+
+def test_sam_text_fields_and_tag_types():
+    rec = formatbam.sam_line_to_record("r1\t99\tc2\t101\t37\t5S10M2D3M\t=\t301\t350\tACGTNACGTACGTACGTA\t" + "I" * 18 +
+                                       "\tNM:i:2\tXS:i:-5\tXB:i:70000\tMD:Z:10^AC3\tXT:A:U\tXF:f:1.5\tXA:B:s,1,-2,3", {"c1": 0, "c2": 1})
+    ref_id, pos, l_name, mapq, bin_, n_cig, flag, l_seq, nref, npos, tlen = struct.unpack_from("<iiBBHHHiiii", rec, 0)
+    assert (ref_id, pos, l_name, mapq, n_cig, flag, l_seq, nref, npos, tlen) == (1, 100, 3, 37, 4, 99, 18, 1, 300, 350)
+    assert bin_ == bamio._reg2bin(100, 115)
+    tags = bamio._parse_tags(rec, 32 + 3 + 16 + 9 + 18)
+    assert tags["NM"] == 2 and tags["XS"] == -5 and tags["XB"] == 70000 and tags["MD"] == "10^AC3" and tags["XT"] == "U"
+    assert rec[32 + 3 + 16 + 9 + 18 + 2:32 + 3 + 16 + 9 + 18 + 3] == b"C"          # smallest integer type, as htslib stores it
+    with pytest.raises(ValueError, match="@SQ"):
+        formatbam.sam_line_to_record("r1\t0\tnope\t1\t0\t3M\t*\t0\t0\tACG\tIII", {"c1": 0})
+    with pytest.raises(ValueError, match="11 are mandatory"):
+        formatbam.sam_line_to_record("r1\t0\tc1", {"c1": 0})
+
+
 def test_formatbam_single_end_and_errors(tmp_path):
     contigs, recs, primaries = _aligner_output("sim_a")
     raw, out = os.path.join(tmp_path, "raw.bam"), os.path.join(tmp_path, "out.bam")
