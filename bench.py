@@ -71,7 +71,7 @@ def algorithmic_bytes(kernel, meta):
     if kernel.startswith("k_scan_clips"):
         return n * 1 + listed * 8              # flags of every read + one 8-byte list entry per lenient-clipped read
     if kernel.startswith("k_clip_events"):
-        return listed * (8 + 7) + ev * 8       # list entry + mapq, contig_id, one position column (7 B) + one key per event
+        return listed * (8 + 16) + ev * 8      # list entry + the read's dense 16-byte clip record (device_reads attaches them) + one key per event
     if kernel == "k_classify":
         return meta["join_visits"] * 13        # ref_start, ref_end (8 B) + mapq, flags, link (5 B) per (site, read) visit (estimated count)
     if kernel == "k_bucket_sort":

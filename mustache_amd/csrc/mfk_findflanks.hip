@@ -215,7 +215,7 @@ __device__ __forceinline__ BktRun d_bucket_run(bool has, uint32_t b, int lane) {
 
 // same grid and per-read logic as k_clip_events
 __global__ __launch_bounds__(256) void k_clip_events_bkt(DevReads R, DevParams P, const uint64_t *list, const uint32_t *seg_count, uint32_t seg_cap,
-                                                         uint64_t *bkt, uint32_t *bkt_count, uint32_t B) {
+                                                         uint64_t *bkt, uint32_t *bkt_count, uint32_t B, uint64_t bmul) {
     const uint32_t cnt = seg_count[blockIdx.y * SEG_PAD];
     const uint32_t n = cnt < seg_cap ? cnt : seg_cap;
     list += (size_t)blockIdx.y * seg_cap;
@@ -234,8 +234,10 @@ __global__ __launch_bounds__(256) void k_clip_events_bkt(DevReads R, DevParams P
                 if (lk) { const int32_t site = lk == 1 ? c.rs - 1 : c.rs; k3 = ((uint64_t)(c.base + (uint32_t)(site + 1)) << 32) | (1ull << 31) | (uint64_t)c.r; h3 = true; }
             }
         }
-        // bucket = position range of the flat axis
-        uint32_t b5 = (uint32_t)(((k5 >> 32) * (uint64_t)B) / R.gpos_span), b3 = (uint32_t)(((k3 >> 32) * (uint64_t)B) / R.gpos_span);
+        // bucket = position range of the flat axis.  Any monotone map of gpos onto [0, B) will do (the buckets are sorted one by
+        // one and concatenated), so instead of gpos * B / span (two 64-bit divisions per thread, a sixth of this kernel's time)
+        // it is gpos * floor(2^32 B / span) >> 32 with the factor made by the host; an axis shorter than B is its own bucket index.
+        uint32_t b5 = bmul ? (uint32_t)(((k5 >> 32) * bmul) >> 32) : (uint32_t)(k5 >> 32), b3 = bmul ? (uint32_t)(((k3 >> 32) * bmul) >> 32) : (uint32_t)(k3 >> 32);
         if (b5 >= B) b5 = B - 1;
         if (b3 >= B) b3 = B - 1;
         // both reservations are issued before either result is needed: one atomic round trip per sweep, not two
@@ -870,7 +872,7 @@ int findflanks_impl(mfk_ctx *ctx, const mfk_reads *reads, const mfk_params *para
         PROF_LAUNCH(k_scan_clips, dim3(nblk), dim3(SCAN_THREADS), 0, st, R, list, ev_count + SEG_PAD, (uint32_t)seg_cap);
         KCHK();
         if (bucketed) {
-            PROF_LAUNCH(k_clip_events_bkt, dim3(32, LIST_SEGS), dim3(256), 0, st, R, P, (const uint64_t *)list, (const uint32_t *)(ev_count + SEG_PAD), (uint32_t)seg_cap, bkt, bkt_count, B);
+            PROF_LAUNCH(k_clip_events_bkt, dim3(32, LIST_SEGS), dim3(256), 0, st, R, P, (const uint64_t *)list, (const uint32_t *)(ev_count + SEG_PAD), (uint32_t)seg_cap, bkt, bkt_count, B, R.gpos_span > B ? (((uint64_t)B << 32) / R.gpos_span) : (uint64_t)0);
         } else {
             PROF_LAUNCH(k_clip_events, dim3(8, LIST_SEGS), dim3(256), 0, st, R, P, (const uint64_t *)list, (const uint32_t *)(ev_count + SEG_PAD), (uint32_t)seg_cap, ev, ev_count, (uint32_t)cap64);
         }
