@@ -50,53 +50,95 @@ __device__ __forceinline__ uint4 d_load_flags16(const DevReads &R, int64_t g, in
     return v;
 }
 
-// list entry: read index | flags << 32; with the packer's dense clip records (mfk_reads.clip_rec) the low word is the
-// read's index in THAT table instead: clip_tile[tile] clipped reads lie before this 4096-read tile, and the in-tile prefix
-// sum that places the entries is also the read's rank among the tile's clipped reads.  The list has LIST_SEGS segments of seg_cap entries, each with its own counter
+// list entry: read index | flags << 32.  With the packer's dense clip records (mfk_reads.clip_rec) the low word is the
+// read's index in THAT table instead (clip_tile[tile] clipped reads lie before this 4096-read tile, and the in-tile prefix
+// sum gives the read's rank among the tile's clipped reads), and the entry is written AT that index: one flat list in read
+// order, no reservations.  Without the records the list has LIST_SEGS segments of seg_cap entries, each with its own counter
 // (a cache line apart): a workgroup reserves room with one atomic per tile, and thousands of those on ONE address would
 // serialise in the L2 and cost more than the whole stream.
 #define LIST_SEGS 64
 #define SEG_PAD 32     // counters 128 bytes apart
+// A workgroup takes SCAN_SUB consecutive 4096-read tiles per round: one block-wide prefix sum (the four per-tile counts of a
+// lane packed into one 64-bit word, 16 bits each: a tile holds at most 4096 clipped reads) and ONE list reservation for the
+// 16 k reads.  The reservation is a returning atomic, a round trip that cannot be hidden behind the next round's loads; with
+// one tile per round it was most of the kernel (C5: 17 k tiles, 8 rounds per workgroup, 54 us for 69 MB).
+#define SCAN_SUB 4
 __global__ __launch_bounds__(SCAN_THREADS) void k_scan_clips(DevReads R, uint64_t *list, uint32_t *seg_count, uint32_t seg_cap) {
-    __shared__ uint32_t sh[8];
+    __shared__ unsigned long long sh[8];
     __shared__ uint32_t s_base;
     const uint32_t seg = blockIdx.x % LIST_SEGS;
-    list += (size_t)seg * seg_cap;
+    if (!R.clip_rec) list += (size_t)seg * seg_cap;
     const int64_t ngroups = (R.n + 15) >> 4;
-    const int64_t ntiles = (ngroups + SCAN_THREADS - 1) / SCAN_THREADS;
-    uint4 nxt = d_load_flags16(R, (int64_t)blockIdx.x * SCAN_THREADS + threadIdx.x, ngroups);
-    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const uint4 v = nxt;
-        const int64_t r0 = (tile * SCAN_THREADS + threadIdx.x) << 4;
-        if (tile + gridDim.x < ntiles) nxt = d_load_flags16(R, (tile + gridDim.x) * SCAN_THREADS + threadIdx.x, ngroups);
-        // 16-bit map of this lane's lenient-clipped reads
-        uint32_t cmap = 0;
-        {
-            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+    const int64_t ntiles = (ngroups + SCAN_THREADS - 1) / SCAN_THREADS;          // 4096-read tiles
+    const int64_t nrounds = (ntiles + SCAN_SUB - 1) / SCAN_SUB;
+    uint4 nxt[SCAN_SUB];
+#pragma unroll
+    for (int s = 0; s < SCAN_SUB; s++) nxt[s] = d_load_flags16(R, ((int64_t)blockIdx.x * SCAN_SUB + s) * SCAN_THREADS + threadIdx.x, ngroups);
+    for (int64_t round = blockIdx.x; round < nrounds; round += gridDim.x) {
+        uint4 v[SCAN_SUB];
+#pragma unroll
+        for (int s = 0; s < SCAN_SUB; s++) v[s] = nxt[s];
+        if (round + gridDim.x < nrounds) {
+#pragma unroll
+            for (int s = 0; s < SCAN_SUB; s++) nxt[s] = d_load_flags16(R, ((round + gridDim.x) * SCAN_SUB + s) * SCAN_THREADS + threadIdx.x, ngroups);
+        }
+        // 16-bit map of this lane's lenient-clipped reads in each of the tiles
+        uint32_t cmap[SCAN_SUB];
+        unsigned long long packed = 0;
+#pragma unroll
+        for (int s = 0; s < SCAN_SUB; s++) {
+            const uint32_t w[4] = {v[s].x, v[s].y, v[s].z, v[s].w};
+            uint32_t m = 0;
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 uint32_t t = w[j];
                 t = (t | (t >> 1) | (t >> 2) | (t >> 3)) & 0x01010101u;
-                cmap |= ((t & 1u) | ((t >> 7) & 2u) | ((t >> 14) & 4u) | ((t >> 21) & 8u)) << (4 * j);
+                m |= ((t & 1u) | ((t >> 7) & 2u) | ((t >> 14) & 4u) | ((t >> 21) & 8u)) << (4 * j);
             }
+            cmap[s] = m;
+            packed |= (unsigned long long)__popc(m) << (16 * s);
         }
-        uint32_t total;
-        uint32_t slot = block_excl_scan(__popc(cmap), sh, &total);
-        if (total) {   // block-uniform
+        unsigned long long totals;
+        const unsigned long long pre = block_excl_scan64(packed, sh, &totals);   // per tile: clipped reads of the lanes before this one
+        if (totals && R.clip_rec) {
+            // Dense clip records: a read's rank in the table (clipped reads before its tile + before it in the tile) IS its list
+            // slot.  No reservation, no counter, nothing the round has to wait for; the list comes out in read order.
+#pragma unroll
+            for (int s = 0; s < SCAN_SUB; s++) {
+                uint32_t m = cmap[s];
+                if (!m) continue;
+                uint32_t c = R.clip_tile[round * SCAN_SUB + s] + ((uint32_t)(pre >> (16 * s)) & 0xFFFFu);
+                const uint64_t lo = (uint64_t)v[s].x | ((uint64_t)v[s].y << 32), hi = (uint64_t)v[s].z | ((uint64_t)v[s].w << 32);
+                while (m) {
+                    const int k = __builtin_ctz(m);
+                    m &= m - 1;
+                    const uint64_t f = ((k < 8 ? lo : hi) >> ((k & 7) * 8)) & 0xFF;
+                    if ((int64_t)c < R.n_clip) list[c] = (uint64_t)c | (f << 32);
+                    c++;
+                }
+            }
+        } else if (totals) {   // block-uniform
+            uint32_t tile_base[SCAN_SUB], total = 0;
+#pragma unroll
+            for (int s = 0; s < SCAN_SUB; s++) { tile_base[s] = total; total += (uint32_t)(totals >> (16 * s)) & 0xFFFFu; }
             if (threadIdx.x == 0) s_base = atomicAdd(&seg_count[seg * SEG_PAD], total);
-            uint32_t ci = R.clip_rec ? R.clip_tile[tile] + slot : 0;
             __syncthreads();
-            slot += s_base;
-            const uint64_t lo = (uint64_t)v.x | ((uint64_t)v.y << 32), hi = (uint64_t)v.z | ((uint64_t)v.w << 32);
-            while (cmap) {
-                const int k = __builtin_ctz(cmap);
-                cmap &= cmap - 1;
-                const uint64_t f = ((k < 8 ? lo : hi) >> ((k & 7) * 8)) & 0xFF;
-                if (slot < seg_cap) list[slot] = (R.clip_rec ? (uint64_t)ci : (uint64_t)(r0 + k)) | (f << 32);
-                slot++; ci++;
+            const uint32_t base = s_base;
+#pragma unroll
+            for (int s = 0; s < SCAN_SUB; s++) {
+                uint32_t slot = base + tile_base[s] + ((uint32_t)(pre >> (16 * s)) & 0xFFFFu), m = cmap[s];
+                const int64_t r0 = ((round * SCAN_SUB + s) * SCAN_THREADS + threadIdx.x) << 4;
+                const uint64_t lo = (uint64_t)v[s].x | ((uint64_t)v[s].y << 32), hi = (uint64_t)v[s].z | ((uint64_t)v[s].w << 32);
+                while (m) {
+                    const int k = __builtin_ctz(m);
+                    m &= m - 1;
+                    const uint64_t f = ((k < 8 ? lo : hi) >> ((k & 7) * 8)) & 0xFF;
+                    if (slot < seg_cap) list[slot] = (uint64_t)(r0 + k) | (f << 32);
+                    slot++;
+                }
             }
+            __syncthreads();   // s_base is reused by the next round (sh is protected by the barrier at the head of the scan)
         }
-        __syncthreads();   // s_base / sh are reused by the next tile
     }
 }
 
@@ -143,12 +185,12 @@ __global__ __launch_bounds__(256) void k_clip_events(DevReads R, DevParams P, co
                                                      uint64_t *ev, uint32_t *ev_count, uint32_t cap) {
     __shared__ uint64_t stage[EV_STAGE];
     __shared__ uint32_t s_n, s_base;
-    const uint32_t cnt = seg_count[blockIdx.y * SEG_PAD];
-    const uint32_t n = cnt < seg_cap ? cnt : seg_cap;
-    list += (size_t)blockIdx.y * seg_cap;
+    uint32_t n, wg = blockIdx.x, nwg = gridDim.x;
+    if (R.clip_rec) { n = (uint32_t)R.n_clip; wg = blockIdx.y * gridDim.x + blockIdx.x; nwg = gridDim.x * gridDim.y; }   // one flat list (k_scan_clips)
+    else { const uint32_t cnt = seg_count[blockIdx.y * SEG_PAD]; n = cnt < seg_cap ? cnt : seg_cap; list += (size_t)blockIdx.y * seg_cap; }
     if (threadIdx.x == 0) s_n = 0;
     __syncthreads();
-    for (uint32_t b0 = blockIdx.x * 256; b0 < n; b0 += gridDim.x * 256) {   // block-uniform trip count
+    for (uint32_t b0 = wg * 256; b0 < n; b0 += nwg * 256) {   // block-uniform trip count
         const uint32_t i = b0 + threadIdx.x;
         if (i < n) {
             const uint64_t e = list[i];
@@ -194,33 +236,104 @@ __global__ __launch_bounds__(256) void k_clip_events(DevReads R, DevParams P, co
 // (a site deeper than BKT_CAP clips) makes the host fall back to the list + rocPRIM path: nothing is lost, only time.
 #define BKT_CAP 4096
 
-// where a lane's key goes inside its run of equal buckets: run = consecutive lanes with the same bucket; the run's first
-// lane reserves room for the whole run
-struct BktRun { int hl, len; bool head; };
+// Where a lane's key goes inside its run of equal buckets.  A run = the lanes that hold a key for the same bucket with no
+// lane holding a key for ANOTHER bucket between them (lanes without a key of this kind do not break a run: 5p and 3p clips
+// alternate along a wave, and a run that ended at every gap meant nearly one reservation per key).  The run's first lane
+// reserves room for the whole run: one returning atomic per run.  With the flat list in read order the keys of a wave are
+// sorted by position, so a wave makes one or two reservations per kind; the device's rate of returning atomics, not its
+// bandwidth, was what bounded this kernel.
+struct BktRun { int hl, len, off; bool head; };
 __device__ __forceinline__ BktRun d_bucket_run(bool has, uint32_t b, int lane) {
-    if (!has) b = 0xFFFFFFFFu;
-    const uint32_t prev = __shfl_up(b, 1, 64);
+    const unsigned long long hasmask = __ballot(has);
+    const unsigned long long below = hasmask & ((1ull << lane) - 1ull);               // lanes with a key before this one
+    const int prev = below ? 63 - __clzll((long long)below) : lane;
+    const uint32_t prev_b = __shfl(b, prev, 64);
     BktRun r;
-    r.head = has && (lane == 0 || prev != b);
-    const unsigned long long headmask = __ballot(r.head), hasmask = __ballot(has);
-    r.hl = 0; r.len = 0;
+    r.head = has && (!below || prev_b != b);
+    const unsigned long long headmask = __ballot(r.head);
+    r.hl = 0; r.len = 0; r.off = 0;
     if (has) {
-        const unsigned long long below = headmask & ((2ull << lane) - 1ull);                // run heads at or below this lane
-        r.hl = 63 - __clzll((long long)below);
-        const unsigned long long breaks = (headmask | ~hasmask) & ~((2ull << r.hl) - 1ull);   // where the run ends
-        r.len = (breaks ? __ffsll((long long)breaks) - 1 : 64) - r.hl;
+        const unsigned long long heads_here = headmask & ((2ull << lane) - 1ull);      // run heads at or below this lane (never empty)
+        r.hl = 63 - __clzll((long long)heads_here);
+        const unsigned long long later = r.hl == 63 ? 0ull : (headmask & ~((2ull << r.hl) - 1ull));
+        const int end = later ? __ffsll((long long)later) - 1 : 64;                   // first lane of the next run
+        const unsigned long long from_head = ~((1ull << r.hl) - 1ull);
+        const unsigned long long run = hasmask & from_head & (end == 64 ? ~0ull : ((1ull << end) - 1ull));
+        r.len = __popcll(run);
+        r.off = __popcll(run & ((1ull << lane) - 1ull));
     }
     return r;
+}
+
+// One sweep of k_clip_events_bkt over the dense clip records, U entries per thread.  The kernel is a chain of dependent
+// round trips (list entry -> record -> contig base -> bucket reservation -> store) at ~3 us each under load, and a sample
+// with millions of clipped reads needs several sweeps per workgroup: with U entries per thread the trips of U entries are
+// in flight together.  Every load is unconditional (indices clamped, validity carried in a flag), so nothing keeps the
+// compiler from issuing a stage's loads back to back.
+template <int U>
+__device__ __forceinline__ void d_events_sweep_rec(const DevReads &R, const DevParams &P, const uint64_t *list, uint32_t n, uint32_t b0,
+                                                   uint64_t *bkt, uint32_t *bkt_count, uint32_t B, uint64_t bmul, int lane) {
+    uint64_t e[U]; bool in[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) { const uint32_t i = b0 + (uint32_t)u * 256u + threadIdx.x; in[u] = i < n; e[u] = list[in[u] ? i : 0u]; }
+    uint4 q[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) { const uint32_t ci = (uint32_t)e[u]; in[u] = in[u] && (int64_t)ci < R.n_clip; q[u] = reinterpret_cast<const uint4 *>(R.clip_rec)[in[u] ? ci : 0u]; }
+    uint32_t base[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) { const uint32_t cid = q[u].w & 0xFFFFu; in[u] = in[u] && cid < (uint32_t)R.n_contigs && (int64_t)q[u].x < R.n; base[u] = R.contig_base[in[u] ? cid : 0u]; }
+    uint64_t k5[U], k3[U]; bool h5[U], h3[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+        const uint8_t f = (uint8_t)(e[u] >> 32);
+        const int lk = d_lkind(f), rk = d_rkind(f);
+        const uint32_t r = q[u].x;
+        const int32_t rs = (int32_t)q[u].y, re = (int32_t)q[u].z;
+        bool ial_bad = false;
+        if (lk && rk && in[u]) {
+            if (P.minial <= 255) ial_bad = (int)(q[u].w >> 24) < P.minial;   // the record holds min(inner length, 255)
+            else ial_bad = (int)R.qlen[r] - (rk == 1 ? (int)R.last_op_len[r] : 1) - (lk == 1 ? (int)R.first_op_len[r] : 1) < P.minial;
+        }
+        const bool ok = in[u] && (int)((q[u].w >> 16) & 0xFFu) >= P.minq && !ial_bad;
+        h5[u] = ok && rk; h3[u] = ok && lk;
+        const int32_t s5 = rk == 1 ? re : re - 1, s3 = lk == 1 ? rs - 1 : rs;
+        k5[u] = h5[u] ? (((uint64_t)(base[u] + (uint32_t)(s5 + 1)) << 32) | (uint64_t)r) : 0ull;
+        k3[u] = h3[u] ? (((uint64_t)(base[u] + (uint32_t)(s3 + 1)) << 32) | (1ull << 31) | (uint64_t)r) : 0ull;
+    }
+    uint32_t b5[U], b3[U], a5[U], a3[U]; int hl5[U], hl3[U], of5[U], of3[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {   // every reservation of the sweep is issued before any result is needed
+        b5[u] = bmul ? (uint32_t)(((k5[u] >> 32) * bmul) >> 32) : (uint32_t)(k5[u] >> 32);
+        b3[u] = bmul ? (uint32_t)(((k3[u] >> 32) * bmul) >> 32) : (uint32_t)(k3[u] >> 32);
+        if (b5[u] >= B) b5[u] = B - 1;
+        if (b3[u] >= B) b3[u] = B - 1;
+        const BktRun r5 = d_bucket_run(h5[u], b5[u], lane), r3 = d_bucket_run(h3[u], b3[u], lane);
+        hl5[u] = r5.hl; hl3[u] = r3.hl; of5[u] = r5.off; of3[u] = r3.off;
+        a5[u] = 0; a3[u] = 0;
+        if (r5.head) a5[u] = atomicAdd(&bkt_count[b5[u]], (uint32_t)r5.len);
+        if (r3.head) a3[u] = atomicAdd(&bkt_count[b3[u]], (uint32_t)r3.len);
+    }
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+        const uint32_t base5 = __shfl(a5[u], hl5[u], 64), base3 = __shfl(a3[u], hl3[u], 64);
+        if (h5[u]) { const uint32_t slot = base5 + (uint32_t)of5[u]; if (slot < BKT_CAP) bkt[(size_t)b5[u] * BKT_CAP + slot] = k5[u]; }
+        if (h3[u]) { const uint32_t slot = base3 + (uint32_t)of3[u]; if (slot < BKT_CAP) bkt[(size_t)b3[u] * BKT_CAP + slot] = k3[u]; }
+    }
 }
 
 // same grid and per-read logic as k_clip_events
 __global__ __launch_bounds__(256) void k_clip_events_bkt(DevReads R, DevParams P, const uint64_t *list, const uint32_t *seg_count, uint32_t seg_cap,
                                                          uint64_t *bkt, uint32_t *bkt_count, uint32_t B, uint64_t bmul) {
-    const uint32_t cnt = seg_count[blockIdx.y * SEG_PAD];
-    const uint32_t n = cnt < seg_cap ? cnt : seg_cap;
-    list += (size_t)blockIdx.y * seg_cap;
     const int lane = threadIdx.x & 63;
-    for (uint32_t b0 = blockIdx.x * 256; b0 < n; b0 += gridDim.x * 256) {   // block-uniform trip count
+    uint32_t n, wg = blockIdx.x, nwg = gridDim.x;
+    if (R.clip_rec) {   // one flat list in read order (k_scan_clips); all branches here are block-uniform
+        n = (uint32_t)R.n_clip; wg = blockIdx.y * gridDim.x + blockIdx.x; nwg = gridDim.x * gridDim.y;
+        if (n > nwg * 256u) {   // several sweeps per workgroup: four entries per thread in flight
+            for (uint32_t b0 = wg * 1024u; b0 < n; b0 += nwg * 1024u) d_events_sweep_rec<4>(R, P, list, n, b0, bkt, bkt_count, B, bmul, lane);
+            return;
+        }
+    } else { const uint32_t cnt = seg_count[blockIdx.y * SEG_PAD]; n = cnt < seg_cap ? cnt : seg_cap; list += (size_t)blockIdx.y * seg_cap; }
+    for (uint32_t b0 = wg * 256; b0 < n; b0 += nwg * 256) {   // block-uniform trip count
         const uint32_t i = b0 + threadIdx.x;
         uint64_t k5 = 0, k3 = 0;
         bool h5 = false, h3 = false;
@@ -247,8 +360,8 @@ __global__ __launch_bounds__(256) void k_clip_events_bkt(DevReads R, DevParams P
         if (r3.head) base3 = atomicAdd(&bkt_count[b3], (uint32_t)r3.len);
         base5 = __shfl(base5, r5.hl, 64);
         base3 = __shfl(base3, r3.hl, 64);
-        if (h5) { const uint32_t slot = base5 + (uint32_t)(lane - r5.hl); if (slot < BKT_CAP) bkt[(size_t)b5 * BKT_CAP + slot] = k5; }
-        if (h3) { const uint32_t slot = base3 + (uint32_t)(lane - r3.hl); if (slot < BKT_CAP) bkt[(size_t)b3 * BKT_CAP + slot] = k3; }
+        if (h5) { const uint32_t slot = base5 + (uint32_t)r5.off; if (slot < BKT_CAP) bkt[(size_t)b5 * BKT_CAP + slot] = k5; }
+        if (h3) { const uint32_t slot = base3 + (uint32_t)r3.off; if (slot < BKT_CAP) bkt[(size_t)b3 * BKT_CAP + slot] = k3; }
     }
 }
 
@@ -844,7 +957,7 @@ int findflanks_impl(mfk_ctx *ctx, const mfk_reads *reads, const mfk_params *para
     SPAN_EVENT(ev0);
     // (stage 1 below) -------------------------------------------------------------------------------
     const int64_t ngroups = (R.n + 15) >> 4;
-    unsigned nblk = (unsigned)((ngroups + SCAN_THREADS - 1) / SCAN_THREADS);
+    unsigned nblk = (unsigned)((ngroups + SCAN_THREADS * SCAN_SUB - 1) / (SCAN_THREADS * SCAN_SUB));   // one round of SCAN_SUB tiles per workgroup and turn
     if (nblk > SCAN_MAX_BLOCKS) nblk = SCAN_MAX_BLOCKS;
     if (nblk < 1) nblk = 1;
     uint32_t *d_stats = nullptr, *ev_count = nullptr;   // ev_count[0] events, [SEG_PAD * (1 + seg)] listed reads of a segment
@@ -863,9 +976,14 @@ int findflanks_impl(mfk_ctx *ctx, const mfk_reads *reads, const mfk_params *para
         if (cap64 > 0xFFFFFFF0ull || seg_cap > 0x7FFFFFF0ull) { snprintf(ctx->err, sizeof ctx->err, "more than 2^32 soft-clip events in one call"); return 1; }
         if (bucketed) bkt = aalloc<uint64_t>(ctx, (size_t)B * BKT_CAP);
         else ev = aalloc<uint64_t>(ctx, (size_t)cap64);
-        uint64_t *list = aalloc<uint64_t>(ctx, (size_t)seg_cap * LIST_SEGS);
-        if ((bucketed ? !bkt : !ev) || !list) return 1;
+        // the list of clipped reads: 64 segments with a counter each, or (dense clip records) one flat list with a slot per record,
+        // zeroed first so that a table that does not restate the columns loses clips instead of leaving slots unwritten
+        const bool dense = R.clip_rec != nullptr;
+        uint64_t *list = nullptr;
+        if (!dense) { list = aalloc<uint64_t>(ctx, (size_t)seg_cap * LIST_SEGS); if (!list) return 1; }
+        if (bucketed ? !bkt : !ev) return 1;
         FillGroup z(ctx, 0);
+        if (dense) z.want(&list, (size_t)R.n_clip + 16);
         z.want(&d_stats, MFK_N_STATS); z.want(&ev_count, h_cnt.size());
         if (bucketed) z.want(&bkt_count, B);
         if (z.commit()) return 1;
@@ -885,7 +1003,8 @@ int findflanks_impl(mfk_ctx *ctx, const mfk_reads *reads, const mfk_params *para
         }
         ht.lap("scan + events + read-back");
         uint64_t seg_max = 0, listed = 0, bmax = 0, bsum = 0;
-        for (int sgi = 0; sgi < LIST_SEGS; sgi++) { uint64_t c = h_cnt[(size_t)SEG_PAD * (1 + sgi)]; listed += c; if (c > seg_max) seg_max = c; }
+        if (R.clip_rec) listed = (uint64_t)R.n_clip;   // (flat list: nothing to overflow)
+        else for (int sgi = 0; sgi < LIST_SEGS; sgi++) { uint64_t c = h_cnt[(size_t)SEG_PAD * (1 + sgi)]; listed += c; if (c > seg_max) seg_max = c; }
         if (bucketed) { for (uint32_t c : h_bkt) { bsum += c; if (c > bmax) bmax = c; } }
         if (bsum > 0xFFFFFFF0ull) { snprintf(ctx->err, sizeof ctx->err, "more than 2^32 soft-clip events in one call"); return 1; }
         E = bucketed ? (uint32_t)bsum : h_cnt[0];
