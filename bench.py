@@ -589,7 +589,8 @@ def main():
                 roofline["whole_step"] = {"algorithmic_bytes": own, "GBps": round(own / (ms_per_step * 1e-3) / 1e9, 1), "frac_of_hbm_peak": round(own / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
                                           "survey_8d_model": {"bytes": d8, "GBps": round(d8 / (ms_per_step * 1e-3) / 1e9, 1), "frac_of_hbm_peak": round(d8 / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
                                                               "what": "SURVEY 8(d)'s per-read figure (25.6 B/read + 13 B per site x read visit + the pairing stage's per-pair bytes): what a 24-byte-record layout would move; the SoA layout of this build moves `algorithmic_bytes`"},
-                                          "note": "the step is a chain of dependent launches over a few dozen sites: launch- and latency-bound, not HBM-bound"}
+                                          "note": ("the step is a chain of dependent launches over a few dozen sites: launch- and latency-bound, not HBM-bound" if int(st_pf[0]) < 1000 else
+                                                   "thousands of sites: the step is bound by the per-site-side consensus (k_job_small, vector-ALU issue at four waves per SIMD) and the per-pair kernels, not by HBM")}
         if args.dump_profile:
             with open(args.dump_profile, "w") as fh:
                 fh.write("# per-kernel HIP-event timing, every launch bracketed, over %d untimed steps after the warm-up (config %s)\n" % (warm_calls, args.config))
