@@ -161,6 +161,12 @@ def test_empty_and_tiny_inputs(hip, oracle):
     packed = pack_reads(rs.contigs, rs, pool="all")
     res = hip.run_findflanks(_device_reads(hip, packed), lib.make_params())
     assert len(res["flanks"]) == 0 and len(res["sites"]) == 0
+    # no read at all, with and without the (empty) dense clip records
+    none = pack_reads(rs.contigs, ReadSet([("c1", 1000)], []), pool="all")
+    assert none.n_reads == 0 and none.clip_records()[1].tolist() == [0]
+    for clip_rec in (True, False):
+        res = hip.run_findflanks(device_reads(hip, none, "cuda:0", clip_rec=clip_rec), lib.make_params())
+        assert len(res["flanks"]) == 0 and len(res["sites"]) == 0
 
 
 @pytest.mark.parametrize("name", util.CASES)
