@@ -621,6 +621,10 @@ bool load_index(const char *path, Index *ix) {
     // marks and blocks ascend, or the file is not one of ours
     for (size_t k = 1; ok && k < ix->marks.size(); ++k) ok = ix->marks[k].u > ix->marks[k - 1].u;
     for (size_t k = 1; ok && k < ix->block_u.size(); ++k) ok = ix->block_u[k] > ix->block_u[k - 1] && ix->block_at[k] > ix->block_at[k - 1];
+    // every offset inside the stream it describes (a damaged file must fail here, not index out of the tables later)
+    if (ok && !ix->block_u.empty()) ok = ix->block_u.front() == 0 && ix->block_u.back() < ix->total_u && ix->block_at.back() < ix->bam_size;
+    if (ok) ok = ix->hdr_u_end <= ix->total_u && ix->max_span >= 0 && ix->total_u < ((uint64_t)1 << 46);
+    if (ok && !ix->marks.empty()) ok = ix->marks.back().u < ix->total_u && ix->marks.front().u >= ix->hdr_u_end;
     return ok;
 }
 

@@ -1,6 +1,7 @@
 """libmfkio.so (include/mfk_bamio.h): the native BGZF/BAM decoder + packer against the Python packer, array for array."""
 import ctypes as C
 import os
+import struct
 import re
 
 import numpy as np
@@ -338,6 +339,19 @@ def test_stale_or_foreign_index_falls_back_to_the_full_pass(tmp_path):
             open(bad, "wb").write(blob)
         got = pack.pack_bam(path, pool="regions", regions=regs, index=bad)
         assert not got.io_stats["indexed"]
+    # an index of the right file whose offsets were damaged (first block not at 0, a mark beyond the stream): refused on load
+    pack.pack_bam(path, pool="clipped", index_out=idx)
+    good = bytearray(open(idx, "rb").read())
+    n_marks, n_blocks = struct.unpack_from("<QQ", good, 8 + 32 + 8)
+    assert pack.pack_bam(path, pool="regions", regions=regs, index=idx).io_stats["indexed"]
+    for off, val in ((8 + 32 + 8 + 16 + 16 * n_marks + 8, 7),                          # uncompressed offset of block 0
+                     (8 + 32 + 8 + 16 + 16 * (n_marks - 1), 1 << 40)):                    # stream offset of the last mark
+        dmg = bytearray(good)
+        struct.pack_into("<Q", dmg, off, val)
+        open(bad, "wb").write(bytes(dmg))
+        got = pack.pack_bam(path, pool="regions", regions=regs, index=bad)
+        assert not got.io_stats["indexed"]
+        same(got, pack.pack_bam(path, pool="regions", regions=regs))
     # inverted regions keep the Python meaning through the full pass
     got = pack.pack_bam(path, pool="regions", regions=regs + [(0, 500, 400, 450, 420)], index=idx)
     assert not got.io_stats["indexed"]
