@@ -339,6 +339,21 @@ int mfk_profile_fetch(mfk_ctx *ctx, char *names, int64_t names_cap, double *ms, 
  * region pays for two event records per launch only where a duration is wanted.  Also clears the totals. */
 int mfk_profile_select(mfk_ctx *ctx, const char *names);
 
+/* ---- BGZF inflate on the device (SURVEY 8f N3 "optionally GPU inflate"; the reference inflates inside pysam/htslib,
+ * findflanks.py:22, 100-121).  One wave per block; compressed bytes in device memory -> inflated bytes in device memory.
+ * First stage of a decode that stays on the device; the shipped stage drivers still use the host reader (libmfkio.so). ---- */
+typedef struct mfk_bgzf_block {
+    uint64_t comp_off;   /* offset of the block's raw deflate stream in the compressed buffer          */
+    uint64_t out_off;    /* where its bytes go in the output buffer                                    */
+    uint32_t comp_len;   /* length of the deflate stream (BSIZE - XLEN - 19)                           */
+    uint32_t out_len;    /* ISIZE                                                                      */
+} mfk_bgzf_block;
+/* blocks: HOST array.  d_comp / d_out: DEVICE.  h_status: NULL or n_blocks codes (0 = ok).  Returns 0, 12 when some block
+ * does not inflate to exactly out_len bytes (*n_bad: how many; nothing is read or written outside a block's own ranges,
+ * whatever the data), 1 for bad arguments.  The blocks' CRC32 is not checked here. */
+int mfk_bgzf_inflate(mfk_ctx *ctx, const void *d_comp, int64_t comp_bytes, const mfk_bgzf_block *blocks, int64_t n_blocks,
+                     void *d_out, int64_t out_bytes, int32_t *h_status, int64_t *n_bad);
+
 #ifdef __cplusplus
 }
 #endif

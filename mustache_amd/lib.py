@@ -20,6 +20,9 @@ STAGE_PARSE, STAGE_MINLENGTH, STAGE_MINCOUNT, STAGE_MINDIST1, STAGE_UNCLIPPED, S
 _p = C.c_void_p
 
 
+BGZF_BLOCK_DTYPE = np.dtype([("comp_off", np.uint64), ("out_off", np.uint64), ("comp_len", np.uint32), ("out_len", np.uint32)])   # mfk_bgzf_block
+
+
 class MfkReads(C.Structure):
     _fields_ = [("n_reads", C.c_int64),
                 ("ref_start", _p), ("ref_end", _p), ("link", _p), ("contig_id", _p), ("qlen", _p),
@@ -137,6 +140,8 @@ class Binding:
             f("allgather_fetch", C.c_int, [_p, C.c_int, _p, _p])
             f("allgather_fetch_all", C.c_int, [_p, _p, _p])
             f("allgather_next_bytes", C.c_int64, [_p])
+        if hasattr(self.so, prefix + "bgzf_inflate"):
+            f("bgzf_inflate", C.c_int, [_p, _p, C.c_int64, _p, C.c_int64, _p, C.c_int64, _p, C.POINTER(C.c_int64)])
         if hasattr(self.so, prefix + "span_timing"):
             fn = getattr(self.so, prefix + "span_timing")
             fn.restype, fn.argtypes = C.c_int, [_p, C.c_int]
@@ -194,6 +199,19 @@ class Binding:
             r.clip_rec, r.clip_tile = _ptr(arrays["clip_rec"]), _ptr(arrays["clip_tile"])
         r._keep = (arrays, clen, crs)
         return r
+
+    # ---- BGZF inflate on the device (include/mfk.h mfk_bgzf_inflate) ---------------------------------------------------------
+    def run_bgzf_inflate(self, d_comp, blocks, d_out, want_status=False):
+        """d_comp / d_out: uint8 device tensors; blocks: numpy array of BGZF_BLOCK_DTYPE.  Raises MfkError when a block does
+        not inflate (after filling ``status`` when asked for).  -> (n_bad, status or None)."""
+        blocks = np.ascontiguousarray(blocks, dtype=BGZF_BLOCK_DTYPE)
+        status = np.zeros(blocks.shape[0], dtype=np.int32) if want_status else None
+        bad = C.c_int64()
+        rc = self.bgzf_inflate(self.ctx, _ptr(d_comp), int(d_comp.numel()), blocks.ctypes.data, blocks.shape[0], _ptr(d_out), int(d_out.numel()),
+                               status.ctypes.data if want_status else None, C.byref(bad))
+        if rc not in (0, 12) or (rc == 12 and not want_status):
+            self._check(rc)
+        return int(bad.value), status
 
     # ---- multi-GPU merge inside the library (RCCL; include/mfk.h mfk_comm_* / mfk_allgather_sites) ----------------------
     def make_comm_id(self):
