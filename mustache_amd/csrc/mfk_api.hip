@@ -56,6 +56,7 @@ void mfk_destroy(mfk_ctx *ctx) {
     (void)hipStreamSynchronize(ctx->stream2);
     (void)hipStreamSynchronize(ctx->stream3);
     (void)mfk_comm_free(ctx);
+    mfk_decode_release(ctx);
     for (auto &c : ctx->chunks) (void)hipFree(c.p);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     if (ctx->gather_count) (void)hipFree(ctx->gather_count);

@@ -82,6 +82,7 @@ struct mfk_ctx {
     char *na_pinned;                // pinned staging of mfk_recall_noalloc (header | sites | counts), allocated by mfk_create
     std::vector<int32_t> ir_ov;     // external inverted-repeat table for the next pairflanks call: rows i5 i3 has a1s a1e a2s a2e, sorted
     // multi-GPU merge (mfk_comm.hip): RCCL communicator of this ctx and the result of the last mfk_allgather_sites
+    void *dec = nullptr;            // device decode (mfk_decode.hip): the state between mfk_decode_bam and mfk_decode_bam_fetch
     void *comm; int comm_rank, comm_world;
     std::vector<uint8_t> gat; size_t gat_msg, gat_hint; std::vector<int64_t> gat_counts; int32_t gat_row_bytes;   // gat_hint: largest table of the last gather
 };
@@ -161,6 +162,7 @@ void noalloc_teardown(mfk_ctx *ctx);
 static inline unsigned nblocks(int64_t n, int threads) { int64_t b = (n + threads - 1) / threads; return (unsigned)(b < 1 ? 1 : b); }
 
 // device-wide primitives (rocPRIM) on the ctx stream, temp storage from the arena
+void mfk_decode_release(mfk_ctx *ctx);   // mfk_decode.hip: frees ctx->dec
 int dev_sort_keys64(mfk_ctx *ctx, uint64_t *keys_in, uint64_t *keys_out, size_t n, int begin_bit, int end_bit);
 int dev_sort_pairs64(mfk_ctx *ctx, uint64_t *keys_in, uint64_t *keys_out, uint32_t *vals_in, uint32_t *vals_out, size_t n, int begin_bit, int end_bit);
 int dev_excl_scan32(mfk_ctx *ctx, const uint32_t *in, uint32_t *out, size_t n);   // out has n+1 entries: out[n] = total

@@ -54,6 +54,8 @@ def device_reads(binding, packed: PackedReads, device, clip_rec=True):
     """Move a PackedReads to ``device`` and describe it to the library.  clip_rec: attach the dense clip records
     (``PackedReads.clip_records``, include/mfk.h mfk_clip_rec): worth their one host pass when the reads stay resident for
     more than one call; the one-shot commands, whose time is the decode, leave them out."""
+    if hasattr(packed, "device_struct"):        # decoded on the device (gpudecode.DevicePacked): the columns are there already
+        return packed.device_struct(binding)
     tensors = packed.to_torch(device, clip_rec=clip_rec)
     return binding.reads_struct(tensors, packed.n_reads, packed.max_span, _lib.host_header(packed))
 
@@ -100,8 +102,9 @@ def _findflanks(bamfile, min_softclip_length, min_softclip_count, min_alignment_
                 min_distance_to_mate, min_softclip_ratio, max_indel_ratio, large_insertion_cutoff,
                 min_count_consensus, sample_id, output_file=None, device="cuda:0", verbose=True, decoder="native",
                 exclude_flags=0, record_index=True):
-    """Drop-in for reference findflanks.py:18-59 (same positional arguments).  ``decoder``: "native" (libmfkio.so) or
-    "python" (bamio.BamReader + pack_reads, the readable statement of the same packing rules).  ``exclude_flags``: skip
+    """Drop-in for reference findflanks.py:18-59 (same positional arguments).  ``decoder``: "native" (libmfkio.so, host threads),
+    "gpu" (mfk_decode_bam: inflate, record parse and packing as kernels; same arrays) or "python" (bamio.BamReader + pack_reads, the
+    readable statement of the same packing rules).  ``exclude_flags``: skip
     records with any of these FLAG bits (0x900 = what the reference's formatbam step removes, samtools.py:9-18), for BAM
     files that did not go through formatbam; 0 = every mapped record, like the reference.  ``record_index``: the pass over
     the BAM also leaves ``<output_file>.mfki`` (record offsets + coordinates per 32 KiB of the uncompressed stream and the
@@ -121,16 +124,28 @@ def _findflanks(bamfile, min_softclip_length, min_softclip_count, min_alignment_
         log("Parsing softclipped sites from provided BAM file...")
     if decoder == "native":
         packed = pack_bam(bamfile, pool="clipped", exclude_flags=exclude_flags, index_out=index_path(output_file, record_index))
+    elif decoder == "gpu":
+        # the whole decode on the device (gpudecode.py, mfk_decode_bam): only the compressed file crosses PCIe
+        from .gpudecode import GpuDecodeUnverified, decode_bam
+        try:
+            packed = decode_bam(binding, bamfile, pool="clipped", exclude_flags=exclude_flags, device=device, index_out=index_path(output_file, record_index))
+        except GpuDecodeUnverified as e:
+            log("device decode: %s; reading the file with the host reader instead" % e)
+            packed = pack_bam(bamfile, pool="clipped", exclude_flags=exclude_flags, index_out=index_path(output_file, record_index))
     elif decoder == "python":
         from .bamio import BamReader
         with BamReader(bamfile) as bam:
             packed = pack_reads(bam.contigs, bam, pool="clipped", exclude_flags=exclude_flags)
     else:
-        raise ValueError("decoder must be 'native' or 'python', not %r" % (decoder,))
+        raise ValueError("decoder must be 'native', 'gpu' or 'python', not %r" % (decoder,))
     if verbose:
         log("Packed %d mapped reads (%.1f MB of records)" % (packed.n_reads, packed.nbytes_hot() / 1e6))
         st = getattr(packed, "io_stats", None)
-        if st:
+        if st and st.get("decoder") == "gpu":
+            log("BAM decode on the device: %.3f s (block table + header %.3f, file upload %.3f, inflate + boundaries + count %.3f, fill + links %.3f), %.1f M records/s" % (
+                st["seconds_total"], st["seconds_block_table_and_header"], st["seconds_upload_file"], st["seconds_device_stage1"], st["seconds_device_stage2"],
+                st["n_records"] / max(st["seconds_total"], 1e-9) / 1e6))
+        elif st:
             log("BAM decode: %.2f s on %d threads (inflate %.2f s, parse %.2f s, names %.2f s), %.1f M records/s" % (
                 st["seconds_total"], st["n_threads"], st["seconds_inflate"], st["seconds_parse"], st["seconds_link"],
                 st["n_records"] / max(st["seconds_total"], 1e-9) / 1e6))
@@ -146,5 +161,8 @@ def _findflanks(bamfile, min_softclip_length, min_softclip_count, min_alignment_
     LAST_TIMING["findflanks"] = {"decode_s": round(t1 - t0, 4), "inflate_s": round(st.get("seconds_inflate", 0.0), 4),
                                  "parse_s": round(st.get("seconds_parse", 0.0), 4), "links_s": round(st.get("seconds_link", 0.0), 4),
                                  "upload_s": round(t2 - t1, 4), "kernels_and_tsv_s": round(t3 - t2, 4), "device_ms": round(binding.device_ms(), 3),
-                                 "reads_packed": int(packed.n_reads), "inflated_bytes": int(st.get("uncompressed_bytes", 0))}
+                                 "reads_packed": int(packed.n_reads), "inflated_bytes": int(st.get("uncompressed_bytes", 0)), "decoder": st.get("decoder", decoder)}
+    for k in ("seconds_block_table_and_header", "seconds_upload_file", "seconds_device_stage1", "seconds_device_stage2"):
+        if k in st:
+            LAST_TIMING["findflanks"][k.replace("seconds_", "") + "_s"] = round(st[k], 4)
     return out

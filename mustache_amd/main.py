@@ -39,10 +39,11 @@ def cli():
 @click.option("--sample_id", "-id", default=None)
 @click.option("--output_file", "-o", default="mustache.findflanks.tsv")
 @click.option("--exclude-flags", "exclude_flags", default="0", help="Skip records with any of these FLAG bits, e.g. 0x900 for a BAM that did not go through formatbam (not in the reference).")
+@click.option("--decoder", type=click.Choice(["native", "gpu", "python"]), default="native", help="Who reads the BAM: host threads (libmfkio.so), the GPU (inflate + parse + packing as kernels) or the Python statement of the packing rules; same arrays (not in the reference).")
 @click.option("--device", default="cuda:0", help="GPU to run on (not in the reference).")
 def findflanks(bamfile, min_softclip_length, min_softclip_count, min_alignment_quality, min_alignment_inner_length,
                min_distance_to_mate, min_softclip_ratio, max_indel_ratio, large_insertion_cutoff,
-               min_count_consensus, sample_id, output_file, exclude_flags, device):
+               min_count_consensus, sample_id, output_file, exclude_flags, decoder, device):
     from .findflanks import _findflanks
     if sample_id is None:
         sample_id = abspath(output_file)           # reference main.py:84-85
@@ -54,7 +55,7 @@ def findflanks(bamfile, min_softclip_length, min_softclip_count, min_alignment_q
                sample_id=sample_id, output_file=output_file)
     _findflanks(bamfile, min_softclip_length, min_softclip_count, min_alignment_quality, min_alignment_inner_length,
                 min_distance_to_mate, min_softclip_ratio, max_indel_ratio, large_insertion_cutoff,
-                min_count_consensus, sample_id, output_file, device=device, exclude_flags=int(str(exclude_flags), 0))
+                min_count_consensus, sample_id, output_file, device=device, exclude_flags=int(str(exclude_flags), 0), decoder=decoder)
 
 
 @cli.command(short_help="Pair identified flanks with each other to represent 5' and 3' ends of inserted sequence.")
