@@ -301,7 +301,7 @@ def end_to_end(n_records, tmp, device):
     pf_args = (d["max_direct_repeat_length"], d["min_alignment_quality"], d["min_alignment_inner_length"], d["max_junction_spanning_prop"], d["large_insertion_cutoff"])
     try:
         # base set first (one copy): the expectation, and the warm-up of the library
-        _findflanks(one, *ff_args, output_file=tsv1, device=device, verbose=False)
+        _findflanks(one, *ff_args, output_file=tsv1, device=device, verbose=False, decoder="native")
         _pairflanks(tsv1, one, one + ".fa", *pf_args, output_file=tsv2, device=device, verbose=False)
         def base_table(path, id_col):      # the one-copy file names its contigs <name>_000000: back to <name>, then repeated per copy
             t = pd.read_csv(path, sep="\t").drop(columns=[id_col])
@@ -310,23 +310,35 @@ def end_to_end(n_records, tmp, device):
         want_ff, want_pf = base_table(tsv1, "flank_id"), base_table(tsv2, "pair_id")
         # the pairs table is sorted by contig NAME (pandas sort_values in the reference, pairflanks.py:248), the flank table keeps file order
         want_pf = want_pf.sort_values(["contig", "pos_5p", "pos_3p"], kind="stable").reset_index(drop=True)
-        t0 = time.perf_counter()
-        _findflanks(bam, *ff_args, output_file=tsv1, device=device, verbose=False)
-        t1 = time.perf_counter()
-        _pairflanks(tsv1, bam, fa, *pf_args, output_file=tsv2, device=device, verbose=False)
-        t2 = time.perf_counter()
-        got_ff = pd.read_csv(tsv1, sep="\t").drop(columns=["flank_id"])
-        got_pf = pd.read_csv(tsv2, sep="\t").drop(columns=["pair_id"])
-        ok = got_ff.to_csv(sep="\t", index=False) == want_ff.to_csv(sep="\t", index=False) and \
-            got_pf.to_csv(sep="\t", index=False) == want_pf.to_csv(sep="\t", index=False)
-        return {"records": n_rec, "bam_bytes": os.path.getsize(bam), "contigs": len(contigs), "flank_rows": int(len(got_ff)), "pairs": int(len(got_pf)),
-                "findflanks_s": round(t1 - t0, 3), "pairflanks_s": round(t2 - t1, 3),
-                "value": round(n_rec / (t2 - t0), 1), "unit": "reads/s",
-                "what": "BAM + FASTA files -> findflanks TSV -> pairflanks TSV (two commands like the reference's; findflanks inflates the whole file and leaves a record index, "
-                        "pairflanks reads only the BGZF blocks around its candidate regions through it, as bam.fetch does through the BAI), host decode threads = %s" % os.environ.get("OMP_NUM_THREADS", "all"),
-                "record_index_bytes": os.path.getsize(tsv1 + ".mfki") if os.path.exists(tsv1 + ".mfki") else None,
-                "stages": dict(ff_mod.LAST_TIMING),
-                "tables_equal_base_repeated": bool(ok), "write_inputs_s": round(write_s, 1)}
+        def run(decoder):
+            t0 = time.perf_counter()
+            _findflanks(bam, *ff_args, output_file=tsv1, device=device, verbose=False, decoder=decoder)
+            t1 = time.perf_counter()
+            _pairflanks(tsv1, bam, fa, *pf_args, output_file=tsv2, device=device, verbose=False)
+            t2 = time.perf_counter()
+            got_ff = pd.read_csv(tsv1, sep="\t").drop(columns=["flank_id"])
+            got_pf = pd.read_csv(tsv2, sep="\t").drop(columns=["pair_id"])
+            ok = got_ff.to_csv(sep="\t", index=False) == want_ff.to_csv(sep="\t", index=False) and \
+                got_pf.to_csv(sep="\t", index=False) == want_pf.to_csv(sep="\t", index=False)
+            return {"findflanks_s": round(t1 - t0, 3), "pairflanks_s": round(t2 - t1, 3), "value": round(n_rec / (t2 - t0), 1), "unit": "reads/s",
+                    "flank_rows": int(len(got_ff)), "pairs": int(len(got_pf)), "stages": dict(ff_mod.LAST_TIMING), "tables_equal_base_repeated": bool(ok),
+                    "record_index_bytes": os.path.getsize(tsv1 + ".mfki") if os.path.exists(tsv1 + ".mfki") else None}
+        # The commands' default: findflanks decodes on the device (mfk_decode_bam: inflate, record boundaries, packing and name links
+        # as kernels; only the compressed file crosses PCIe), pairflanks reads the blocks around its regions on the host.  The first
+        # call sizes the ctx's decode buffers for this file, the second finds them in place: both are reported, `value` is the first.
+        first = run("gpu")
+        second = run("gpu")
+        out = {"records": n_rec, "bam_bytes": os.path.getsize(bam), "contigs": len(contigs)}
+        out.update(first)
+        out["second_call"] = {"findflanks_s": second["findflanks_s"], "pairflanks_s": second["pairflanks_s"], "value": second["value"],
+                              "tables_equal_base_repeated": second["tables_equal_base_repeated"]}
+        out["what"] = ("BAM + FASTA files -> findflanks TSV -> pairflanks TSV, the two commands with their defaults (findflanks --decoder gpu: the whole decode on "
+                       "the device, leaves a record index; pairflanks reads only the BGZF blocks around its candidate regions through it, as bam.fetch does "
+                       "through the BAI, host decode threads = %s)" % os.environ.get("OMP_NUM_THREADS", "all"))
+        out["write_inputs_s"] = round(write_s, 1)
+        host = run("native")
+        out["host_decode"] = dict(host, what="the same with findflanks --decoder native (libmfkio.so: libdeflate + record parse on %s host threads)" % os.environ.get("OMP_NUM_THREADS", "all"))
+        return out
     finally:
         for p in (bam, fa, one, one + ".fa", tsv1, tsv2, tsv1 + ".mfki"):
             try:

@@ -100,10 +100,11 @@ def findflanks_packed(binding, reads_struct, contig_names, params, sample_id, ou
 
 def _findflanks(bamfile, min_softclip_length, min_softclip_count, min_alignment_quality, min_alignment_inner_length,
                 min_distance_to_mate, min_softclip_ratio, max_indel_ratio, large_insertion_cutoff,
-                min_count_consensus, sample_id, output_file=None, device="cuda:0", verbose=True, decoder="native",
+                min_count_consensus, sample_id, output_file=None, device="cuda:0", verbose=True, decoder="gpu",
                 exclude_flags=0, record_index=True):
-    """Drop-in for reference findflanks.py:18-59 (same positional arguments).  ``decoder``: "native" (libmfkio.so, host threads),
-    "gpu" (mfk_decode_bam: inflate, record parse and packing as kernels; same arrays) or "python" (bamio.BamReader + pack_reads, the
+    """Drop-in for reference findflanks.py:18-59 (same positional arguments).  ``decoder``: "gpu" (the default; mfk_decode_bam: inflate, record
+    boundaries, packing and name links as kernels, only the compressed file crosses PCIe; a file whose guessed record boundaries do
+    not verify is read by the host reader instead), "native" (libmfkio.so, host threads; same arrays) or "python" (bamio.BamReader + pack_reads, the
     readable statement of the same packing rules).  ``exclude_flags``: skip
     records with any of these FLAG bits (0x900 = what the reference's formatbam step removes, samtools.py:9-18), for BAM
     files that did not go through formatbam; 0 = every mapped record, like the reference.  ``record_index``: the pass over

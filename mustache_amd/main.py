@@ -39,7 +39,7 @@ def cli():
 @click.option("--sample_id", "-id", default=None)
 @click.option("--output_file", "-o", default="mustache.findflanks.tsv")
 @click.option("--exclude-flags", "exclude_flags", default="0", help="Skip records with any of these FLAG bits, e.g. 0x900 for a BAM that did not go through formatbam (not in the reference).")
-@click.option("--decoder", type=click.Choice(["native", "gpu", "python"]), default="native", help="Who reads the BAM: host threads (libmfkio.so), the GPU (inflate + parse + packing as kernels) or the Python statement of the packing rules; same arrays (not in the reference).")
+@click.option("--decoder", type=click.Choice(["gpu", "native", "python"]), default="gpu", help="Who reads the BAM: the GPU (inflate + record parse + packing as kernels), host threads (libmfkio.so) or the Python statement of the packing rules; same arrays (not in the reference).")
 @click.option("--device", default="cuda:0", help="GPU to run on (not in the reference).")
 def findflanks(bamfile, min_softclip_length, min_softclip_count, min_alignment_quality, min_alignment_inner_length,
                min_distance_to_mate, min_softclip_ratio, max_indel_ratio, large_insertion_cutoff,
