@@ -359,15 +359,19 @@ int mfk_bgzf_inflate(mfk_ctx *ctx, const void *d_comp, int64_t comp_bytes, const
  * the BAM (findflanks.py:100-121, sctools.py:5-31).  Two calls: sizes, then the caller allocates and the columns are written
  * into its buffers.  Results equal mfkio_pack_bam_filtered's arrays (tests/test_gpu_decode.py). ---- */
 /* BGZF block table of a file in HOST memory; blocks == NULL only counts; file_off: NULL or the file offset of every block. */
-int mfk_bgzf_block_table(mfk_ctx *ctx, const void *file, int64_t size, mfk_bgzf_block *blocks, uint64_t *file_off, int64_t cap,
-                         int64_t *n_blocks, int64_t *inflated_bytes);
+int mfk_bgzf_block_table(mfk_ctx *ctx, const void *file, int64_t size, mfk_bgzf_block *blocks, uint64_t *file_off, uint32_t *crc,
+                         int64_t cap, int64_t *n_blocks, int64_t *inflated_bytes);   /* crc: NULL or the CRC-32 of every block's trailer */
+/* CRC-32 (gzip's) of the byte ranges out_off .. out_off + out_len of d_data (DEVICE), one per block of the HOST table. */
+int mfk_bgzf_crc32(mfk_ctx *ctx, const void *d_data, int64_t data_bytes, const mfk_bgzf_block *blocks, int64_t n_blocks, uint32_t *h_crc);
 /* Stage 1.  d_comp: the file in DEVICE memory; blocks: HOST; first_record_off: offset of the first alignment record in the
  * inflated stream (the caller reads the header); pool_mode 0 none / 1 clipped / 2 all; exclude_flags: FLAG bits to skip.
  * sizes[8] <- n_reads, n_cx, n_blk, n_pool, pool bytes, 0, n_records, inflated bytes.  Returns 0; 13 = a guessed record
  * boundary did not verify (use the host reader); 14 = a record the packer rejects (sizes[0] = its index among all records,
- * sizes[1] = reason); 15 = damaged stream; 12 = a block does not inflate. */
-int mfk_decode_bam(mfk_ctx *ctx, const void *d_comp, int64_t comp_bytes, const mfk_bgzf_block *blocks, int64_t n_blocks,
-                   int64_t first_record_off, int32_t n_contigs, int32_t pool_mode, uint32_t exclude_flags, int64_t *sizes);
+ * sizes[1] = reason); 15 = damaged stream; 12 = a block does not inflate, or (block_crc: HOST, NULL = not checked) its
+ * inflated bytes do not have the CRC-32 of its trailer. */
+int mfk_decode_bam(mfk_ctx *ctx, const void *d_comp, int64_t comp_bytes, const mfk_bgzf_block *blocks, const uint32_t *block_crc,
+                   int64_t n_blocks, int64_t first_record_off, int32_t n_contigs, int32_t pool_mode, uint32_t exclude_flags,
+                   int64_t *sizes);
 /* Stage 2.  dst: DEVICE buffers sized from stage 1 (cx_off n_cx + 1, pool_off n_pool + 1 entries; the h_ fields are ignored).
  * h_contig_read_start: HOST, n_contigs + 1.  marks / mark_ref_pos: NULL, or HOST room for ceil(inflated / granule) entries
  * of the record index (stream offset of the first record starting in the granule, ~0 = none; its reference id and position). */

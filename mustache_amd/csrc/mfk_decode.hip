@@ -387,7 +387,7 @@ extern "C" {
 // BGZF block table of a file in host memory (SAM specification 4.1).  blocks == NULL: only counts.  Empty blocks (the EOF
 // marker) are left out.  file_off: NULL or the file offset of every kept block (for the record index).  Returns 0, or 1 with
 // mfk_last_error for bytes that are not BGZF.
-int mfk_bgzf_block_table(mfk_ctx *ctx, const void *file, int64_t size, mfk_bgzf_block *blocks, uint64_t *file_off, int64_t cap, int64_t *n_blocks, int64_t *inflated_bytes) {
+int mfk_bgzf_block_table(mfk_ctx *ctx, const void *file, int64_t size, mfk_bgzf_block *blocks, uint64_t *file_off, uint32_t *crc, int64_t cap, int64_t *n_blocks, int64_t *inflated_bytes) {
     if (!ctx || size < 0 || (size > 0 && !file) || !n_blocks || !inflated_bytes) return 1;
     const uint8_t *f = static_cast<const uint8_t *>(file);
     int64_t n = 0;
@@ -412,6 +412,7 @@ int mfk_bgzf_block_table(mfk_ctx *ctx, const void *file, int64_t size, mfk_bgzf_
             if (blocks && n < cap) {
                 blocks[n].comp_off = o + 12 + xlen; blocks[n].out_off = u; blocks[n].comp_len = (uint32_t)(bsize - 12 - xlen - 8); blocks[n].out_len = isize;
                 if (file_off) file_off[n] = o;
+                if (crc) { const uint8_t *cp = h + bsize - 8; crc[n] = (uint32_t)cp[0] | ((uint32_t)cp[1] << 8) | ((uint32_t)cp[2] << 16) | ((uint32_t)cp[3] << 24); }
             }
             n++; u += isize;
         }
@@ -428,7 +429,7 @@ int mfk_bgzf_block_table(mfk_ctx *ctx, const void *file, int64_t size, mfk_bgzf_
 // n_records (all alignment records), inflated bytes.  Errors: 13 = the record boundaries could not be verified (use the host
 // reader), 14 = a record the packer rejects (sizes[0] = its index among all records, sizes[1] = the reason, PE_* above),
 // 15 = damaged stream (bad or truncated record).
-int mfk_decode_bam(mfk_ctx *ctx, const void *d_comp, int64_t comp_bytes, const mfk_bgzf_block *blocks, int64_t n_blocks, int64_t first_record_off,
+int mfk_decode_bam(mfk_ctx *ctx, const void *d_comp, int64_t comp_bytes, const mfk_bgzf_block *blocks, const uint32_t *block_crc, int64_t n_blocks, int64_t first_record_off,
                    int32_t n_contigs, int32_t pool_mode, uint32_t exclude_flags, int64_t *sizes) {
     if (!ctx || !sizes || n_blocks < 0 || n_blocks > 0x7FFFFFF0 || first_record_off < 0 || n_contigs <= 0 || n_contigs > 65535 || pool_mode < 0 || pool_mode > 2) return 1;
     ctx->err[0] = 0;
@@ -444,6 +445,21 @@ int mfk_decode_bam(mfk_ctx *ctx, const void *d_comp, int64_t comp_bytes, const m
     if ((uint64_t)first_record_off > U) { snprintf(ctx->err, sizeof ctx->err, "mfk_decode_bam: first record behind the end of the stream"); return 1; }
     if (!ensure(&S->u, &S->u_cap, (size_t)U + 64)) { snprintf(ctx->err, sizeof ctx->err, "mfk_decode_bam: out of device memory for the inflated stream (%llu bytes)", (unsigned long long)U); return 1; }
     if (int rc = mfk_bgzf_inflate(ctx, d_comp, comp_bytes, blocks, n_blocks, S->u, (int64_t)U, nullptr, nullptr)) return rc;
+    if (block_crc && n_blocks) {   // the gzip trailers' CRC-32 against the inflated bytes, as the host reader checks them
+        arena_reset(ctx);
+        hipStream_t cs = ctx->stream;
+        mfk_bgzf_block *d_blocks = aalloc<mfk_bgzf_block>(ctx, (size_t)n_blocks);
+        uint32_t *d_expect = aalloc<uint32_t>(ctx, (size_t)n_blocks), *d_bad = aalloc<uint32_t>(ctx, 64);
+        if (!d_blocks || !d_expect || !d_bad) return 1;
+        HIPCHK(hipMemcpyAsync(d_blocks, blocks, (size_t)n_blocks * sizeof(mfk_bgzf_block), hipMemcpyHostToDevice, cs));
+        HIPCHK(hipMemcpyAsync(d_expect, block_crc, (size_t)n_blocks * 4, hipMemcpyHostToDevice, cs));
+        HIPCHK(hipMemsetAsync(d_bad, 0, 4, cs));
+        if (int rc = bgzf_crc32_launch(ctx, S->u, d_blocks, (uint32_t)n_blocks, d_expect, nullptr, d_bad, cs)) return rc;
+        uint32_t bad = 0;
+        HIPCHK(hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, cs));
+        HIPCHK(hipStreamSynchronize(cs));
+        if (bad) { snprintf(ctx->err, sizeof ctx->err, "BGZF checksum mismatch (corrupt file): %u of %lld blocks", bad, (long long)n_blocks); return 12; }
+    }
     S->U = U; S->first_off = (uint64_t)first_record_off; S->n_blocks = n_blocks; S->n_contigs = n_contigs; S->pool_mode = pool_mode; S->exclude_flags = exclude_flags;
     memset(sizes, 0, 8 * sizeof(int64_t));
     sizes[7] = (int64_t)U;

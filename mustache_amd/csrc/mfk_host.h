@@ -163,6 +163,7 @@ static inline unsigned nblocks(int64_t n, int threads) { int64_t b = (n + thread
 
 // device-wide primitives (rocPRIM) on the ctx stream, temp storage from the arena
 void mfk_decode_release(mfk_ctx *ctx);   // mfk_decode.hip: frees ctx->dec
+int bgzf_crc32_launch(mfk_ctx *ctx, const uint8_t *d_data, const mfk_bgzf_block *d_blocks, uint32_t n, const uint32_t *d_expect, uint32_t *d_crc_out, uint32_t *d_bad, hipStream_t st);   // mfk_inflate.hip
 int dev_sort_keys64(mfk_ctx *ctx, uint64_t *keys_in, uint64_t *keys_out, size_t n, int begin_bit, int end_bit);
 int dev_sort_pairs64(mfk_ctx *ctx, uint64_t *keys_in, uint64_t *keys_out, uint32_t *vals_in, uint32_t *vals_out, size_t n, int begin_bit, int end_bit);
 int dev_excl_scan32(mfk_ctx *ctx, const uint32_t *in, uint32_t *out, size_t n);   // out has n+1 entries: out[n] = total

@@ -136,10 +136,11 @@ def _write_index(path, bam_path, total_u, first_off, max_span, exclude_flags, ma
         pass
 
 
-def decode_bam(binding, path, pool="clipped", exclude_flags=0, device="cuda:0", index_out=None):
+def decode_bam(binding, path, pool="clipped", exclude_flags=0, device="cuda:0", index_out=None, check_crc=True):
     """BAM file -> DevicePacked.  pool: 'none' | 'clipped' | 'all'.  index_out: also write the record index of the file there
     (``pack.pack_bam``'s ``index_out``).  Raises PackError for what the packers reject, GpuDecodeUnverified when the caller
-    should use the host reader, MfkError for damaged files."""
+    should use the host reader, MfkError for damaged files (a block that does not inflate, or whose bytes do not have the
+    CRC-32 of its trailer: ``check_crc``, as the host reader checks it)."""
     import torch
     if pool not in POOL_MODES:
         raise ValueError("pool must be one of %s for the device decode" % (sorted(POOL_MODES),))
@@ -149,10 +150,11 @@ def decode_bam(binding, path, pool="clipped", exclude_flags=0, device="cuda:0", 
         raise MfkError("%s is not a BAM file (empty)" % path)
     mm = np.memmap(path, dtype=np.uint8, mode="r")
     nb, total = C.c_int64(), C.c_int64()
-    binding._check(binding.bgzf_block_table(binding.ctx, mm.ctypes.data, size, None, None, 0, C.byref(nb), C.byref(total)))
+    binding._check(binding.bgzf_block_table(binding.ctx, mm.ctypes.data, size, None, None, None, 0, C.byref(nb), C.byref(total)))
     blocks = np.zeros(nb.value, dtype=BGZF_BLOCK_DTYPE)
     file_off = np.zeros(nb.value, dtype=np.uint64)
-    binding._check(binding.bgzf_block_table(binding.ctx, mm.ctypes.data, size, blocks.ctypes.data, file_off.ctypes.data, nb.value, C.byref(nb), C.byref(total)))
+    crcs = np.zeros(max(nb.value, 1), dtype=np.uint32)
+    binding._check(binding.bgzf_block_table(binding.ctx, mm.ctypes.data, size, blocks.ctypes.data, file_off.ctypes.data, crcs.ctypes.data, nb.value, C.byref(nb), C.byref(total)))
     names, lens, first_off = _header(mm, blocks)
     if not names:
         raise MfkError("%s has no reference sequences in its header" % path)
@@ -165,8 +167,8 @@ def decode_bam(binding, path, pool="clipped", exclude_flags=0, device="cuda:0", 
     torch.cuda.synchronize()
     t2 = time.perf_counter()
     sizes = np.zeros(8, dtype=np.int64)
-    rc = binding.decode_bam(binding.ctx, comp.data_ptr(), size, blocks.ctypes.data, blocks.shape[0], first_off, len(names), POOL_MODES[pool],
-                            int(exclude_flags), sizes.ctypes.data)
+    rc = binding.decode_bam(binding.ctx, comp.data_ptr(), size, blocks.ctypes.data, crcs.ctypes.data if check_crc else None, blocks.shape[0], first_off,
+                            len(names), POOL_MODES[pool], int(exclude_flags), sizes.ctypes.data)
     if rc == 13:
         raise GpuDecodeUnverified(binding.last_error(binding.ctx).decode())
     if rc == 14:

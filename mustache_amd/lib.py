@@ -143,8 +143,9 @@ class Binding:
         if hasattr(self.so, prefix + "bgzf_inflate"):
             f("bgzf_inflate", C.c_int, [_p, _p, C.c_int64, _p, C.c_int64, _p, C.c_int64, _p, C.POINTER(C.c_int64)])
         if hasattr(self.so, prefix + "decode_bam"):
-            f("bgzf_block_table", C.c_int, [_p, _p, C.c_int64, _p, _p, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int64)])
-            f("decode_bam", C.c_int, [_p, _p, C.c_int64, _p, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_uint32, _p])
+            f("bgzf_block_table", C.c_int, [_p, _p, C.c_int64, _p, _p, _p, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int64)])
+            f("bgzf_crc32", C.c_int, [_p, _p, C.c_int64, _p, C.c_int64, _p])
+            f("decode_bam", C.c_int, [_p, _p, C.c_int64, _p, _p, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_uint32, _p])
             f("decode_bam_fetch", C.c_int, [_p, C.POINTER(MfkReads), _p, C.POINTER(C.c_int32), C.c_int64, _p, _p])
         if hasattr(self.so, prefix + "span_timing"):
             fn = getattr(self.so, prefix + "span_timing")

@@ -7,7 +7,7 @@ import struct
 import numpy as np
 import pytest
 
-from mustache_amd import bamio, gpudecode, lib, pack
+from mustache_amd import bamio, gpudecode, gpuinflate, lib, pack
 from mustache_amd.pack import ALL_FIELDS, pack_bam
 from mustache_amd.records import AlignedRead
 from mustache_amd.simulate import simulate_readset
@@ -138,3 +138,22 @@ def test_findflanks_through_the_device_decoder(hip, tmp_path, name):
     want = case["findflanks_tsv"].splitlines()      # the reference's own table (its sample column holds another name)
     assert [ln.split("\t")[1:] for ln in open(out_g).read().splitlines()] == [ln.split("\t")[1:] for ln in want]
     assert os.path.exists(out_g + ".mfki")
+
+
+def test_checksum_of_every_block_is_checked(hip, tmp_path):
+    """The host reader verifies the CRC-32 of every BGZF block; so does the device decode."""
+    genome, rs, truth = simulate_readset(seed=41, contig_lens=(30000,), n_insertions=2, coverage=60)
+    path = os.path.join(tmp_path, "a.bam")
+    bamio.write_bam(path, rs)
+    data = bytearray(open(path, "rb").read())
+    blocks, crcs, total = gpuinflate.bgzf_blocks(bytes(data))
+    assert blocks.shape[0] > 3
+    b = blocks[2]
+    trailer = int(b["comp_off"]) + int(b["comp_len"])             # CRC32 | ISIZE behind the deflate stream
+    data[trailer] ^= 0x01
+    open(path, "wb").write(bytes(data))
+    with pytest.raises(lib.MfkError, match="checksum"):
+        gpudecode.decode_bam(hip, path)
+    with pytest.raises(ValueError, match="checksum"):
+        pack_bam(path, pool="clipped")
+    assert gpudecode.decode_bam(hip, path, check_crc=False).n_reads > 0

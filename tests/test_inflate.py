@@ -176,3 +176,22 @@ def test_kernel_reports_damaged_blocks_and_stays_inside_its_ranges(hip):
     wrong["out_off"][3] = total
     with pytest.raises(lib.MfkError, match="outside the buffers"):
         hip.run_bgzf_inflate(comp, wrong, out[:total])
+
+
+@pytest.mark.gpu
+def test_device_crc32_equals_zlib(hip):
+    import torch
+    rng = np.random.default_rng(12)
+    sizes = [0, 1, 2, 15, 16, 17, 63, 64, 65, 1000, 1023, 1024, 1025, 4097, 65279, 65280, 65536, 33333, 7]
+    data = bytes(rng.integers(0, 256, sum(sizes) + 64, dtype=np.uint8))
+    for shift in (0, 1, 5, 16):                                   # every alignment of the first block
+        blocks = np.zeros(len(sizes), dtype=lib.BGZF_BLOCK_DTYPE)
+        o = shift
+        for k, n in enumerate(sizes):
+            blocks[k] = (0, o, 0, n)
+            o += n
+        dev = torch.frombuffer(bytearray(data), dtype=torch.uint8).to("cuda:0")
+        got = np.zeros(len(sizes), dtype=np.uint32)
+        hip._check(hip.bgzf_crc32(hip.ctx, dev.data_ptr(), dev.numel(), blocks.ctypes.data, len(sizes), got.ctypes.data))
+        want = [zlib.crc32(data[int(b["out_off"]):int(b["out_off"]) + int(b["out_len"])]) for b in blocks]
+        assert got.tolist() == want, shift
