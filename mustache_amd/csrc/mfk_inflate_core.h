@@ -195,10 +195,6 @@ MFK_HD inline int infl_symbol(uint64_t buf, const uint16_t *tab, int bits, const
     return -1;
 }
 
-MFK_TABLE uint16_t INFL_LBASE[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
-MFK_TABLE uint8_t INFL_LEXT[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
-MFK_TABLE uint16_t INFL_DBASE[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
-MFK_TABLE uint8_t INFL_DEXT[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
 MFK_TABLE uint8_t INFL_CLORD[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
 
 // Bytes written by one lane and read by another lane OF THE SAME WAVE go through memory on the device: the wave's stores so
@@ -303,15 +299,20 @@ MFK_HD inline int32_t infl_block(const uint8_t *in, uint32_t clen, uint8_t *out,
                 if (s == 256) break;
                 s -= 257;
                 if (s >= 29) return INFL_ERR_CODE;
-                const uint32_t len = INFL_LBASE[s] + (uint32_t)(buf & ((1u << INFL_LEXT[s]) - 1u));
-                INFL_TAKE(INFL_LEXT[s]);
+                // base and extra bits by arithmetic (RFC 1951 3.2.5 is regular): a table in memory costs a dependent load per match
+                const int lext = s < 8 || s == 28 ? 0 : (s >> 2) - 1;
+                const uint32_t lbase = s < 8 ? 3u + (uint32_t)s : (s == 28 ? 258u : ((4u + ((uint32_t)s & 3u)) << lext) + 3u);
+                const uint32_t len = lbase + (uint32_t)(buf & ((1u << lext) - 1u));
+                INFL_TAKE(lext);
                 INFL_FILL();
                 const int ds = infl_symbol(buf, T.dst, INFL_DBITS, T.dcount, T.dsym, &used);
                 if (ds < 0) return INFL_ERR_CODE;
                 INFL_TAKE(used);
                 if (ds >= 30) return INFL_ERR_DIST;
-                const uint32_t dist = INFL_DBASE[ds] + (uint32_t)(buf & ((1u << INFL_DEXT[ds]) - 1u));
-                INFL_TAKE(INFL_DEXT[ds]);
+                const int dext = ds < 4 ? 0 : (ds >> 1) - 1;
+                const uint32_t dbase = ds < 4 ? (uint32_t)ds + 1u : ((2u + ((uint32_t)ds & 1u)) << dext) + 1u;
+                const uint32_t dist = dbase + (uint32_t)(buf & ((1u << dext) - 1u));
+                INFL_TAKE(dext);
                 if (dist > opos) return INFL_ERR_DIST;
                 if (opos + len > ulen) return INFL_ERR_OUT;
                 // lane k copies byte k; a match that overlaps itself repeats its first `dist` bytes, all of them written before
