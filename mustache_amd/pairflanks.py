@@ -99,8 +99,9 @@ def genome_arrays(genome, contig_names):
     chunks, off = [], [0]
     for n in contig_names:
         s = genome.get(n, "")
-        chunks.append(np.frombuffer(s.encode("ascii"), dtype=np.uint8))
-        off.append(off[-1] + len(s))
+        a = s if isinstance(s, np.ndarray) else np.frombuffer(s.encode("ascii"), dtype=np.uint8)   # (read_fasta_arrays gives bytes already)
+        chunks.append(a)
+        off.append(off[-1] + a.shape[0])
     g = np.concatenate(chunks) if chunks else np.zeros(0, np.uint8)
     if g.size == 0:
         g = np.zeros(1, np.uint8)
@@ -185,7 +186,7 @@ def _pairflanks(flanksfile, bamfile, genome, max_direct_repeat_length, min_align
         from . import einverted
         einverted.find_einverted()          # fail before any work when the executable is missing
     import torch
-    from .bamio import BamReader, read_fasta
+    from .bamio import BamReader, read_fasta_arrays
     binding = _lib.load(int(str(device).split(":")[1]) if ":" in str(device) else 0)
     params = _lib.make_params(max_direct_repeat_length=max_direct_repeat_length,
                               min_alignment_quality=min_alignment_quality,
@@ -195,7 +196,7 @@ def _pairflanks(flanksfile, bamfile, genome, max_direct_repeat_length, min_align
     import time
     t0 = time.perf_counter()
     flanks = pd.read_csv(flanksfile, sep="\t")                                 # pairflanks.py:23 (default NA parsing)
-    gen = read_fasta(genome)
+    gen = read_fasta_arrays(genome)
     with BamReader(bamfile) as bam:
         contig_names = [n for n, _ in bam.contigs]
         if flanks.shape[0] == 0:

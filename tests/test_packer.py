@@ -135,3 +135,23 @@ def test_clip_records_restate_the_columns():
     if empty is not None:
         r0, t0 = empty.clip_records()
         assert r0.shape[0] == 0 and t0.tolist() == [0]
+
+
+def test_fasta_arrays_equal_the_line_reader(tmp_path):
+    """bamio.read_fasta_arrays (no Python loop over the lines) against bamio.read_fasta, odd files included."""
+    import os
+    from mustache_amd import bamio
+    rng = np.random.default_rng(2)
+    seq = lambda n: "".join(rng.choice(list("ACGTNacgtn"), n))
+    texts = [">c1 some description\n" + "\n".join(seq(60) for _ in range(50)) + "\n>c2\n" + seq(17) + "\n>empty\n>c4\n" + seq(200),   # no newline at the end
+             ">w\r\n" + seq(60) + "\r\n" + seq(12) + "\r\n",                                    # CRLF
+             ">b\n  " + seq(10) + " \n\t" + seq(5) + "\n\n>c\n" + seq(8) + "\n",                  # blanks: the strip rule
+             "", ">only_header", "no header line\n>x\nAC>GT\nA\n"]
+    for k, t in enumerate(texts):
+        path = os.path.join(tmp_path, "f%d.fa" % k)
+        open(path, "w", newline="").write(t)
+        want = bamio.read_fasta(path)
+        got = bamio.read_fasta_arrays(path)
+        assert list(got) == list(want), k
+        for name in want:
+            assert got[name].tobytes().decode() == want[name], (k, name)
