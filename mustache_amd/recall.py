@@ -58,13 +58,24 @@ def recall_packed(binding, reads_struct, contig_names, params, pairs, output_fil
 
 
 def _recall(pairsfile, bamfile, min_alignment_quality, min_alignment_inner_length, large_insertion_cutoff, output_file,
-            device="cuda:0", verbose=True):
-    """Drop-in for reference recall.py:15-28 (same positional arguments)."""
+            device="cuda:0", verbose=True, decoder="gpu"):
+    """Drop-in for reference recall.py:15-28 (same positional arguments).  ``decoder`` as in ``_findflanks``: "gpu" (the BAM is
+    decoded on the device, gpudecode.py) or "native" (host threads, libmfkio.so); same arrays."""
     pairs = pd.read_csv(pairsfile, sep="\t")
     binding = _lib.load(int(str(device).split(":")[1]) if ":" in str(device) else 0)
     params = _lib.make_params(min_alignment_quality=min_alignment_quality,
                               min_alignment_inner_length=min_alignment_inner_length,
                               large_insertion_cutoff=large_insertion_cutoff)
-    packed = pack_bam(bamfile, pool="none")        # libmfkio.so: multi-threaded BGZF inflate + packing
+    packed = None
+    if decoder == "gpu":
+        from .gpudecode import GpuDecodeUnverified, decode_bam
+        try:
+            packed = decode_bam(binding, bamfile, pool="none", device=device)
+        except GpuDecodeUnverified as e:
+            log("device decode: %s; reading the file with the host reader instead" % e)
+    elif decoder != "native":
+        raise ValueError("decoder must be 'gpu' or 'native', not %r" % (decoder,))
+    if packed is None:
+        packed = pack_bam(bamfile, pool="none")        # libmfkio.so: multi-threaded BGZF inflate + packing
     rs = device_reads(binding, packed, device, clip_rec=False)
     return recall_packed(binding, rs, packed.contig_names, params, pairs, output_file, verbose)
