@@ -42,7 +42,8 @@ _NP = {"ref_start": np.int32, "ref_end": np.int32, "link": np.int32, "contig_id"
 
 
 class GpuDecodeUnverified(MfkError):
-    """A guessed record boundary did not verify on the device: decode this file with the host reader."""
+    """Decode this file with the host reader: a guessed record boundary did not verify on the device, or the file (its
+    compressed bytes, its inflated stream and the per-record work arrays) does not fit the device's free memory."""
 
 
 class DevicePacked:
@@ -161,16 +162,20 @@ def decode_bam(binding, path, pool="clipped", exclude_flags=0, device="cuda:0", 
     if len(names) > 65535:
         raise PackError("more than 65535 contigs")
     t1 = time.perf_counter()
-    with warnings.catch_warnings():
-        warnings.simplefilter("ignore")         # (the mapping is read-only; the tensor is only read)
-        comp = torch.from_numpy(np.asarray(mm)).to(device)
-    torch.cuda.synchronize()
+    try:
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")         # (the mapping is read-only; the tensor is only read)
+            comp = torch.from_numpy(np.asarray(mm)).to(device)
+        torch.cuda.synchronize()
+    except torch.cuda.OutOfMemoryError:
+        raise GpuDecodeUnverified("no room on the device for the file (%d bytes)" % size)
     t2 = time.perf_counter()
     sizes = np.zeros(8, dtype=np.int64)
     rc = binding.decode_bam(binding.ctx, comp.data_ptr(), size, blocks.ctypes.data, crcs.ctypes.data if check_crc else None, blocks.shape[0], first_off,
                             len(names), POOL_MODES[pool], int(exclude_flags), sizes.ctypes.data)
-    if rc == 13:
-        raise GpuDecodeUnverified(binding.last_error(binding.ctx).decode())
+    msg = binding.last_error(binding.ctx).decode() if rc else ""
+    if rc == 13 or (rc == 1 and "out of device memory" in msg):     # (a file too large to decode in one piece: the host reader streams it)
+        raise GpuDecodeUnverified(msg)
     if rc == 14:
         raise PackError("%s (alignment record %d of the file)" % (_REJECT.get(int(sizes[1]), "rejected record"), int(sizes[0])))
     binding._check(rc)
