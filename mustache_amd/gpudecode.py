@@ -12,6 +12,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 import struct
+import threading
 import time
 import warnings
 import zlib
@@ -151,24 +152,50 @@ def decode_bam(binding, path, pool="clipped", exclude_flags=0, device="cuda:0", 
         raise MfkError("%s is not a BAM file (empty)" % path)
     mm = np.memmap(path, dtype=np.uint8, mode="r")
     nb, total = C.c_int64(), C.c_int64()
-    binding._check(binding.bgzf_block_table(binding.ctx, mm.ctypes.data, size, None, None, None, 0, C.byref(nb), C.byref(total)))
-    blocks = np.zeros(nb.value, dtype=BGZF_BLOCK_DTYPE)
-    file_off = np.zeros(nb.value, dtype=np.uint64)
-    crcs = np.zeros(max(nb.value, 1), dtype=np.uint32)
-    binding._check(binding.bgzf_block_table(binding.ctx, mm.ctypes.data, size, blocks.ctypes.data, file_off.ctypes.data, crcs.ctypes.data, nb.value, C.byref(nb), C.byref(total)))
-    names, lens, first_off = _header(mm, blocks)
-    if not names:
-        raise MfkError("%s has no reference sequences in its header" % path)
-    if len(names) > 65535:
-        raise PackError("more than 65535 contigs")
-    t1 = time.perf_counter()
-    try:
-        with warnings.catch_warnings():
-            warnings.simplefilter("ignore")         # (the mapping is read-only; the tensor is only read)
-            comp = torch.from_numpy(np.asarray(mm)).to(device)
-        torch.cuda.synchronize()
-    except torch.cuda.OutOfMemoryError:
+
+    def table(cap):
+        blocks = np.zeros(cap, dtype=BGZF_BLOCK_DTYPE)
+        file_off = np.zeros(cap, dtype=np.uint64)
+        crcs = np.zeros(max(cap, 1), dtype=np.uint32)
+        binding._check(binding.bgzf_block_table(binding.ctx, mm.ctypes.data, size, blocks.ctypes.data, file_off.ctypes.data, crcs.ctypes.data, cap, C.byref(nb), C.byref(total)))
+        return blocks, file_off, crcs
+    if size < 28 or bytes(mm[:4]) != b"\x1f\x8b\x08\x04":
+        table(0)                         # raises: not a BGZF file (before anything is copied anywhere)
+    # The file's bytes go up as they are, on a thread of their own; the walk over the block headers and the header of the BAM,
+    # which need nothing from the device, happen meanwhile.
+    box = {}
+
+    def upload():
+        try:
+            box["comp"] = torch.from_numpy(np.asarray(mm)).to(device)
+            torch.cuda.synchronize(device)
+        except BaseException as e:       # (handed to the calling thread below)
+            box["err"] = e
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")  # (the mapping is read-only; the tensor is only read)
+        th = threading.Thread(target=upload)
+        th.start()
+        try:
+            cap = size // 8192 + 1024    # one walk when the blocks average 8 KiB or more (they do), else a second
+            blocks, file_off, crcs = table(cap)
+            if nb.value > cap:
+                blocks, file_off, crcs = table(nb.value)
+            blocks, file_off, crcs = blocks[:nb.value], file_off[:nb.value], crcs[:max(nb.value, 1)]
+            if total.value >= 1 << 34:   # (32-bit block offsets in the packed layout: the host reader takes such a file in passes)
+                raise GpuDecodeUnverified("%d inflated bytes: more than the device decode takes in one piece" % total.value)
+            names, lens, first_off = _header(mm, blocks)
+            if not names:
+                raise MfkError("%s has no reference sequences in its header" % path)
+            if len(names) > 65535:
+                raise PackError("more than 65535 contigs")
+            t1 = time.perf_counter()
+        finally:
+            th.join()
+    if isinstance(box.get("err"), torch.cuda.OutOfMemoryError):
         raise GpuDecodeUnverified("no room on the device for the file (%d bytes)" % size)
+    if "err" in box:
+        raise box["err"]
+    comp = box.pop("comp")
     t2 = time.perf_counter()
     sizes = np.zeros(8, dtype=np.int64)
     rc = binding.decode_bam(binding.ctx, comp.data_ptr(), size, blocks.ctypes.data, crcs.ctypes.data if check_crc else None, blocks.shape[0], first_off,

@@ -30,13 +30,16 @@ def flanks_to_table(flanks: pd.DataFrame, contig_names):
     if -1 in ids:
         raise KeyError("contig %r of the flanks file is not in the BAM header" % contigs[ids.index(-1)])
     tab["contig_id"] = ids
-    tab["pos"] = [int(p) for p in flanks["pos"].tolist()]
+    def ints(c):                # an integer column as it is; anything else value by value, so that a NaN still raises
+        v = flanks[c].to_numpy()
+        return v if v.dtype.kind in "iu" else [int(x) for x in v.tolist()]
+    tab["pos"] = ints("pos")
     orient = flanks["orient"].to_numpy(dtype=object)
     tab["orient"] = np.where(orient == "5p", 5, np.where(orient == "3p", 3, 0))
     for c in ("softclip_count_5p", "softclip_count_3p", "runthrough_count", "small_insertion_count_5p",
               "small_insertion_count_3p", "large_insertion_count_5p", "large_insertion_count_3p", "deletion_count",
               "upstream_deletion_count", "downstream_deletion_count", "total_count", "consensus_softclip_count"):
-        tab[c] = [int(v) for v in flanks[c].tolist()]
+        tab[c] = ints(c)
     seqs = [str(s).encode("ascii") for s in flanks["consensus_seq"].tolist()]
     lens = np.fromiter((len(s) for s in seqs), dtype=np.int64, count=len(seqs))
     tab["seq_len"] = lens
@@ -117,8 +120,9 @@ def contig_ranks(contig_names):
 
 
 def pairflanks_packed(binding, reads_struct, contig_names, params, flanks: pd.DataFrame, genome_dev, genome_off,
-                      output_file=None, verbose=True, ir_backend="builtin", ir_detector=None):
-    """``_pairflanks`` after the inputs are on the device.  ``flanks`` is the frame read from the findflanks TSV.
+                      output_file=None, verbose=True, ir_backend="builtin", ir_detector=None, table=None):
+    """``_pairflanks`` after the inputs are on the device.  ``flanks`` is the frame read from the findflanks TSV
+    (``table``: its ``flanks_to_table`` when the caller has made it already).
     ``ir_backend``: "builtin" = the library's own inverted-repeat detector, "einverted" = run EMBOSS
     einverted per candidate pair like the reference does and pass its repeats to the library."""
     if flanks.shape[0] == 0:                                                   # pairflanks.py:32-40 (quirk P12)
@@ -129,7 +133,7 @@ def pairflanks_packed(binding, reads_struct, contig_names, params, flanks: pd.Da
         if output_file:
             flank_pairs.to_csv(output_file, sep="\t", index=False)
         return flank_pairs
-    tab, seqs = flanks_to_table(flanks, contig_names)
+    tab, seqs = table if table is not None else flanks_to_table(flanks, contig_names)
     if ir_backend == "einverted":
         from . import einverted
         binding.set_pair_ir(*einverted.ir_table(tab, seqs, int(params.max_direct_repeat_length), detector=ir_detector))
@@ -201,7 +205,8 @@ def _pairflanks(flanksfile, bamfile, genome, max_direct_repeat_length, min_align
         contig_names = [n for n, _ in bam.contigs]
         if flanks.shape[0] == 0:
             return pairflanks_packed(binding, None, contig_names, params, flanks, None, None, output_file, verbose, ir_backend)
-        tab, _ = flanks_to_table(flanks, contig_names)
+        table = flanks_to_table(flanks, contig_names)
+        tab = table[0]
         g, goff = genome_arrays(gen, contig_names)
         glen = np.diff(goff)
         regions = candidate_regions(tab, max_direct_repeat_length, glen)
@@ -221,7 +226,7 @@ def _pairflanks(flanksfile, bamfile, genome, max_direct_repeat_length, min_align
     gdev = torch.from_numpy(g).to(device)
     torch.cuda.synchronize()
     t2 = time.perf_counter()
-    out = pairflanks_packed(binding, rs, contig_names, params, flanks, gdev, goff, output_file, verbose, ir_backend)
+    out = pairflanks_packed(binding, rs, contig_names, params, flanks, gdev, goff, output_file, verbose, ir_backend, table=table)
     t3 = time.perf_counter()
     st = getattr(packed, "io_stats", None) or {}
     from . import findflanks as _ff
