@@ -157,3 +157,25 @@ def test_checksum_of_every_block_is_checked(hip, tmp_path):
     with pytest.raises(ValueError, match="checksum"):
         pack_bam(path, pool="clipped")
     assert gpudecode.decode_bam(hip, path, check_crc=False).n_reads > 0
+
+
+def test_truncated_and_damaged_files_fail_like_the_host_reader(hip, tmp_path):
+    """A file cut in the middle of a block, one cut between blocks (no EOF marker, a record cut off) and one with a damaged
+    deflate stream: an error from both readers, never a table (the upload thread is joined before the error leaves)."""
+    genome, rs, truth = simulate_readset(seed=42, contig_lens=(30000,), n_insertions=2, coverage=60)
+    path = os.path.join(tmp_path, "a.bam")
+    bamio.write_bam(path, rs)
+    data = open(path, "rb").read()
+    blocks, crcs, total = gpuinflate.bgzf_blocks(data)
+    assert blocks.shape[0] > 4
+    cut_mid = int(blocks[3]["comp_off"]) + int(blocks[3]["comp_len"]) // 2
+    cut_between = int(blocks[3]["comp_off"]) - 18                 # (the 18-byte header of block 3 starts here)
+    damaged = bytearray(data)
+    damaged[int(blocks[2]["comp_off"]) + 7] ^= 0xFF
+    for name, body in (("mid", data[:cut_mid]), ("between", data[:cut_between]), ("damaged", bytes(damaged))):
+        p = os.path.join(tmp_path, name + ".bam")
+        open(p, "wb").write(body)
+        with pytest.raises((lib.MfkError, ValueError)):
+            gpudecode.decode_bam(hip, p)
+        with pytest.raises((lib.MfkError, ValueError)):
+            pack_bam(p, pool="clipped")
