@@ -347,6 +347,59 @@ def end_to_end(n_records, tmp, device):
                 pass
 
 
+def table_digest(ff, pf):
+    h = hashlib.sha256()
+    for a in (ff["flanks"].tobytes(), ff["seqs"], pf["pairs"].tobytes(), pf["strs"]):
+        h.update(a)
+    return h.hexdigest()[:16]
+
+
+def concurrent_contexts(hip, reads, params, ranks, g_dev, goff, n_reads, contexts, steps, device_id):
+    """The same fused call from `contexts` host threads at once, each with a library context of its own (own streams, arena and
+    pinned buffers) on the same resident inputs: what a cohort run does with several samples per GPU (the reference: one process
+    per sample under `snakemake --cores`, main.py:44).  One context's step is a chain of short launches and five read-backs that
+    leaves most of the device idle; the other contexts' chains run in the gaps.  Reported beside `value`, which stays one call
+    at a time."""
+    import threading
+    import torch
+    from mustache_amd import lib
+    ctxs = [hip] + [lib.Binding(lib.LIB_PATH, "mfk_", device_id) for _ in range(contexts - 1)]
+    for c in ctxs:
+        c.span_timing(False)
+        for _ in range(3):
+            ff, pf = c.run_flankpairs(reads, params, ranks, g_dev, goff)
+    want = table_digest(ff, pf)
+    got, errs = [None] * len(ctxs), []
+    gate = threading.Barrier(len(ctxs) + 1)
+
+    def work(i):
+        try:
+            gate.wait()
+            for _ in range(steps):
+                ff_, pf_ = ctxs[i].run_flankpairs(reads, params, ranks, g_dev, goff)
+            got[i] = table_digest(ff_, pf_)
+        except BaseException as e:      # noqa: BLE001 -- reported in the JSON line
+            errs.append(repr(e))
+    ths = [threading.Thread(target=work, args=(i,)) for i in range(len(ctxs))]
+    torch.cuda.synchronize()
+    for t in ths:
+        t.start()
+    gate.wait()
+    t0 = time.perf_counter()
+    for t in ths:
+        t.join()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    hip.span_timing(True)
+    for c in ctxs[1:]:
+        c.close()
+    return {"contexts": contexts, "steps": steps * contexts, "ms_per_step": round(dt / (steps * contexts) * 1e3, 4),
+            "value": round(n_reads * steps * contexts / dt, 1), "unit": "reads/s", "tables_equal": bool(not errs and all(d == want for d in got)),
+            "errors": errs,
+            "what": "the fused call from %d host threads at once, one library context each, same resident inputs; every context's tables "
+                    "compared with the single-context ones (sha256); `value` above stays one call at a time" % contexts}
+
+
 def launch_ranks(n, argv, launch_only):
     """`python bench.py --gpus N` without an external launcher: this process starts N fresh child processes of the same
     script (one rank per GPU: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set, as torch.distributed.run would),
@@ -409,10 +462,11 @@ def main():
     ap.add_argument("--table-configs", default="C1_ecoli_100x,C3_klebsiella,C4_ecoli_batch,C5_meta_50mb",
                     help="other configs measured for the `configs` table at N = 1 ('' = none)")
     ap.add_argument("--end-to-end-reads", type=int, default=4_000_000, help="records of the BAM file of the end_to_end leg (0 = skip)")
-    ap.add_argument("--quick", action="store_true", help="only the timed region and the roofline (no CPU legs, no configs table, no end-to-end leg)")
+    ap.add_argument("--contexts", type=int, default=3, help="N = 1: the `concurrent_contexts` leg runs the same steps from this many host threads at once, one library context each (1 = skip)")
+    ap.add_argument("--quick", action="store_true", help="only the timed region and the roofline (no CPU legs, no configs table, no end-to-end leg, no concurrent contexts)")
     args = ap.parse_args()
     if args.quick:
-        args.no_cpu_baseline, args.table_configs, args.end_to_end_reads = True, "", 0
+        args.no_cpu_baseline, args.table_configs, args.end_to_end_reads, args.contexts = True, "", 0, 1
 
     # ---- ranks: an external launcher (WORLD_SIZE set) or our own (N children of this script) -----------------------------
     env_world = os.environ.get("WORLD_SIZE")
@@ -631,6 +685,8 @@ def main():
                           "device_ms_per_step": round(dev_ms, 4) if dev_ms else None, "generate_s": round(gen_s, 1)},
                "roofline": roofline, "cpu_baseline": cpu}
         if world == 1:
+            if args.contexts > 1 and not sharded:
+                out["concurrent_contexts"] = concurrent_contexts(hip, reads, params, ranks, g_dev, goff, reads_here, args.contexts, args.steps, local_rank)
             del reads
             torch.cuda.empty_cache()
             if sample is not None:

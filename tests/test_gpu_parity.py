@@ -286,3 +286,20 @@ def test_chained_scan_epoch_wrap(hip, oracle, monkeypatch):
         assert len(want["flanks"]) >= 10
     finally:
         own.close()
+
+
+@pytest.mark.gpu
+def test_library_contexts_in_concurrent_threads_give_the_same_tables(hip):
+    """Two more contexts on the same GPU, a host thread each, all three running the fused call on the same resident inputs at
+    once (a cohort run with several samples per GPU): every context's tables equal the single-context ones."""
+    import torch
+    import bench
+    from mustache_amd import lib as _lib, pairflanks as pfh
+    from mustache_amd.findflanks import device_reads
+    from mustache_amd.synth import synth_packed
+    packed, genome, truth = synth_packed(contig_lens=(120000, 30000), n_insertions=12, coverage=120, seed=77, pool="all")
+    g, goff = pfh.genome_arrays(genome, packed.contig_names)
+    reads = device_reads(hip, packed, "cuda:0")
+    g_dev = torch.from_numpy(g).to("cuda:0")
+    r = bench.concurrent_contexts(hip, reads, _lib.make_params(), pfh.contig_ranks(packed.contig_names), g_dev, goff, packed.n_reads, 3, 15, 0)
+    assert r["tables_equal"] and not r["errors"] and r["steps"] == 45
