@@ -155,3 +155,27 @@ def test_fasta_arrays_equal_the_line_reader(tmp_path):
         assert list(got) == list(want), k
         for name in want:
             assert got[name].tobytes().decode() == want[name], (k, name)
+
+
+def test_flank_table_from_the_tsv_frame():
+    """pairflanks' table of the findflanks TSV: integer columns are taken as they are, anything else value by value (so a
+    hole in a count column is an error, as int(nan) is in the reference's row loop), unknown contigs are an error."""
+    import io
+    import pandas as pd
+    from mustache_amd import pairflanks as pfh
+    case = util.load_json("sim_a")
+    flanks = pd.read_csv(io.StringIO(case["findflanks_tsv"]), sep="\t")
+    names = sorted(set(str(c) for c in flanks["contig"]))
+    tab, seqs = pfh.flanks_to_table(flanks, names)
+    assert len(tab) == len(flanks) > 0
+    assert tab["pos"].tolist() == [int(p) for p in flanks["pos"]] and tab["total_count"].tolist() == [int(v) for v in flanks["total_count"]]
+    assert tab["orient"].tolist() == [5 if o == "5p" else 3 for o in flanks["orient"]]
+    assert bytes(seqs) == "".join(flanks["consensus_seq"]).encode() and int(tab["seq_len"].sum()) == len(seqs)
+    as_float = flanks.copy()
+    as_float["runthrough_count"] = as_float["runthrough_count"].astype(float)          # whole numbers in a float column: fine
+    assert np.array_equal(pfh.flanks_to_table(as_float, names)[0], tab)
+    as_float.loc[0, "runthrough_count"] = np.nan
+    with pytest.raises(ValueError):
+        pfh.flanks_to_table(as_float, names)
+    with pytest.raises(KeyError):
+        pfh.flanks_to_table(flanks, ["some_other_contig"])
