@@ -201,3 +201,53 @@ def cohort_table(per_sample, sample_numbers=None, device=None, binding=None):
         off += len(t["seqs"])
     mine = np.concatenate(rows) if rows else np.zeros(0, dtype=_lib.FLANK_DTYPE)
     return allgather_flanks(mine, b"".join(blobs), device, binding=binding)
+
+
+def flankpairs_concurrent(samples, params, device="cuda:0", contexts=3):
+    """Samples that are NOT run as one batch (different parameters per call site, samples arriving one by one, a sample too
+    large to concatenate): each is one fused findflanks + pairflanks call, and ``contexts`` host threads with a library
+    context each take them from a queue, so the launch chains of several samples share the device (a deep isolate's step
+    leaves most of it idle: three contexts run three samples in the time of 1.6).  The reference runs
+    one process per sample (Snakefile:64-109); on a GPU that is the wrong unit, processes take turns.
+
+    samples: list of (PackedReads or gpudecode.DevicePacked, genome bytes as uint8 array, genome offsets) as
+    ``pairflanks.genome_arrays`` makes them.  Returns [(findflanks result, pairflanks result)] in the order of ``samples``;
+    the first exception of any worker is raised after all have stopped."""
+    import threading
+    import torch
+    from .findflanks import device_reads
+    from .pairflanks import contig_ranks
+    dev_id = int(str(device).split(":")[1]) if ":" in str(device) else 0
+    n = len(samples)
+    out, errs = [None] * n, []
+    lock = threading.Lock()
+    nxt = [0]
+
+    def work(k):
+        binding = None
+        try:
+            binding = _lib.load(dev_id) if k == 0 else _lib.Binding(_lib.LIB_PATH, "mfk_", dev_id)
+            while not errs:
+                with lock:
+                    i = nxt[0]
+                    nxt[0] += 1
+                if i >= n:
+                    break
+                packed, g, goff = samples[i]
+                reads = device_reads(binding, packed, device)
+                g_dev = torch.from_numpy(np.ascontiguousarray(g)).to(device)
+                out[i] = binding.run_flankpairs(reads, params, contig_ranks(packed.contig_names), g_dev, goff)
+                del reads, g_dev
+        except BaseException as e:      # noqa: BLE001 -- raised by the caller's thread below
+            errs.append(e)
+        finally:
+            if k and binding is not None:
+                binding.close()
+    ths = [threading.Thread(target=work, args=(k,)) for k in range(max(1, min(int(contexts), n)))]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    if errs:
+        raise errs[0]
+    return out

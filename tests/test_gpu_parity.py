@@ -303,3 +303,32 @@ def test_library_contexts_in_concurrent_threads_give_the_same_tables(hip):
     g_dev = torch.from_numpy(g).to("cuda:0")
     r = bench.concurrent_contexts(hip, reads, _lib.make_params(), pfh.contig_ranks(packed.contig_names), g_dev, goff, packed.n_reads, 3, 15, 0)
     assert r["tables_equal"] and not r["errors"] and r["steps"] == 45
+
+
+@pytest.mark.gpu
+def test_samples_over_concurrent_contexts_equal_their_own_runs(hip):
+    """cohort.flankpairs_concurrent: seven samples of different size over three contexts, results in sample order and equal
+    to each sample's own run; a failing sample stops the queue and its error reaches the caller."""
+    from mustache_amd import cohort
+    from mustache_amd.synth import synth_packed
+    samples = []
+    for k in range(7):
+        packed, genome, truth = synth_packed(contig_lens=(40000 + 9000 * k, 12000), n_insertions=3 + k, coverage=40 + 10 * k, seed=300 + k, pool="all")
+        g, goff = pfh.genome_arrays(genome, packed.contig_names)
+        samples.append((packed, g, goff))
+    params = lib.make_params()
+    got = cohort.flankpairs_concurrent(samples, params, "cuda:0", contexts=3)
+    assert len(got) == 7
+    import torch
+    for (packed, g, goff), (ff, pf) in zip(samples, got):
+        reads = device_reads(hip, packed, "cuda:0")
+        wf, wp = hip.run_flankpairs(reads, params, pfh.contig_ranks(packed.contig_names), torch.from_numpy(g).to("cuda:0"), goff)
+        assert len(wf["flanks"]) > 0
+        assert np.array_equal(ff["flanks"], wf["flanks"]) and ff["seqs"] == wf["seqs"]
+        assert np.array_equal(pf["pairs"], wp["pairs"]) and pf["strs"] == wp["strs"]
+    bad = list(samples)
+    bad[2] = (None, samples[2][1], samples[2][2])                      # (fails on the host, before anything reaches the device)
+    with pytest.raises(AttributeError):
+        cohort.flankpairs_concurrent(bad, params, "cuda:0", contexts=3)
+    again = cohort.flankpairs_concurrent(samples[:2], params, "cuda:0", contexts=3)      # the contexts are usable afterwards
+    assert np.array_equal(again[1][0]["flanks"], got[1][0]["flanks"])
