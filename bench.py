@@ -363,36 +363,40 @@ def concurrent_contexts(hip, reads, params, ranks, g_dev, goff, n_reads, context
     import threading
     import torch
     from mustache_amd import lib
-    ctxs = [hip] + [lib.Binding(lib.LIB_PATH, "mfk_", device_id) for _ in range(contexts - 1)]
-    for c in ctxs:
-        c.span_timing(False)
-        for _ in range(3):
-            ff, pf = c.run_flankpairs(reads, params, ranks, g_dev, goff)
-    want = table_digest(ff, pf)
-    got, errs = [None] * len(ctxs), []
-    gate = threading.Barrier(len(ctxs) + 1)
+    ctxs = [hip]
+    try:
+        for _ in range(contexts - 1):
+            ctxs.append(lib.Binding(lib.LIB_PATH, "mfk_", device_id))
+        for c in ctxs:
+            c.span_timing(False)
+            for _ in range(3):
+                ff, pf = c.run_flankpairs(reads, params, ranks, g_dev, goff)
+        want = table_digest(ff, pf)
+        got, errs = [None] * len(ctxs), []
+        gate = threading.Barrier(len(ctxs) + 1)
 
-    def work(i):
-        try:
-            gate.wait()
-            for _ in range(steps):
-                ff_, pf_ = ctxs[i].run_flankpairs(reads, params, ranks, g_dev, goff)
-            got[i] = table_digest(ff_, pf_)
-        except BaseException as e:      # noqa: BLE001 -- reported in the JSON line
-            errs.append(repr(e))
-    ths = [threading.Thread(target=work, args=(i,)) for i in range(len(ctxs))]
-    torch.cuda.synchronize()
-    for t in ths:
-        t.start()
-    gate.wait()
-    t0 = time.perf_counter()
-    for t in ths:
-        t.join()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    hip.span_timing(True)
-    for c in ctxs[1:]:
-        c.close()
+        def work(i):
+            try:
+                gate.wait()
+                for _ in range(steps):
+                    ff_, pf_ = ctxs[i].run_flankpairs(reads, params, ranks, g_dev, goff)
+                got[i] = table_digest(ff_, pf_)
+            except BaseException as e:      # noqa: BLE001 -- reported in the JSON line
+                errs.append(repr(e))
+        ths = [threading.Thread(target=work, args=(i,)) for i in range(len(ctxs))]
+        torch.cuda.synchronize()
+        for t in ths:
+            t.start()
+        gate.wait()
+        t0 = time.perf_counter()
+        for t in ths:
+            t.join()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    finally:
+        hip.span_timing(True)
+        for c in ctxs[1:]:
+            c.close()
     return {"contexts": contexts, "steps": steps * contexts, "ms_per_step": round(dt / (steps * contexts) * 1e3, 4),
             "value": round(n_reads * steps * contexts / dt, 1), "unit": "reads/s", "tables_equal": bool(not errs and all(d == want for d in got)),
             "errors": errs,
@@ -685,8 +689,12 @@ def main():
                           "device_ms_per_step": round(dev_ms, 4) if dev_ms else None, "generate_s": round(gen_s, 1)},
                "roofline": roofline, "cpu_baseline": cpu}
         if world == 1:
+            # the legs below are reported beside the headline: a failure in one of them is a field of the line, not the end of the run
             if args.contexts > 1 and not sharded:
-                out["concurrent_contexts"] = concurrent_contexts(hip, reads, params, ranks, g_dev, goff, reads_here, args.contexts, args.steps, local_rank)
+                try:
+                    out["concurrent_contexts"] = concurrent_contexts(hip, reads, params, ranks, g_dev, goff, reads_here, args.contexts, args.steps, local_rank)
+                except Exception as e:      # noqa: BLE001
+                    out["concurrent_contexts"] = {"error": repr(e)}
             del reads
             torch.cuda.empty_cache()
             if sample is not None:
@@ -702,13 +710,19 @@ def main():
                 torch.cuda.empty_cache()
             rows = []
             for name in [c for c in args.table_configs.split(",") if c and c != args.config]:
-                rows.append(time_config(hip, name, args.pool, device, isolates=args.isolates))
+                try:
+                    rows.append(time_config(hip, name, args.pool, device, isolates=args.isolates))
+                except Exception as e:      # noqa: BLE001
+                    rows.append({"workload": name, "error": repr(e)})
             if rows or args.table_configs:
                 me = {"workload": args.config, "reads": reads_here, "ms_per_step": round(ms_per_step, 4), "reads_per_s": round(value, 1),
                       "steps": args.steps, "insertions": n_insertions, "flank_rows": int(len(ff["flanks"])), "pairs": int(len(pf["pairs"])), "pool": args.pool}
                 out["configs"] = [me] + rows
             if args.end_to_end_reads > 0:
-                out["end_to_end"] = end_to_end(args.end_to_end_reads, os.environ.get("TMPDIR", "/tmp"), device)
+                try:
+                    out["end_to_end"] = end_to_end(args.end_to_end_reads, os.environ.get("TMPDIR", "/tmp"), device)
+                except Exception as e:      # noqa: BLE001
+                    out["end_to_end"] = {"error": repr(e)}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
