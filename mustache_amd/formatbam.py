@@ -16,8 +16,9 @@ byte; nothing is decoded that does not have to be):
    dropped.  Same here.)
 3. ``samtools sort`` (samtools.py:21-30): by (reference id, position, strand), unmapped reads last; ties keep their
    input order here (samtools does not promise an order for them).  The ``@HD`` line says ``SO:coordinate``.
-4. ``samtools index`` (samtools.py:32-38): ``<out_bam>.bai`` with the binning index, the 16 kb linear index and the
-   count of reads without coordinates (SAM specification section 5.2).
+4. ``samtools index`` (samtools.py:32-38): ``<out_bam>.bai`` with the binning index (and htslib's metadata pseudo-bin 37450
+   per reference: the span of its records, its mapped / unmapped counts, what ``samtools idxstats`` reads), the 16 kb
+   linear index and the count of reads without coordinates (SAM specification section 5.2).
 
 The hot path does not need the index (the interval joins run on the GPU over the packed arrays); it is written so that
 the file is a drop-in for every other consumer of the reference's formatbam output.
@@ -34,6 +35,8 @@ import zlib
 import numpy as np
 
 from .bamio import _BGZF_EOF, _SEQ_LUT, _reg2bin, bgzf_block
+
+_META_BIN = 37450
 
 _BLOCK = 0xFF00
 _REF_CONSUMING = (0, 2, 3, 7, 8)     # M D N = X
@@ -336,11 +339,16 @@ def write_bam_and_index(path, text, contigs, records, procs=8):
     bins = [dict() for _ in range(n_ref)]
     linear = [dict() for _ in range(n_ref)]
     n_no_coor = 0
+    meta = [None] * n_ref                                                        # per reference: [first offset, last end, mapped, unmapped]
     for k, r in enumerate(records):
         ref_id, pos, l_name, n_cig, flag, _ = _core(r)
         if ref_id < 0 or pos < 0:
             n_no_coor += 1
             continue
+        if meta[ref_id] is None:
+            meta[ref_id] = [int(vbeg[k]), int(vend[k]), 0, 0]
+        meta[ref_id][1] = int(vend[k])
+        meta[ref_id][3 if flag & 4 else 2] += 1
         end = pos
         for c in struct.unpack_from("<%dI" % n_cig, r, 32 + l_name):
             if (c & 15) in _REF_CONSUMING:
@@ -358,11 +366,13 @@ def write_bam_and_index(path, text, contigs, records, procs=8):
                 linear[ref_id][w] = int(vbeg[k])
     out = [b"BAI\1", struct.pack("<i", n_ref)]
     for c in range(n_ref):
-        out.append(struct.pack("<i", len(bins[c])))
+        out.append(struct.pack("<i", len(bins[c]) + (1 if meta[c] else 0)))
         for b in sorted(bins[c]):
             out.append(struct.pack("<Ii", b, len(bins[c][b])))
             for beg, end in bins[c][b]:
                 out.append(struct.pack("<QQ", beg, end))
+        if meta[c]:   # the metadata pseudo-bin htslib writes (SAM specification 5.2: bin 37450 with two "chunks": the span of the
+            out.append(struct.pack("<IiQQQQ", _META_BIN, 2, *meta[c]))   # reference's records, its mapped / unmapped counts; idxstats reads it)
         n_intv = max(linear[c]) + 1 if linear[c] else 0
         out.append(struct.pack("<i", n_intv))
         offs, nxt = [0] * n_intv, 0

@@ -191,11 +191,22 @@ def test_index_points_at_the_records_of_each_bin(tmp_path):
     assert bai[:4] == b"BAI\1"
     n_ref, = struct.unpack_from("<i", bai, 4)
     assert n_ref == len(contigs)
-    o, n_chunks, seen = 8, 0, 0
+    o, n_chunks, seen, n_meta = 8, 0, 0, 0
+    names = [n for n, _ in contigs]
+    placed = [0] * n_ref                                                    # records per reference (all mapped here)
+    for r in bamio.BamReader(out):
+        placed[names.index(r.reference_name)] += 1
     for c in range(n_ref):
         n_bin, = struct.unpack_from("<i", bai, o); o += 4
         for _ in range(n_bin):
             b, n_chunk = struct.unpack_from("<Ii", bai, o); o += 8
+            if b == 37450:                                                  # metadata pseudo-bin: record span, mapped / unmapped counts
+                assert n_chunk == 2
+                ref_beg, ref_end, n_mapped, n_unmapped = struct.unpack_from("<QQQQ", bai, o); o += 32
+                assert ref_beg < ref_end and n_mapped == placed[c] > 0 and n_unmapped == 0
+                assert struct.unpack_from("<i", _bgzf_record_at(out, ref_beg), 0)[0] == c
+                n_meta += 1
+                continue
             for _ in range(n_chunk):
                 beg, end = struct.unpack_from("<QQ", bai, o); o += 16
                 assert beg < end
@@ -213,7 +224,7 @@ def test_index_points_at_the_records_of_each_bin(tmp_path):
                 assert ref_id == c
                 seen += 1
     n_no_coor, = struct.unpack_from("<Q", bai, o)
-    assert n_no_coor == 0 and o + 8 == len(bai) and n_chunks > 0 and seen > 0
+    assert n_no_coor == 0 and o + 8 == len(bai) and n_chunks > 0 and seen > 0 and n_meta == sum(1 for n in placed if n)
 
 
 def test_packers_skip_excluded_flags(tmp_path):
