@@ -7,7 +7,10 @@
 // symbol before it.  So all 64 lanes run the SAME decode (same instructions on the same values: no divergence, the table
 // reads are LDS broadcasts), and the lane index is used only where there is something to share out: filling the lookup
 // tables, holding the next 256 bytes of input (one dword per lane, fetched with a uniform readlane), and copying a match
-// (lane k copies byte k).  The host build is the same code with a wave of one lane.
+// (lane k copies byte k).  The host build is the same code with a wave of one lane.  Two things the device build adds, both
+// about instruction count (the kernel is bound by instruction issue, vector and scalar alike, not by memory): every branch
+// on a value that all lanes share is taken through INFL_U below, and runs of literals are decoded in a loop of their own
+// that holds nothing a literal does not need.
 //
 // Tables per decoder (4 KB, in LDS on the device): a 10-bit primary table for literal/length codes and a 9-bit one for
 // distance codes (entry = symbol << 4 | code length, 0 = a longer code), and for the rare longer codes the canonical
@@ -26,6 +29,15 @@
 #define INFL_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
 #else
 #define INFL_WAVE_SYNC() do { } while (0)
+#endif
+
+// A condition that is the same in every lane BY CONSTRUCTION (all lanes run the same decode) but not by anything the compiler
+// can prove: taken as "any lane says so" (a ballot) it becomes a scalar branch; left as a vector compare, every such branch is compiled as masked
+// divergent code (save the execution mask, branch if empty, restore), which was a good third of the kernel's instructions.
+#ifdef __HIP_DEVICE_COMPILE__
+#define INFL_U(c) (__builtin_amdgcn_ballot_w64((bool)(c)) != 0ull)   /* a vector compare into a scalar mask, and a scalar branch on it */
+#else
+#define INFL_U(c) (c)
 #endif
 
 #define INFL_LBITS 10
@@ -89,7 +101,7 @@ struct InflInput<64> {
     }
     __device__ void init(const uint8_t *p, uint32_t len, int lane) { in = p; n = len; load(0, lane); }
     __device__ uint32_t fetch32(uint32_t pos, int lane) {
-        if (pos < cbase || pos + 8 > cbase + 256) load(pos & ~3u, lane);   // wave-uniform
+        if (INFL_U(pos < cbase || pos + 8 > cbase + 256)) load(pos & ~3u, lane);   // wave-uniform
         const uint32_t rel = pos - cbase, idx = __builtin_amdgcn_readfirstlane((int)(rel >> 2));
         const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)chunk, (int)idx);
         const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)chunk, (int)idx + 1);
@@ -184,12 +196,12 @@ MFK_HD inline int infl_build(const uint8_t *lens, int n, uint16_t *tab, int bits
 // one symbol: primary table, else the canonical walk.  Returns the symbol or -1; *used = bits of the code.
 MFK_HD inline int infl_symbol(uint64_t buf, const uint16_t *tab, int bits, const uint16_t *count, const uint16_t *sym, int *used) {
     const uint16_t e = tab[buf & ((1u << bits) - 1u)];
-    if (e & 15) { *used = e & 15; return e >> 4; }
+    if (INFL_U(e & 15)) { *used = e & 15; return e >> 4; }
     int code = 0, first = 0, index = 0;
     for (int l = 1; l <= 15; l++) {
         code |= (int)((buf >> (l - 1)) & 1u);
         const int c = count[l];
-        if (code - c < first) { *used = l; return sym[index + (code - first)]; }
+        if (INFL_U(code - c < first)) { *used = l; return sym[index + (code - first)]; }
         index += c; first += c; first <<= 1; code <<= 1;
     }
     return -1;
@@ -221,7 +233,7 @@ MFK_HD inline int32_t infl_block(const uint8_t *in, uint32_t clen, uint8_t *out,
     uint32_t pos = 0;      // next input byte to put into the bit buffer
     uint32_t opos = 0;
     uint32_t seen = 0;     // out[0..seen) is known to have landed: a match that reads only from there need not wait for the stores behind it
-#define INFL_FILL() do { if (cnt <= 32) { buf |= (uint64_t)rd.fetch32(pos, lane) << cnt; cnt += 32; pos += 4; } } while (0)
+#define INFL_FILL() do { if (INFL_U(cnt <= 32)) { buf |= (uint64_t)rd.fetch32(pos, lane) << cnt; cnt += 32; pos += 4; } } while (0)
 #define INFL_TAKE(nb) do { buf >>= (nb); cnt -= (nb); } while (0)
     for (;;) {
         INFL_FILL();
@@ -285,20 +297,41 @@ MFK_HD inline int32_t infl_block(const uint8_t *in, uint32_t clen, uint8_t *out,
                 if (infl_build<WAVE>(T.lens, hlit, T.lit, INFL_LBITS, T.lcount, T.lsym, lane)) return INFL_ERR_LENS;
             }
             for (;;) {
+#ifdef __HIP_DEVICE_COMPILE__
+                // literals in a row, the common case: nothing in this loop that a literal does not need (every lane stores the
+                // same byte to the same address: one request, and no change of the execution mask)
+                // (one way out: a literal with no room left is found by the general code below as well.  After a refill the buffer
+                // holds 33 bits or more and a code of the primary table is at most INFL_LBITS = 10: three literals per refill check.)
+#define INFL_LITERAL()                                                                                                          \
+                    {                                                                                                           \
+                        const uint32_t e = T.lit[(uint32_t)buf & ((1u << INFL_LBITS) - 1u)];                                    \
+                        if (!INFL_U((e & 15u) != 0u && e < (256u << 4) && opos < ulen)) break;   /* a match, the end, a long code */ \
+                        out[opos] = (uint8_t)(e >> 4);                                                                          \
+                        opos++;                                                                                                 \
+                        INFL_TAKE((int)(e & 15u));                                                                              \
+                    }
+                for (;;) {
+                    INFL_FILL();
+                    INFL_LITERAL()
+                    INFL_LITERAL()
+                    INFL_LITERAL()
+                }
+#undef INFL_LITERAL
+#endif
                 INFL_FILL();
                 int used = 0;
                 int s = infl_symbol(buf, T.lit, INFL_LBITS, T.lcount, T.lsym, &used);
-                if (s < 0) return INFL_ERR_CODE;
+                if (INFL_U(s < 0)) return INFL_ERR_CODE;
                 INFL_TAKE(used);
-                if (s < 256) {
-                    if (opos >= ulen) return INFL_ERR_OUT;
+                if (INFL_U(s < 256)) {
+                    if (INFL_U(opos >= ulen)) return INFL_ERR_OUT;
                     if (lane == 0) out[opos] = (uint8_t)s;
                     opos++;
                     continue;
                 }
-                if (s == 256) break;
+                if (INFL_U(s == 256)) break;
                 s -= 257;
-                if (s >= 29) return INFL_ERR_CODE;
+                if (INFL_U(s >= 29)) return INFL_ERR_CODE;
                 // base and extra bits by arithmetic (RFC 1951 3.2.5 is regular): a table in memory costs a dependent load per match
                 const int lext = s < 8 || s == 28 ? 0 : (s >> 2) - 1;
                 const uint32_t lbase = s < 8 ? 3u + (uint32_t)s : (s == 28 ? 258u : ((4u + ((uint32_t)s & 3u)) << lext) + 3u);
@@ -306,18 +339,18 @@ MFK_HD inline int32_t infl_block(const uint8_t *in, uint32_t clen, uint8_t *out,
                 INFL_TAKE(lext);
                 INFL_FILL();
                 const int ds = infl_symbol(buf, T.dst, INFL_DBITS, T.dcount, T.dsym, &used);
-                if (ds < 0) return INFL_ERR_CODE;
+                if (INFL_U(ds < 0)) return INFL_ERR_CODE;
                 INFL_TAKE(used);
-                if (ds >= 30) return INFL_ERR_DIST;
+                if (INFL_U(ds >= 30)) return INFL_ERR_DIST;
                 const int dext = ds < 4 ? 0 : (ds >> 1) - 1;
                 const uint32_t dbase = ds < 4 ? (uint32_t)ds + 1u : ((2u + ((uint32_t)ds & 1u)) << dext) + 1u;
                 const uint32_t dist = dbase + (uint32_t)(buf & ((1u << dext) - 1u));
                 INFL_TAKE(dext);
-                if (dist > opos) return INFL_ERR_DIST;
-                if (opos + len > ulen) return INFL_ERR_OUT;
+                if (INFL_U(dist > opos)) return INFL_ERR_DIST;
+                if (INFL_U(opos + len > ulen)) return INFL_ERR_OUT;
                 // lane k copies byte k; a match that overlaps itself repeats its first `dist` bytes, all of them written before
                 const uint32_t src0 = opos - dist, src1 = src0 + (dist >= len ? len : dist);   // the bytes it reads: out[src0..src1)
-                if (src1 > seen) { infl_publish(); seen = opos; }
+                if (INFL_U(src1 > seen)) { infl_publish(); seen = opos; }
                 const uint8_t *from = out + src0;
                 for (uint32_t k = (uint32_t)lane; k < len; k += WAVE) out[opos + k] = from[dist >= len ? k : k % dist];
                 opos += len;
