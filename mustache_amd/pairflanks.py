@@ -199,17 +199,50 @@ def _pairflanks(flanksfile, bamfile, genome, max_direct_repeat_length, min_align
                               large_insertion_cutoff=large_insertion_cutoff)
     import time
     t0 = time.perf_counter()
-    flanks = pd.read_csv(flanksfile, sep="\t")                                 # pairflanks.py:23 (default NA parsing)
-    gen = read_fasta_arrays(genome)
-    with BamReader(bamfile) as bam:
+    # the FASTA is read on a thread of its own while the flank table is parsed and the BAM's regions are decoded
+    import threading
+    box = {}
+
+    def fasta():
+        try:
+            box["gen"] = read_fasta_arrays(genome)
+        except BaseException as e:      # noqa: BLE001 -- raised by the calling thread below
+            box["err"] = e
+    th = threading.Thread(target=fasta)
+    th.start()
+
+    def genome_of(contig_names):
+        th.join()
+        if "err" in box:
+            raise box["err"]
+        return genome_arrays(box["gen"], contig_names)
+    try:
+        flanks = pd.read_csv(flanksfile, sep="\t")                             # pairflanks.py:23 (default NA parsing)
+        bam = BamReader(bamfile)
+    except BaseException:
+        th.join()
+        raise
+    with bam:
         contig_names = [n for n, _ in bam.contigs]
         if flanks.shape[0] == 0:
+            th.join()
             return pairflanks_packed(binding, None, contig_names, params, flanks, None, None, output_file, verbose, ir_backend)
-        table = flanks_to_table(flanks, contig_names)
+        try:
+            table = flanks_to_table(flanks, contig_names)
+        except BaseException:
+            th.join()
+            raise
         tab = table[0]
-        g, goff = genome_arrays(gen, contig_names)
-        glen = np.diff(goff)
-        regions = candidate_regions(tab, max_direct_repeat_length, glen)
+        # Which reads are loaded is decided with the contig lengths of the BAM header (the reference clamps the direct-repeat
+        # window at len(genome[contig]), pairflanks.py:294-305; the kernel does, with the FASTA's offsets): a header length that
+        # differs from the FASTA's can only make a region larger, i.e. load reads that no window then uses.
+        if decoder == "native":
+            blen = np.asarray([max(int(n), 0) for _, n in bam.contigs], dtype=np.int64)
+            regions = candidate_regions(tab, max_direct_repeat_length, blen)
+            g = goff = None
+        else:
+            g, goff = genome_of(contig_names)
+            regions = candidate_regions(tab, max_direct_repeat_length, np.diff(goff))
         # only reads that can overlap a candidate region are packed; reads over a direct-repeat window carry bases
         if decoder == "native":
             packed = pack_bam(bamfile, pool="regions", regions=regions, exclude_flags=exclude_flags, index=index_path(flanksfile, record_index))
@@ -221,6 +254,8 @@ def _pairflanks(flanksfile, bamfile, genome, max_direct_repeat_length, min_align
             packed = _pack_regions_python(bam, contig_names, regions, exclude_flags)
         else:
             raise ValueError("decoder must be 'native' or 'python', not %r" % (decoder,))
+    if g is None:
+        g, goff = genome_of(contig_names)
     t1 = time.perf_counter()
     rs = device_reads(binding, packed, device, clip_rec=False)
     gdev = torch.from_numpy(g).to(device)
